@@ -1,0 +1,238 @@
+/*
+ * simmr_hip.h — C ABI of the MI355X-native simmr hot path (libsimmr_hip.so).
+ *
+ * This is the drop-in boundary for the per-read sampling / mutation path of
+ * genomicsoup/simmr.  The reference has no FFI: the seam is the call made once
+ * per run from simmr/src/main.rs:180-186 into
+ *     simulate::simulate_pe_reads      (simmr/src/simulate.rs:110-150)
+ *     simulate::simulate_long_reads    (simmr/src/simulate.rs:323-406)
+ * parameterised by the two trait objects
+ *     ErrorProfile      (simmr/src/error_profiles/base.rs:6-32)
+ *     AbundanceProfile  (simmr/src/abundance_profiles/base.rs:10-69).
+ * Every entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, no exceptions / unwinding across the boundary;
+ *   - every function returns 0 (SIMMR_OK) or a negative errno-style code and
+ *     simmr_last_error() gives the message (reference: Result<_, String>,
+ *     simulate.rs:165-170,205-210);
+ *   - one engine == one GPU == one host thread (not thread-safe), matching
+ *     the single-threaded reference;
+ *   - output buffers are caller-owned DEVICE pointers (hipMalloc / torch);
+ *     the plan step reports the sizes needed (the reference returns owned
+ *     Vec<SimulatedRead>, simulate.rs:119).
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry
+ *     point fails with SIMMR_ENODEV.
+ */
+#ifndef SIMMR_HIP_H
+#define SIMMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIMMR_ABI_VERSION 1
+
+/* status codes (negative errno values) */
+#define SIMMR_OK 0
+#define SIMMR_EINVAL (-22)  /* bad argument                                   */
+#define SIMMR_ENOMEM (-12)  /* device/host allocation failed                  */
+#define SIMMR_ENODEV (-19)  /* no usable gfx950 device / HIP runtime error    */
+#define SIMMR_ERANGE (-34)  /* output capacity too small / value out of range */
+#define SIMMR_ESTATE (-1)   /* call order violated (emit before plan, ...)    */
+#define SIMMR_EGENOME (-61) /* genome unusable (reference: Err(String) at
+                               simulate.rs:220-225 / infinite loop at :370)   */
+
+/* ErrorProfile implementations, reference cli.rs:62-70 + error_profiles/mod.rs */
+enum simmr_profile_kind {
+  SIMMR_PERFECT_SHORT = 0, /* error_profiles/perfect_short.rs */
+  SIMMR_MINIMAL_SHORT = 1, /* error_profiles/minimal_short.rs */
+  SIMMR_PERFECT_LONG = 2,  /* error_profiles/perfect_long.rs  */
+  SIMMR_MINIMAL_LONG = 3,  /* error_profiles/minimal_long.rs  */
+  SIMMR_CUSTOM = 4         /* error_profiles/custom_short.rs  */
+};
+
+/* Which generator feeds the per-base draws.
+ * REFERENCE: the reference's own streams — rand 0.8.5 StdRng (ChaCha12 keyed
+ *   by PCG32 seed expansion) consumed exactly as simulate.rs / the profiles
+ *   consume them.  Output is bit-identical to the reference for everything the
+ *   reference itself makes deterministic under --seed.
+ * PHILOX: counter-based Philox4x32-10 keyed by (seed, read, base); positions
+ *   and lengths still come from the reference streams, per-base Phred and
+ *   substitution draws do not.  Statistical tolerance only (BASELINE.json
+ *   north_star). */
+enum simmr_rng_mode { SIMMR_RNG_REFERENCE = 0, SIMMR_RNG_PHILOX = 1 };
+
+/* Long-read length policy (Appendix A Q5 of SURVEY.md).
+ * REFERENCE: with a seed, get_random_read_length(seed) (simulate.rs:358) is
+ *   the same value for every read of the run; reproduced exactly.
+ * PER_READ: every read draws its own Gamma length, contig and read seed from
+ *   a private StdRng keyed by mix(seed, read index).  This is what the
+ *   reference does without --seed (fresh entropy per call), made reproducible.
+ *   Selected automatically when has_seed == 0. */
+enum simmr_length_mode { SIMMR_LEN_REFERENCE = 0, SIMMR_LEN_PER_READ = 1 };
+
+/* Flattened ErrorProfile (trait: error_profiles/base.rs:6-32; construction:
+ * cli.rs:229-301).  Plain data, copied by the callee. */
+typedef struct simmr_error_profile {
+  uint32_t kind;        /* enum simmr_profile_kind                           */
+  uint32_t rng_mode;    /* enum simmr_rng_mode                               */
+  uint32_t length_mode; /* enum simmr_length_mode (long reads only)          */
+  uint16_t read_length; /* --read-length   (cli.rs:126)                      */
+  uint16_t insert_size; /* --insert-size   (cli.rs:143)                      */
+  uint8_t mean_phred;   /* --mean-phred-score (cli.rs:152)                   */
+  uint8_t reserved0[3];
+  double read_length_std; /* minimal-short: 15.0 (cli.rs:240)               */
+  double insert_size_std; /* minimal-short: 75.0 (cli.rs:239)               */
+  float gamma_shape;      /* (mean/std)^2, minimal_long.rs:68                */
+  float gamma_scale;      /* std^2/mean,   minimal_long.rs:69                */
+  const void* custom_model;    /* bincode ErrorModelParams (shared/encoding.rs:102-117) */
+  uint64_t custom_model_bytes;
+} simmr_error_profile;
+
+/* Contiguous range of global unit indices (pairs for PE, reads for long) that
+ * this engine / GPU generates.  Replaces nothing in the reference (it has no
+ * sharding); ids stay identical to the single-process run. */
+typedef struct simmr_range {
+  uint64_t first;
+  uint64_t count;
+} simmr_range;
+
+/* Result of a plan step: what the emit step will write. */
+typedef struct simmr_plan_info {
+  uint64_t n_units;      /* pairs (PE) or reads (long) planned in this shard  */
+  uint64_t n_reads;      /* 2*n_units for PE, n_units for long                */
+  uint64_t total_bases;  /* bytes needed in seq[] and in qual[]               */
+  uint64_t seed_used;    /* the seed (given, or drawn from OS entropy)        */
+  uint64_t outer_slots;  /* u64 draws consumed from the outer StdRng stream   */
+  uint32_t const_read_length; /* long/REFERENCE: the run-wide length, else 0  */
+  uint32_t reserved;
+} simmr_plan_info;
+
+/* flags[] bits */
+#define SIMMR_FLAG_REVCOMP 0x01u     /* ReadMetadata.is_reverse_complement    */
+#define SIMMR_FLAG_QSEED_SUBST 0x02u /* mate-2 Phred seed drew None (simulate.rs:266):
+                                        the reference uses OS entropy there; we
+                                        substitute simmr_entropy_substitute() */
+#define SIMMR_FLAG_MSEED_SUBST 0x04u /* same for the mutation seed (simulate.rs:270) */
+#define SIMMR_FLAG_REDRAWN 0x08u     /* mate-2 window was re-drawn (simulate.rs:241-247) */
+
+/* SoA replacement of Vec<SimulatedRead> (simulate.rs:27-75).  All pointers are
+ * DEVICE pointers owned by the caller.  Read r of a PE shard is mate (r & 1)
+ * of pair (r >> 1); mates are interleaved exactly as fastq.rs:32-121 writes
+ * them.  Any pointer except seq/qual/seq_off may be NULL to skip that column. */
+typedef struct simmr_reads_out {
+  uint8_t* seq;       /* ASCII bases, total_bases bytes                       */
+  uint8_t* qual;      /* Phred + qual_offset, total_bases bytes               */
+  uint64_t* seq_off;  /* n_reads + 1 CSR offsets into seq / qual              */
+  uint64_t* start;    /* ReadMetadata.start_pos (mate 2: the larger bound)    */
+  uint64_t* end;      /* ReadMetadata.end_pos                                 */
+  uint32_t* contig;   /* index of the source Seq inside its genome            */
+  uint32_t* genome;   /* staged genome index (long reads span genomes)        */
+  uint32_t* read_id;  /* SimulatedRead.id (simulate.rs:85-89), shared by mates */
+  uint8_t* flags;     /* SIMMR_FLAG_*                                         */
+  uint64_t seq_capacity;   /* bytes available in seq and in qual              */
+  uint64_t reads_capacity; /* entries available in the per-read columns       */
+  uint32_t qual_offset;    /* 0: raw Phred as SingleRead.quality; 33: FASTQ   */
+  uint32_t reserved;
+} simmr_reads_out;
+
+/* Device-side counters a run accumulates (reduced across GPUs by the caller
+ * with one all-reduce).  Indices into the uint64 array. */
+enum simmr_counter {
+  SIMMR_CNT_READS = 0,
+  SIMMR_CNT_BASES = 1,
+  SIMMR_CNT_ACGT_BASES = 2,
+  SIMMR_CNT_SUBSTITUTIONS = 3,
+  SIMMR_CNT_OUTER_REJECTS = 4,
+  SIMMR_CNT_REDRAWN = 5,
+  SIMMR_CNT_SEED_SUBST = 6,
+  SIMMR_CNT_QUAL_SUM = 7,
+  SIMMR_N_COUNTERS = 8
+};
+
+typedef struct simmr_engine simmr_engine; /* opaque */
+
+/* ---- lifetime ---------------------------------------------------------- */
+int simmr_abi_version(void);
+/* Binds to HIP device `device_ordinal`; fails with SIMMR_ENODEV if there is
+ * none or it is not gfx950. */
+int simmr_engine_create(int device_ordinal, simmr_engine** out);
+void simmr_engine_destroy(simmr_engine* e);
+/* Last error text of this engine (or of engine creation when e == NULL). */
+const char* simmr_last_error(const simmr_engine* e);
+/* All work is enqueued on this hipStream_t (default: the null stream). */
+int simmr_engine_set_stream(simmr_engine* e, void* hip_stream);
+
+/* ---- reference staging -------------------------------------------------- */
+/* Replaces the in-RAM `Genome { sequence: Vec<Seq> }` (genome.rs:17-41): the
+ * normalised ASCII contigs are packed once into HBM as a flat 2-bit array
+ * (A0 C1 G2 T3; base i in bits 2(i mod 16) of word i/16 — the code points of
+ * shared/src/encoding.rs:146-152) plus a 1-bit exception plane for 'N' / '-'.
+ * contig_len[i] = bytes in contig_ascii[i] (Seq.seq.len()),
+ * contig_size[i] = Seq.size (differs only under --contiguous, genome.rs:127);
+ * NULL means size == len. */
+int simmr_stage_genome(simmr_engine* e, uint32_t genome_idx, uint32_t n_contigs,
+                       const uint8_t* const* contig_ascii, const uint64_t* contig_len,
+                       const uint64_t* contig_size);
+/* Synthetic genome generated on the device: word k of the packed array (32
+ * bases) is SplitMix64 output k of `splitmix_seed` (BASELINE.md / SURVEY §8d). */
+int simmr_stage_synthetic(simmr_engine* e, uint32_t genome_idx, uint32_t n_contigs,
+                          const uint64_t* contig_len, uint64_t splitmix_seed);
+/* Copies staged bases back as ASCII (debug / tests). dst is a HOST pointer. */
+int simmr_unstage_contig(simmr_engine* e, uint32_t genome_idx, uint32_t contig, uint64_t first,
+                         uint64_t count, uint8_t* dst_host);
+int simmr_genome_info(const simmr_engine* e, uint32_t genome_idx, uint32_t* n_contigs,
+                      uint64_t* total_size);
+
+/* ---- paired-end path ----------------------------------------------------- */
+/* simulate_pe_reads_from_genome (simulate.rs:165-190) for one genome:
+ * `genome_reads` is the reference's num_reads (mates; num_reads/2 pairs,
+ * simulate.rs:179).  Plans pairs [shard.first, shard.first+shard.count) of
+ * that genome: outer StdRng stream (contig draw + pe_seed), then per pair read
+ * length / insert size / window (simulate_pe_read, simulate.rs:205-258).
+ * shard.count == UINT64_MAX means "to the end". */
+int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profile* profile,
+                  uint64_t genome_reads, int has_seed, uint64_t seed, simmr_range shard,
+                  simmr_plan_info* info);
+/* Emits the planned pairs: bases, qualities, mutations, reverse complement,
+ * metadata (simulate.rs:260-299).  read_id_base = id of pair 0 of this genome
+ * (the reference's global AtomicU32, simulate.rs:85-89). */
+int simmr_pe_emit(simmr_engine* e, uint32_t read_id_base, const simmr_reads_out* out);
+
+/* ---- long-read path ------------------------------------------------------ */
+/* simulate_long_reads (simulate.rs:323-406) over all genomes at once (ONE
+ * StdRng stream spans every genome, simulate.rs:348-351).  genome_reads[g] is
+ * the per-genome read count from the abundance profile.  shard is a range of
+ * global read indices (generation order across genomes). */
+int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_idx,
+                    const uint64_t* genome_reads, const simmr_error_profile* profile, int has_seed,
+                    uint64_t seed, simmr_range shard, simmr_plan_info* info);
+int simmr_long_emit(simmr_engine* e, uint32_t read_id_base, const simmr_reads_out* out);
+
+/* ---- counters / timing ---------------------------------------------------- */
+/* Copies the SIMMR_N_COUNTERS running counters to a DEVICE array (for the
+ * caller's all-reduce) and/or a HOST array; either may be NULL. */
+int simmr_counters(simmr_engine* e, uint64_t* dst_device, uint64_t* dst_host);
+int simmr_counters_reset(simmr_engine* e);
+/* HIP-event time (ms) of the dominant emit kernel of the last *_emit call,
+ * measured on the engine's stream. Synchronises the stream. */
+int simmr_last_emit_kernel_ms(simmr_engine* e, float* ms);
+/* HIP-event time (ms) of the last *_plan call's device work. */
+int simmr_last_plan_ms(simmr_engine* e, float* ms);
+
+/* ---- documented substitutions --------------------------------------------- */
+/* Where the reference re-seeds from OS entropy in the middle of a seeded run
+ * (Option<u64>::None at simulate.rs:266,270) we substitute this pure function
+ * of (pe_seed, which) so the run stays reproducible; which = 1 for the Phred
+ * seed, 2 for the mutation seed.  Also used to derive per-read seeds in
+ * SIMMR_LEN_PER_READ mode (which = 3, x = seed ^ read index mix). */
+uint64_t simmr_entropy_substitute(uint64_t x, uint32_t which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMMR_HIP_H */

@@ -1,0 +1,159 @@
+/*
+ * oracle.h — CPU ORACLE for the simmr hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the algorithm of genomicsoup/simmr's per-read
+ * sampling / mutation path (simmr/src/simulate.rs + error_profiles/ +
+ * abundance_profiles/ + util.rs) together with the arithmetic of the pinned,
+ * un-vendored crates it calls (Cargo.lock:656-693):
+ *     rand 0.8.5, rand_chacha 0.3.1, rand_core 0.6.3, rand_distr 0.4.3.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it, and only as the checker.  Nothing under simmr_amd/ links, imports
+ * or executes it.
+ *
+ * Parity pinning: the reference is Rust and cannot be built in
+ * this image (no cargo/rustc), and its two simulate tests are #[ignore]d with
+ * stale ground truth.  The oracle is pinned by
+ *   - the public ChaCha20 / ChaCha12 zero-key vectors,
+ *   - rand 0.8's StdRng unit-test value,
+ *   - the two reference-authored RNG values in comments of
+ *     simmr/src/tests/simulate_tests.rs:27 and :75,
+ *   - the live reference unit tests (util_tests.rs, abundance_profile_tests.rs,
+ *     error_profile_tests.rs, genome_tests.rs, shared/src/encoding.rs:288-314).
+ * Read CONTENT downstream of the RNG (fwd_start for a given pe_seed, Normal /
+ * Gamma outputs) has no reference-authored golden vector: that part is
+ * "parity unpinned" beyond the crate algorithms restated here.  The ziggurat
+ * tables are regenerated from rand_distr's published generator formulas (the
+ * literal tables are not in /root/reference).
+ */
+#ifndef SIMMR_ORACLE_H
+#define SIMMR_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../include/simmr_hip.h" /* POD types only (profile, reads_out, flags) */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- rand_core 0.6.3 BlockRng<ChaCha12Core> == rand 0.8.5 StdRng */
+typedef struct orc_rng {
+  uint32_t key[8];
+  uint64_t counter;     /* block counter of the next refill                  */
+  uint32_t results[64]; /* rand_chacha 0.3.1 buffers 4 blocks per refill     */
+  uint32_t index;       /* next unread word, 64 = empty                      */
+  uint64_t words_used;  /* oracle-only bookkeeping: words consumed so far    */
+} orc_rng;
+
+void orc_chacha_block(const uint32_t key[8], uint64_t counter, uint32_t rounds, uint32_t out[16]);
+void orc_pcg32_expand(uint64_t state, uint32_t key_out[8]);
+void orc_rng_from_seed(orc_rng* r, const uint8_t seed[32]);
+void orc_rng_seed_from_u64(orc_rng* r, uint64_t state);
+uint32_t orc_next_u32(orc_rng* r);
+uint64_t orc_next_u64(orc_rng* r);
+/* gen_range(lo..hi): returns 0 on success, -1 on an empty range (panic in Rust) */
+int orc_gen_range_u64(orc_rng* r, uint64_t lo, uint64_t hi, uint64_t* out);
+int orc_gen_range_u32(orc_rng* r, uint32_t lo, uint32_t hi, uint32_t* out);
+float orc_gen_f32(orc_rng* r);
+double orc_gen_f64(orc_rng* r);
+int orc_gen_bool(orc_rng* r);
+int orc_gen_option_u64(orc_rng* r, uint64_t* out); /* 1 = Some(*out), 0 = None */
+double orc_open01_f64(orc_rng* r);
+float orc_open01_f32(orc_rng* r);
+double orc_standard_normal(orc_rng* r);
+double orc_normal_f64(orc_rng* r, double mean, double std);
+float orc_normal_f32(orc_rng* r, float mean, float std);
+/* Gamma<f32>::new(shape, scale).sample(): -1 if shape <= 1 (not restated) */
+int orc_gamma_f32(orc_rng* r, float shape, float scale, float* out);
+const double* orc_zig_norm_x(void); /* 257 entries */
+const double* orc_zig_norm_f(void); /* 257 entries */
+
+/* ---------------- simmr/src/util.rs */
+uint8_t orc_complement(uint8_t n);
+void orc_reverse_complement(const uint8_t* in, uint64_t n, uint8_t* out);
+uint8_t orc_encode_quality_score(uint8_t s);
+float orc_convert_phred_to_probability(uint8_t score);
+uint8_t orc_convert_probability_to_phred(float prob);
+float orc_convert_phred_to_accuracy(uint8_t score);
+uint8_t orc_convert_accuracy_to_phred(float acc);
+/* shared/src/encoding.rs two_bit_encode_kmer / decode */
+int orc_two_bit_encode_kmer(const uint8_t* kmer, uint32_t k, uint32_t* out);
+int orc_two_bit_decode_kmer(uint32_t code, uint32_t k, uint8_t* out);
+
+uint64_t orc_entropy_substitute(uint64_t x, uint32_t which);
+uint64_t orc_per_read_seed(uint64_t seed, uint64_t read_index);
+
+/* ---------------- ErrorProfile trait methods (error_profiles/) */
+int orc_profile_minimum_genome_size(const simmr_error_profile* p, uint16_t* out);
+int orc_profile_is_long_read(const simmr_error_profile* p);
+int orc_profile_get_read_length(const simmr_error_profile* p, uint64_t seed, uint16_t* out);
+int orc_profile_get_random_read_length(const simmr_error_profile* p, uint64_t seed, uint16_t* out);
+int orc_profile_get_insert_size(const simmr_error_profile* p, uint64_t seed, uint16_t* out);
+int orc_profile_simulate_phred_scores(const simmr_error_profile* p, uint64_t len, uint64_t seed,
+                                      uint8_t* out);
+int orc_profile_simulate_point_mutations(const simmr_error_profile* p, const uint8_t* seq,
+                                         const uint8_t* qual, uint64_t len, uint64_t seed,
+                                         uint8_t* out);
+
+/* ---------------- AbundanceProfile (abundance_profiles/) */
+void orc_uniform_determine_abundances(uint64_t total_reads, uint64_t num_genomes,
+                                      uint64_t* reads_out, double* abund_out);
+void orc_exact_determine_abundances(uint64_t total_reads, uint64_t num_genomes,
+                                    uint64_t* reads_out, double* abund_out);
+void orc_custom_determine_abundances(const double* abundances, uint64_t total_reads,
+                                     uint64_t num_genomes, uint64_t* reads_out, double* abund_out);
+void orc_adjust_for_size(const uint64_t* genome_sizes, const uint64_t* reads_in,
+                         const double* abund_in, uint64_t num_genomes, uint64_t* reads_out,
+                         double* abund_out);
+
+/* ---------------- simulate.rs */
+typedef struct orc_genome {
+  uint32_t n_contigs;
+  const uint8_t* const* seq; /* Seq.seq  */
+  const uint64_t* len;       /* Seq.seq.len() */
+  const uint64_t* size;      /* Seq.size */
+} orc_genome;
+
+/* simulate_pe_reads_from_genome's outer loop (simulate.rs:172-184): fills
+ * contig_idx[i], pe_seed[i] for pairs [first, first+count).  *slots = u64
+ * draws consumed up to the end of the last returned pair. */
+int orc_pe_outer(uint64_t n_contigs, uint64_t seed, uint64_t first, uint64_t count,
+                 uint32_t* contig_idx, uint64_t* pe_seed, uint64_t* slots);
+
+/* Per-pair plan (simulate.rs:211-258). */
+typedef struct orc_pe_plan {
+  uint32_t read_length;
+  uint32_t insert_size;
+  uint64_t fwd_start, fwd_end, rev_end, rev_start;
+  uint64_t qseed2, mseed2; /* seeds used for mate 2 (drawn or substituted) */
+  uint8_t flags2;          /* SIMMR_FLAG_* of mate 2                         */
+} orc_pe_plan;
+int orc_pe_plan_pair(const simmr_error_profile* p, uint64_t contig_size, uint64_t pe_seed,
+                     orc_pe_plan* plan);
+
+/* Whole shard: pairs [first, first+count) of one genome, SoA out (HOST
+ * pointers; same layout as simmr_reads_out).  threads > 1 parallelises over
+ * pairs (cpu_baseline only; results identical).  Returns 0 or a negative code;
+ * *total_bases receives the bytes written to seq/qual. */
+int orc_simulate_pe_reads_from_genome(const orc_genome* g, const simmr_error_profile* p,
+                                      uint64_t genome_reads, uint64_t seed, uint64_t first,
+                                      uint64_t count, uint32_t read_id_base,
+                                      const simmr_reads_out* out, uint64_t* total_bases,
+                                      int threads);
+
+/* simulate_long_reads (simulate.rs:323-406). shard = global read index range. */
+int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
+                            const uint64_t* genome_reads, const simmr_error_profile* p,
+                            int has_seed, uint64_t seed, uint64_t first, uint64_t count,
+                            uint32_t read_id_base, const simmr_reads_out* out,
+                            uint64_t* total_bases, uint32_t* const_len, int threads);
+
+/* counters over a finished SoA (same definitions as enum simmr_counter where
+ * derivable from outputs + the packed reference) */
+const char* orc_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

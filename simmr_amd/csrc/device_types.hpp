@@ -1,0 +1,104 @@
+// device_types.hpp — plain structs shared by the host engine and the kernels.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/simmr_hip.h"
+
+namespace simmr {
+
+// profile kinds as the kernels see them (same values as enum simmr_profile_kind)
+#define SIMMR_K_PERFECT_SHORT 0u
+#define SIMMR_K_MINIMAL_SHORT 1u
+#define SIMMR_K_PERFECT_LONG 2u
+#define SIMMR_K_MINIMAL_LONG 3u
+
+// bits of the device error word
+#define SIMMR_ERRBIT_GENOME 1u /* contig too small for the profile (simulate.rs:220) */
+#define SIMMR_ERRBIT_SLICE 2u  /* slice would leave the contig (a Rust panic)       */
+
+// One sequence record of a staged genome (genome.rs:17-23 `Seq`).
+struct ContigDev {
+  uint64_t base;  // first base of this contig in the genome's packed plane (multiple of 64)
+  uint64_t len;   // Seq.seq.len()
+  uint64_t size;  // Seq.size
+};
+
+// One staged genome: 2-bit code plane + optional 1-bit exception plane.
+// Both planes have 16 bytes of addressable padding in front and 64 behind.
+struct GenomeDev {
+  const uint32_t* packed;
+  const uint32_t* mask;  // nullptr when the genome is pure ACGT
+  const ContigDev* contigs;
+  uint32_t n_contigs;
+  uint32_t has_exc;
+};
+
+// Device form of simmr_error_profile, with host-derived constants.
+struct ProfileDev {
+  uint32_t kind;
+  uint32_t rng_mode;
+  uint32_t read_length;
+  uint32_t insert_size;
+  uint32_t required;  // minimum_genome_size(), u16 arithmetic done on the host
+  float mean_phred_f;
+  float pl_mean;      // perfect-long: convert_phred_to_accuracy(20)
+  float gamma_shape, gamma_scale;
+  double read_length_std, insert_size_std;
+};
+
+struct Key8 {
+  uint32_t k[8];
+};
+
+struct OuterParams {
+  Key8 key;        // ChaCha12 key of the outer StdRng (PCG32 expansion of the seed)
+  uint64_t range;  // gen_range(0..range)
+  uint64_t zone;   // (range << lz) - 1
+};
+
+struct OuterPrefix {
+  uint64_t base;   // units emitted before this workgroup
+  uint32_t state;  // 0 = NEED_IDX, 1 = NEED_SEED at its first slot
+  uint32_t pad;
+};
+
+struct OuterScanResult {
+  uint64_t total_units;
+  uint64_t wg_lo, wg_hi;
+  uint64_t end_slot;
+  uint32_t end_state;
+  uint32_t pad;
+};
+
+// Per-unit plan columns (unit = pair or long read).
+struct PlanArrays {
+  uint32_t* len;    // read length L (both mates) / long-read length
+  uint64_t* a;      // fwd_start / read_start
+  uint64_t* b;      // rev_end (mate-2 slice start) / read_end
+  uint64_t* bytes;  // bytes this unit writes to seq[] (2L or end-start)
+  uint64_t* qs2;    // mate-2 Phred seed   (nullptr when unused)
+  uint64_t* ms2;    // mate-2 mutation seed
+  uint8_t* flags;
+};
+
+struct OutCols {
+  uint64_t* seq_off;
+  uint64_t* start;
+  uint64_t* end;
+  uint32_t* contig;
+  uint32_t* genome;
+  uint32_t* read_id;
+  uint8_t* flags;
+};
+
+// A maximal range of consecutive long reads drawn from one genome.
+struct LongGenomeRun {
+  uint64_t first_read;     // global index of the run's first read
+  uint64_t n_reads;
+  uint64_t max_size;       // largest Seq.size in the genome
+  const uint32_t* usable;  // usable-sequence index -> contig index (reference mode)
+  uint32_t n_usable;
+  uint32_t genome;
+};
+
+}  // namespace simmr

@@ -1,0 +1,890 @@
+// engine.hip — host side of the C ABI declared in include/simmr_hip.h.
+//
+// Owns device memory for staged genomes, the plan of the current shard and the
+// scratch of the outer-stream transducer; enqueues the kernels of kernels.hip
+// on one HIP stream.  No CPU compute path exists here: every entry point that
+// produces reads needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "kernels.hip"
+
+using namespace simmr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t bytes) {
+    if (bytes <= cap) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+    cap = want;
+    return true;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct GenomeHost {
+  bool staged = false;
+  std::vector<ContigDev> contigs;
+  uint64_t total_size = 0;   // sum of Seq.size (Genome.size, genome.rs:135)
+  uint64_t plane_bases = 0;  // bases in the packed plane (contigs padded to 64)
+  uint64_t max_size = 0;
+  bool has_exc = false;
+  DevBuf packed, mask, d_contigs;
+};
+
+constexpr size_t FRONT_PAD_WORDS = 4;  // 16 bytes in front of each plane
+constexpr size_t BACK_PAD_WORDS = 16;
+
+enum PlanKind { PLAN_NONE = 0, PLAN_PE = 1, PLAN_LONG = 2 };
+
+}  // namespace
+
+struct simmr_engine {
+  int device = -1;
+  int n_cu = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<GenomeHost> genomes;
+  DevBuf d_genomes;  // GenomeDev[genomes.size()]
+  DevBuf d_tables, d_counters, d_err, d_scalars;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  float last_emit_ms = 0.f, last_plan_ms = 0.f;
+
+  // current plan
+  int plan_kind = PLAN_NONE;
+  ProfileDev prof{};
+  uint32_t plan_genome = 0;
+  uint64_t plan_first = 0, plan_units = 0, plan_total_bases = 0;
+  bool plan_paired = false;
+  DevBuf u_contig, u_genome, u_seed, u_len, u_a, u_b, u_bytes, u_qs2, u_ms2, u_flags, u_off;
+  DevBuf scan_tmp;
+  // outer-stream scratch
+  DevBuf o_last_idx, o_wg_sums, o_wg_prefix, o_result;
+  // long-read runs
+  DevBuf d_runs, d_usable;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+};
+
+#define HIP_TRY(e, call)                                                                  \
+  do {                                                                                    \
+    hipError_t _s = (call);                                                               \
+    if (_s != hipSuccess)                                                                 \
+      return (e)->fail(SIMMR_ENODEV, "%s failed: %s", #call, hipGetErrorString(_s));      \
+  } while (0)
+
+namespace {
+
+// ---- host copies of the small pieces of arithmetic the host itself needs ----
+Key8 host_pcg32_expand(uint64_t state) {
+  const uint64_t MUL = 6364136223846793005ULL, INC = 11634580027462260723ULL;
+  Key8 key;
+  for (int i = 0; i < 8; i++) {
+    state = state * MUL + INC;
+    uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27);
+    uint32_t rot = (uint32_t)(state >> 59);
+    key.k[i] = (xs >> rot) | (xs << ((32 - rot) & 31));
+  }
+  return key;
+}
+
+uint8_t host_sat_u8(float f) {
+  if (!(f == f) || f <= 0.0f) return 0;
+  if (f >= 255.0f) return 255;
+  return (uint8_t)f;
+}
+// util.rs:109-111 applied to d = 1 - acc, with the host libm
+uint8_t host_phred_of_err(float d) { return host_sat_u8(roundf(-10.0f * log10f(d))); }
+
+void build_tables(Tables* T) {
+  // rand_distr 0.4.3 ziggurat tables for N(0,1), from the crate's generator
+  // formulas (r = 3.654152885361009, v = 0.00492867323399, 256 layers)
+  const double r = 3.6541528853610088, v = 0.00492867323399;
+  auto f = [](double x) { return exp(-x * x / 2.0); };
+  T->zig_x[0] = v / f(r);
+  T->zig_x[1] = r;
+  for (int i = 2; i < 256; i++) {
+    double last = T->zig_x[i - 1];
+    T->zig_x[i] = sqrt(-2.0 * log(v / last + f(last)));
+  }
+  T->zig_x[256] = 0.0;
+  for (int i = 0; i < 257; i++) T->zig_f[i] = f(T->zig_x[i]);
+  // util.rs:69-71,96-98 with the platform libm, as the Rust std does
+  for (int q = 0; q < 256; q++) T->acc[q] = 1.0f - powf(10.0f, -((float)q / 10.0f));
+  // perfect-long Phred as thresholds on d = 1 - acc: q(d) = pl_first + #{i: d <= thresh[i]}
+  T->pl_first = host_phred_of_err(3.0e38f);
+  T->pl_count = 0;
+  for (uint32_t q = T->pl_first + 1; q < T->pl_first + 64; q++) {
+    // largest positive float d with phred(d) >= q (phred is non-increasing in d)
+    uint32_t lo = 1u, hi = 0x7f7fffffu;  // bit patterns of positive finite floats
+    float flo; memcpy(&flo, &lo, 4);
+    if (host_phred_of_err(flo) < q) break;
+    while (lo < hi) {
+      uint32_t mid = lo + (hi - lo + 1) / 2;
+      float fm; memcpy(&fm, &mid, 4);
+      if (host_phred_of_err(fm) >= q) lo = mid; else hi = mid - 1;
+    }
+    float t; memcpy(&t, &lo, 4);
+    T->pl_thresh[T->pl_count++] = t;
+  }
+  for (uint32_t i = T->pl_count; i < 64; i++) T->pl_thresh[i] = -1.0f;
+}
+
+inline uint32_t grid_for(uint64_t n, uint32_t per_block) {
+  uint64_t g = (n + per_block - 1) / per_block;
+  if (g == 0) g = 1;
+  return (uint32_t)g;
+}
+
+int sync_check(simmr_engine* e, const char* what) {
+  hipError_t s = hipStreamSynchronize(e->stream);
+  if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "%s: %s", what, hipGetErrorString(s));
+  s = hipGetLastError();
+  if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "%s: %s", what, hipGetErrorString(s));
+  return SIMMR_OK;
+}
+
+int refresh_genome_table(simmr_engine* e) {
+  std::vector<GenomeDev> tab(e->genomes.size());
+  for (size_t i = 0; i < e->genomes.size(); i++) {
+    GenomeHost& g = e->genomes[i];
+    GenomeDev d{};
+    if (g.staged) {
+      d.packed = g.packed.as<uint32_t>() + FRONT_PAD_WORDS;
+      d.mask = g.has_exc ? g.mask.as<uint32_t>() + FRONT_PAD_WORDS : nullptr;
+      d.contigs = g.d_contigs.as<ContigDev>();
+      d.n_contigs = (uint32_t)g.contigs.size();
+      d.has_exc = g.has_exc ? 1u : 0u;
+    }
+    tab[i] = d;
+  }
+  if (!e->d_genomes.ensure(sizeof(GenomeDev) * std::max<size_t>(tab.size(), 1)))
+    return e->fail(SIMMR_ENOMEM, "genome table allocation failed");
+  HIP_TRY(e, hipMemcpyAsync(e->d_genomes.p, tab.data(), sizeof(GenomeDev) * tab.size(),
+                            hipMemcpyHostToDevice, e->stream));
+  return sync_check(e, "genome table upload");
+}
+
+int layout_genome(simmr_engine* e, GenomeHost& g, uint32_t n_contigs, const uint64_t* contig_len,
+                  const uint64_t* contig_size) {
+  g.contigs.resize(n_contigs);
+  uint64_t base = 0;
+  g.total_size = 0;
+  g.max_size = 0;
+  for (uint32_t c = 0; c < n_contigs; c++) {
+    g.contigs[c].base = base;
+    g.contigs[c].len = contig_len[c];
+    g.contigs[c].size = contig_size ? contig_size[c] : contig_len[c];
+    g.total_size += g.contigs[c].size;
+    g.max_size = std::max(g.max_size, g.contigs[c].size);
+    base += (contig_len[c] + 63) & ~63ULL;
+  }
+  g.plane_bases = base;
+  const size_t pwords = FRONT_PAD_WORDS + base / 16 + BACK_PAD_WORDS;
+  const size_t mwords = FRONT_PAD_WORDS + base / 32 + BACK_PAD_WORDS;
+  if (!g.packed.ensure(pwords * 4) || !g.mask.ensure(mwords * 4) ||
+      !g.d_contigs.ensure(sizeof(ContigDev) * std::max<uint32_t>(n_contigs, 1)))
+    return e->fail(SIMMR_ENOMEM, "genome allocation failed (%zu bytes)", pwords * 4 + mwords * 4);
+  HIP_TRY(e, hipMemsetAsync(g.packed.p, 0, pwords * 4, e->stream));
+  HIP_TRY(e, hipMemsetAsync(g.mask.p, 0, mwords * 4, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(g.d_contigs.p, g.contigs.data(), sizeof(ContigDev) * n_contigs,
+                            hipMemcpyHostToDevice, e->stream));
+  return SIMMR_OK;
+}
+
+int check_genome(simmr_engine* e, uint32_t idx) {
+  if (idx >= e->genomes.size() || !e->genomes[idx].staged)
+    return e->fail(SIMMR_EINVAL, "genome %u is not staged", idx);
+  return SIMMR_OK;
+}
+
+// ---- profile validation (cli.rs:229-301 semantics) -------------------------
+int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, ProfileDev* out) {
+  if (!p) return e->fail(SIMMR_EINVAL, "profile is NULL");
+  if (p->kind > SIMMR_MINIMAL_LONG)
+    return e->fail(SIMMR_EINVAL, "profile kind %u is not implemented on the device", p->kind);
+  if (p->rng_mode != SIMMR_RNG_REFERENCE)
+    return e->fail(SIMMR_EINVAL, "rng_mode %u is not implemented", p->rng_mode);
+  const bool is_long = p->kind == SIMMR_PERFECT_LONG || p->kind == SIMMR_MINIMAL_LONG;
+  if (is_long != want_long)
+    return e->fail(SIMMR_EINVAL, want_long ? "a short-read profile was passed to the long-read path"
+                                           : "a long-read profile was passed to the paired-end path");
+  ProfileDev d{};
+  d.kind = p->kind;
+  d.rng_mode = p->rng_mode;
+  d.read_length = p->read_length;
+  d.insert_size = p->insert_size;
+  d.mean_phred_f = (float)p->mean_phred;
+  d.pl_mean = 1.0f - powf(10.0f, -((float)20 / 10.0f));  // convert_phred_to_accuracy(20)
+  d.gamma_shape = p->gamma_shape;
+  d.gamma_scale = p->gamma_scale;
+  d.read_length_std = p->read_length_std;
+  d.insert_size_std = p->insert_size_std;
+  if (is_long) {
+    d.required = 20000;  // minimal_long.rs:152-154
+    if (!(p->gamma_shape > 1.0f) || !(p->gamma_scale > 0.0f))
+      return e->fail(SIMMR_EINVAL, "gamma shape must be > 1 and scale > 0 (got %g, %g)",
+                     (double)p->gamma_shape, (double)p->gamma_scale);
+  } else {
+    // perfect_short.rs:56-59: 2 * read_length + insert_size in u16.  The
+    // reference overflows silently; reject instead.
+    uint32_t req = 2u * p->read_length + p->insert_size;
+    if (req > 65535u)
+      return e->fail(SIMMR_ERANGE, "2*read_length + insert_size = %u overflows the reference's u16", req);
+    if (p->read_length == 0) return e->fail(SIMMR_EINVAL, "read_length is 0");
+    d.required = req;
+    if (p->kind == SIMMR_MINIMAL_SHORT &&
+        (!(p->read_length_std >= 0.0) || !(p->insert_size_std >= 0.0)))
+      return e->fail(SIMMR_EINVAL, "negative standard deviation");
+  }
+  *out = d;
+  return SIMMR_OK;
+}
+
+uint64_t os_entropy_u64() {
+  std::random_device rd;
+  return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+}
+
+// ---- outer stream ------------------------------------------------------------
+// Runs the transducer over one StdRng(seed) run that starts at `start_slot`
+// with gen_range(0..range): classifies enough blocks to hold `n_total` units,
+// writes (idx, seed) of units [emit_first, emit_first+emit_count) to
+// out_idx/out_seed, and returns the slot following unit n_total-1.
+int run_outer(simmr_engine* e, uint64_t seed, uint64_t range, uint64_t start_slot, uint64_t n_total,
+              uint64_t emit_first, uint64_t emit_count, uint32_t* out_idx, uint64_t* out_seed,
+              uint64_t* end_slot) {
+  if (n_total == 0) { *end_slot = start_slot; return SIMMR_OK; }
+  OuterParams P;
+  P.key = host_pcg32_expand(seed);
+  P.range = range;
+  P.zone = (range << __builtin_clzll(range)) - 1;
+  const double p_acc = ((double)P.zone + 1.0) / 18446744073709551616.0;
+  const double per_unit = 1.0 / p_acc + 1.0;
+  const double var_unit = (1.0 - p_acc) / (p_acc * p_acc);
+  const uint64_t first_block = start_slot >> 3;
+  const uint32_t first_skip = (uint32_t)(start_slot & 7);
+  double want = (double)n_total * per_unit + 6.0 * sqrt((double)n_total * var_unit) + 64.0;
+  uint64_t n_blocks = ((uint64_t)want + first_skip + 7) / 8 + 1;
+  OuterScanResult res{};
+  for (int attempt = 0;; attempt++) {
+    if (attempt > 8) return e->fail(SIMMR_ESTATE, "outer stream did not yield %llu units", (unsigned long long)n_total);
+    const uint64_t n_wg = (n_blocks + 255) / 256;
+    if (n_wg > 0x7fffffffULL) return e->fail(SIMMR_ERANGE, "outer stream too long for one launch");
+    if (!e->o_last_idx.ensure(n_blocks * 4) || !e->o_wg_sums.ensure(n_wg * 4) ||
+        !e->o_wg_prefix.ensure(n_wg * sizeof(OuterPrefix)) || !e->o_result.ensure(sizeof(OuterScanResult)))
+      return e->fail(SIMMR_ENOMEM, "outer stream scratch allocation failed");
+    HIP_TRY(e, hipMemsetAsync(e->o_result.p, 0, sizeof(OuterScanResult), e->stream));
+    hipLaunchKernelGGL(k_outer_classify, dim3((uint32_t)n_wg), dim3(256), 0, e->stream, P, first_block,
+                       n_blocks, first_skip, e->o_last_idx.as<uint32_t>(), e->o_wg_sums.as<uint32_t>());
+    // wg range of the units to emit; the closing unit is looked up separately below
+    hipLaunchKernelGGL(k_outer_scan, dim3(1), dim3(256), 0, e->stream, e->o_wg_sums.as<uint32_t>(), n_wg,
+                       emit_first, emit_count, e->o_wg_prefix.as<OuterPrefix>(),
+                       e->o_result.as<OuterScanResult>());
+    HIP_TRY(e, hipMemcpyAsync(&res, e->o_result.p, sizeof res, hipMemcpyDeviceToHost, e->stream));
+    int rc = sync_check(e, "outer stream classify/scan");
+    if (rc) return rc;
+    if (res.total_units >= n_total) break;
+    n_blocks = n_blocks + n_blocks / 4 + 1024;
+  }
+  uint64_t* d_end = &e->o_result.as<OuterScanResult>()->end_slot;
+  if (emit_count > 0) {
+    const uint64_t n_launch = res.wg_hi - res.wg_lo + 1;
+    hipLaunchKernelGGL(k_outer_emit, dim3((uint32_t)n_launch), dim3(256), 0, e->stream, P, first_block,
+                       n_blocks, first_skip, res.wg_lo, e->o_last_idx.as<uint32_t>(),
+                       e->o_wg_prefix.as<OuterPrefix>(), emit_first, emit_count, out_idx, out_seed, d_end);
+  }
+  if (emit_count == 0 || emit_first + emit_count != n_total) {
+    // locate the workgroup of the closing unit with a second scan query, then
+    // let that workgroup record the end slot (it writes no units: count = 0 range trick
+    // is avoided by pointing the emit range at the closing unit with null outputs)
+    HIP_TRY(e, hipMemsetAsync(e->o_result.p, 0, sizeof(OuterScanResult), e->stream));
+    const uint64_t n_wg = (n_blocks + 255) / 256;
+    hipLaunchKernelGGL(k_outer_scan, dim3(1), dim3(256), 0, e->stream, e->o_wg_sums.as<uint32_t>(), n_wg,
+                       n_total - 1, (uint64_t)1, e->o_wg_prefix.as<OuterPrefix>(),
+                       e->o_result.as<OuterScanResult>());
+    OuterScanResult r2{};
+    HIP_TRY(e, hipMemcpyAsync(&r2, e->o_result.p, sizeof r2, hipMemcpyDeviceToHost, e->stream));
+    int rc = sync_check(e, "outer stream end lookup");
+    if (rc) return rc;
+    if (!e->scan_tmp.ensure(64)) return e->fail(SIMMR_ENOMEM, "scratch allocation failed");
+    hipLaunchKernelGGL(k_outer_emit, dim3(1), dim3(256), 0, e->stream, P, first_block, n_blocks, first_skip,
+                       r2.wg_lo, e->o_last_idx.as<uint32_t>(), e->o_wg_prefix.as<OuterPrefix>(),
+                       n_total - 1, (uint64_t)1, e->scan_tmp.as<uint32_t>(),
+                       e->scan_tmp.as<uint64_t>() + 2, d_end);
+  }
+  uint64_t es = 0;
+  HIP_TRY(e, hipMemcpyAsync(&es, d_end, 8, hipMemcpyDeviceToHost, e->stream));
+  int rc = sync_check(e, "outer stream emit");
+  if (rc) return rc;
+  *end_slot = es;
+  return SIMMR_OK;
+}
+
+// exclusive scan of u_bytes -> u_off (n + 1 entries); returns the total
+int scan_offsets(simmr_engine* e, uint64_t n, uint64_t* total) {
+  if (!e->u_off.ensure((n + 1) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
+  if (n == 0) {
+    HIP_TRY(e, hipMemsetAsync(e->u_off.p, 0, 8, e->stream));
+    *total = 0;
+    return SIMMR_OK;
+  }
+  const uint32_t per_wg = SCAN_THREADS * SCAN_ITEMS;
+  const uint64_t n_wg = (n + per_wg - 1) / per_wg;
+  if (!e->scan_tmp.ensure((n_wg + 2) * 8)) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
+  uint64_t* wg_tot = e->scan_tmp.as<uint64_t>();
+  uint64_t* grand = wg_tot + n_wg;
+  hipLaunchKernelGGL(k_scan_reduce, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
+                     e->u_bytes.as<uint64_t>(), n, wg_tot);
+  hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_THREADS), 0, e->stream, wg_tot, n_wg, grand);
+  hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
+                     e->u_bytes.as<uint64_t>(), n, wg_tot, e->u_off.as<uint64_t>());
+  HIP_TRY(e, hipMemcpyAsync(total, grand, 8, hipMemcpyDeviceToHost, e->stream));
+  return sync_check(e, "offset scan");
+}
+
+int ensure_plan_arrays(simmr_engine* e, uint64_t n, bool need_seeds2, bool need_genome) {
+  const uint64_t m = std::max<uint64_t>(n, 1);
+  bool ok = e->u_contig.ensure(m * 4) && e->u_seed.ensure(m * 8) && e->u_len.ensure(m * 4) &&
+            e->u_a.ensure(m * 8) && e->u_b.ensure(m * 8) && e->u_bytes.ensure(m * 8) &&
+            e->u_flags.ensure(m);
+  if (need_seeds2) ok = ok && e->u_qs2.ensure(m * 8) && e->u_ms2.ensure(m * 8);
+  if (need_genome) ok = ok && e->u_genome.ensure(m * 4);
+  if (!ok) return e->fail(SIMMR_ENOMEM, "plan allocation failed for %llu units", (unsigned long long)n);
+  return SIMMR_OK;
+}
+
+PlanArrays plan_arrays(simmr_engine* e, bool seeds2) {
+  PlanArrays pl;
+  pl.len = e->u_len.as<uint32_t>();
+  pl.a = e->u_a.as<uint64_t>();
+  pl.b = e->u_b.as<uint64_t>();
+  pl.bytes = e->u_bytes.as<uint64_t>();
+  pl.qs2 = seeds2 ? e->u_qs2.as<uint64_t>() : nullptr;
+  pl.ms2 = seeds2 ? e->u_ms2.as<uint64_t>() : nullptr;
+  pl.flags = e->u_flags.as<uint8_t>();
+  return pl;
+}
+
+int read_err_word(simmr_engine* e, uint32_t* w) {
+  HIP_TRY(e, hipMemcpyAsync(w, e->d_err.p, 4, hipMemcpyDeviceToHost, e->stream));
+  return sync_check(e, "error word readback");
+}
+
+int check_out(simmr_engine* e, const simmr_reads_out* out, uint64_t n_reads, uint64_t total) {
+  if (!out) return e->fail(SIMMR_EINVAL, "out is NULL");
+  if (!out->seq_off) return e->fail(SIMMR_EINVAL, "out->seq_off is NULL");
+  if (total > 0 && (!out->seq || !out->qual)) return e->fail(SIMMR_EINVAL, "out->seq / out->qual is NULL");
+  if (out->seq_capacity < total)
+    return e->fail(SIMMR_ERANGE, "seq_capacity %llu < %llu bytes planned",
+                   (unsigned long long)out->seq_capacity, (unsigned long long)total);
+  if (out->reads_capacity < n_reads)
+    return e->fail(SIMMR_ERANGE, "reads_capacity %llu < %llu reads planned",
+                   (unsigned long long)out->reads_capacity, (unsigned long long)n_reads);
+  if (out->qual_offset > 255u) return e->fail(SIMMR_EINVAL, "qual_offset too large");
+  return SIMMR_OK;
+}
+
+OutCols out_cols(const simmr_reads_out* out) {
+  OutCols o;
+  o.seq_off = out->seq_off; o.start = out->start; o.end = out->end; o.contig = out->contig;
+  o.genome = out->genome; o.read_id = out->read_id; o.flags = out->flags;
+  return o;
+}
+
+int stream_grid(simmr_engine* e, uint64_t n_units) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_emit_stream, 64, 0) != hipSuccess || per_cu < 1)
+    per_cu = 8;
+  uint64_t g = (uint64_t)e->n_cu * (uint64_t)per_cu;
+  if (g > n_units) g = n_units;
+  if (g == 0) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+// =============================================================================
+// C ABI
+// =============================================================================
+extern "C" {
+
+int simmr_abi_version(void) { return SIMMR_ABI_VERSION; }
+
+uint64_t simmr_entropy_substitute(uint64_t x, uint32_t which) { return entropy_substitute(x, which); }
+
+const char* simmr_last_error(const simmr_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int simmr_engine_create(int device_ordinal, simmr_engine** out) {
+  if (!out) { g_create_error = "out is NULL"; return SIMMR_EINVAL; }
+  *out = nullptr;
+  int n = 0;
+  hipError_t s = hipGetDeviceCount(&n);
+  if (s != hipSuccess || n <= 0) {
+    g_create_error = std::string("no HIP device available: ") + (s == hipSuccess ? "device count is 0" : hipGetErrorString(s));
+    return SIMMR_ENODEV;
+  }
+  if (device_ordinal < 0 || device_ordinal >= n) {
+    g_create_error = "device ordinal out of range (there is no CPU backend)";
+    return SIMMR_ENODEV;
+  }
+  hipDeviceProp_t prop;
+  if ((s = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess) {
+    g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(s);
+    return SIMMR_ENODEV;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("device is ") + prop.gcnArchName + ", this library holds gfx950 code only";
+    return SIMMR_ENODEV;
+  }
+  if ((s = hipSetDevice(device_ordinal)) != hipSuccess) {
+    g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(s);
+    return SIMMR_ENODEV;
+  }
+  simmr_engine* e = new simmr_engine();
+  e->device = device_ordinal;
+  e->n_cu = prop.multiProcessorCount;
+  bool ok = e->d_tables.ensure(sizeof(Tables)) && e->d_counters.ensure(8 * SIMMR_N_COUNTERS) &&
+            e->d_err.ensure(64) && e->d_scalars.ensure(256);
+  ok = ok && hipEventCreate(&e->ev_a) == hipSuccess && hipEventCreate(&e->ev_b) == hipSuccess &&
+       hipEventCreate(&e->ev_c) == hipSuccess && hipEventCreate(&e->ev_d) == hipSuccess;
+  if (ok) {
+    Tables* T = new Tables();
+    build_tables(T);
+    ok = hipMemcpy(e->d_tables.p, T, sizeof(Tables), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(e->d_counters.p, 0, 8 * SIMMR_N_COUNTERS) == hipSuccess &&
+         hipMemset(e->d_err.p, 0, 64) == hipSuccess;
+    delete T;
+  }
+  if (!ok) {
+    g_create_error = "engine allocation failed";
+    simmr_engine_destroy(e);
+    return SIMMR_ENOMEM;
+  }
+  *out = e;
+  return SIMMR_OK;
+}
+
+void simmr_engine_destroy(simmr_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  for (auto& g : e->genomes) { g.packed.release(); g.mask.release(); g.d_contigs.release(); }
+  DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
+                    &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_bytes, &e->u_qs2,
+                    &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
+                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable};
+  for (DevBuf* b : bufs) b->release();
+  if (e->ev_a) (void)hipEventDestroy(e->ev_a);
+  if (e->ev_b) (void)hipEventDestroy(e->ev_b);
+  if (e->ev_c) (void)hipEventDestroy(e->ev_c);
+  if (e->ev_d) (void)hipEventDestroy(e->ev_d);
+  delete e;
+}
+
+int simmr_engine_set_stream(simmr_engine* e, void* hip_stream) {
+  if (!e) return SIMMR_EINVAL;
+  e->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return SIMMR_OK;
+}
+
+// ---- staging ------------------------------------------------------------------
+int simmr_stage_genome(simmr_engine* e, uint32_t genome_idx, uint32_t n_contigs,
+                       const uint8_t* const* contig_ascii, const uint64_t* contig_len,
+                       const uint64_t* contig_size) {
+  if (!e) return SIMMR_EINVAL;
+  if (!contig_ascii || !contig_len || n_contigs == 0) return e->fail(SIMMR_EINVAL, "empty genome");
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (genome_idx >= e->genomes.size()) e->genomes.resize(genome_idx + 1);
+  GenomeHost& g = e->genomes[genome_idx];
+  g.staged = false;
+  int rc = layout_genome(e, g, n_contigs, contig_len, contig_size);
+  if (rc) return rc;
+  const uint64_t CHUNK = 64ull << 20;  // bases per upload, multiple of 64
+  DevBuf stage;
+  uint64_t maxlen = 0;
+  for (uint32_t c = 0; c < n_contigs; c++) maxlen = std::max(maxlen, contig_len[c]);
+  if (!stage.ensure(std::min(maxlen, CHUNK) + 64)) return e->fail(SIMMR_ENOMEM, "staging buffer allocation failed");
+  HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
+  uint32_t* d_any = e->d_err.as<uint32_t>() + 1;
+  for (uint32_t c = 0; c < n_contigs; c++) {
+    for (uint64_t off = 0; off < contig_len[c]; off += CHUNK) {
+      const uint64_t n = std::min(CHUNK, contig_len[c] - off);
+      HIP_TRY(e, hipMemcpyAsync(stage.p, contig_ascii[c] + off, n, hipMemcpyHostToDevice, e->stream));
+      hipLaunchKernelGGL(k_pack_ascii, dim3(grid_for((n + 31) / 32, 256)), dim3(256), 0, e->stream,
+                         stage.as<uint8_t>(), n, g.contigs[c].base + off,
+                         g.packed.as<uint32_t>() + FRONT_PAD_WORDS, g.mask.as<uint32_t>() + FRONT_PAD_WORDS,
+                         d_any);
+      rc = sync_check(e, "k_pack_ascii");  // the staging buffer is reused
+      if (rc) { stage.release(); return rc; }
+    }
+  }
+  stage.release();
+  uint32_t any = 0;
+  HIP_TRY(e, hipMemcpyAsync(&any, d_any, 4, hipMemcpyDeviceToHost, e->stream));
+  rc = sync_check(e, "staging");
+  if (rc) return rc;
+  g.has_exc = any != 0;
+  g.staged = true;
+  return refresh_genome_table(e);
+}
+
+int simmr_stage_synthetic(simmr_engine* e, uint32_t genome_idx, uint32_t n_contigs,
+                          const uint64_t* contig_len, uint64_t splitmix_seed) {
+  if (!e) return SIMMR_EINVAL;
+  if (!contig_len || n_contigs == 0) return e->fail(SIMMR_EINVAL, "empty genome");
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (genome_idx >= e->genomes.size()) e->genomes.resize(genome_idx + 1);
+  GenomeHost& g = e->genomes[genome_idx];
+  g.staged = false;
+  int rc = layout_genome(e, g, n_contigs, contig_len, nullptr);
+  if (rc) return rc;
+  const uint64_t n64 = g.plane_bases / 32;
+  if (n64)
+    hipLaunchKernelGGL(k_synth, dim3(grid_for(n64, 256)), dim3(256), 0, e->stream,
+                       reinterpret_cast<uint64_t*>(g.packed.as<uint32_t>() + FRONT_PAD_WORDS), n64,
+                       splitmix_seed);
+  rc = sync_check(e, "k_synth");
+  if (rc) return rc;
+  g.has_exc = false;
+  g.staged = true;
+  return refresh_genome_table(e);
+}
+
+int simmr_unstage_contig(simmr_engine* e, uint32_t genome_idx, uint32_t contig, uint64_t first,
+                         uint64_t count, uint8_t* dst_host) {
+  if (!e) return SIMMR_EINVAL;
+  int rc = check_genome(e, genome_idx);
+  if (rc) return rc;
+  GenomeHost& g = e->genomes[genome_idx];
+  if (contig >= g.contigs.size() || first + count > g.contigs[contig].len)
+    return e->fail(SIMMR_ERANGE, "unstage range outside the contig");
+  if (count == 0) return SIMMR_OK;
+  DevBuf tmp;
+  if (!tmp.ensure(count)) return e->fail(SIMMR_ENOMEM, "unstage buffer allocation failed");
+  hipLaunchKernelGGL(k_unpack, dim3(grid_for(count, 256)), dim3(256), 0, e->stream,
+                     g.packed.as<uint32_t>() + FRONT_PAD_WORDS,
+                     g.has_exc ? g.mask.as<uint32_t>() + FRONT_PAD_WORDS : (const uint32_t*)nullptr,
+                     g.contigs[contig].base + first, count, tmp.as<uint8_t>());
+  hipError_t s = hipMemcpyAsync(dst_host, tmp.p, count, hipMemcpyDeviceToHost, e->stream);
+  rc = (s == hipSuccess) ? sync_check(e, "k_unpack") : e->fail(SIMMR_ENODEV, "unstage copy: %s", hipGetErrorString(s));
+  tmp.release();
+  return rc;
+}
+
+int simmr_genome_info(const simmr_engine* e, uint32_t genome_idx, uint32_t* n_contigs, uint64_t* total_size) {
+  if (!e || genome_idx >= e->genomes.size() || !e->genomes[genome_idx].staged) return SIMMR_EINVAL;
+  if (n_contigs) *n_contigs = (uint32_t)e->genomes[genome_idx].contigs.size();
+  if (total_size) *total_size = e->genomes[genome_idx].total_size;
+  return SIMMR_OK;
+}
+
+// ---- paired-end -----------------------------------------------------------------
+int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profile* profile,
+                  uint64_t genome_reads, int has_seed, uint64_t seed, simmr_range shard,
+                  simmr_plan_info* info) {
+  if (!e) return SIMMR_EINVAL;
+  e->plan_kind = PLAN_NONE;
+  HIP_TRY(e, hipSetDevice(e->device));
+  int rc = check_genome(e, genome_idx);
+  if (rc) return rc;
+  ProfileDev prof;
+  if ((rc = make_profile(e, profile, false, &prof))) return rc;
+  GenomeHost& g = e->genomes[genome_idx];
+  // simulate.rs:220-225: a sequence not larger than minimum_genome_size() is an
+  // Err that the caller unwrap()s (simulate.rs:186) — any such sequence can be drawn.
+  for (size_t c = 0; c < g.contigs.size(); c++)
+    if (g.contigs[c].size <= prof.required)
+      return e->fail(SIMMR_EGENOME, "Genome size (%llunt) is smaller than the required length (%u)",
+                     (unsigned long long)g.contigs[c].size, prof.required);
+  const uint64_t n_pairs = genome_reads / 2;  // simulate.rs:179
+  uint64_t first = std::min(shard.first, n_pairs);
+  uint64_t count = std::min(shard.count, n_pairs - first);
+  if (!has_seed) seed = os_entropy_u64();  // simulate.rs:174 from_entropy()
+  const bool seeds2 = prof.kind != SIMMR_K_PERFECT_SHORT;
+  if ((rc = ensure_plan_arrays(e, count, seeds2, false))) return rc;
+  HIP_TRY(e, hipEventRecord(e->ev_a, e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
+  uint64_t end_slot = 0, total = 0;
+  if (count > 0) {
+    rc = run_outer(e, seed, g.contigs.size(), 0, first + count, first, count, e->u_contig.as<uint32_t>(),
+                   e->u_seed.as<uint64_t>(), &end_slot);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
+                       e->d_genomes.as<GenomeDev>(), genome_idx, count, e->u_contig.as<uint32_t>(),
+                       e->u_seed.as<uint64_t>(), plan_arrays(e, seeds2), e->d_tables.as<Tables>(),
+                       e->d_err.as<uint32_t>());
+  }
+  if ((rc = scan_offsets(e, count, &total))) return rc;
+  HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
+  uint32_t errw = 0;
+  if ((rc = read_err_word(e, &errw))) return rc;
+  if (errw & SIMMR_ERRBIT_GENOME) return e->fail(SIMMR_EGENOME, "a sequence is smaller than the required length");
+  if (errw & SIMMR_ERRBIT_SLICE)
+    return e->fail(SIMMR_ERANGE, "a read would extend past its sequence (the reference panics on this slice)");
+  (void)hipEventElapsedTime(&e->last_plan_ms, e->ev_a, e->ev_b);
+  e->plan_kind = PLAN_PE;
+  e->prof = prof;
+  e->plan_genome = genome_idx;
+  e->plan_first = first;
+  e->plan_units = count;
+  e->plan_total_bases = total;
+  e->plan_paired = true;
+  if (info) {
+    memset(info, 0, sizeof *info);
+    info->n_units = count;
+    info->n_reads = 2 * count;
+    info->total_bases = total;
+    info->seed_used = seed;
+    info->outer_slots = end_slot;
+  }
+  return SIMMR_OK;
+}
+
+static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads_out* out) {
+  const uint64_t n_units = e->plan_units;
+  const bool paired = e->plan_paired;
+  const uint64_t n_reads = paired ? 2 * n_units : n_units;
+  int rc = check_out(e, out, n_reads, e->plan_total_bases);
+  if (rc) return rc;
+  const bool seeds2 = paired && e->prof.kind != SIMMR_K_PERFECT_SHORT;
+  PlanArrays pl = plan_arrays(e, seeds2);
+  const uint32_t* u_genome = paired ? nullptr : e->u_genome.as<uint32_t>();
+  hipLaunchKernelGGL(k_write_meta, dim3(grid_for(n_units + 1, 256)), dim3(256), 0, e->stream,
+                     paired ? 1u : 0u, n_units, e->plan_first, read_id_base, e->plan_genome, pl,
+                     e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome, out_cols(out));
+  unsigned long long* counters = e->d_counters.as<unsigned long long>();
+  HIP_TRY(e, hipEventRecord(e->ev_c, e->stream));
+  if (n_units > 0) {
+    if (e->prof.kind == SIMMR_K_PERFECT_SHORT) {
+      const uint64_t groups = (n_reads + PERFECT_GROUP - 1) / PERFECT_GROUP;
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(groups, (uint64_t)e->n_cu * 8);
+      hipLaunchKernelGGL(k_emit_perfect_pe, dim3(grid), dim3(256), 0, e->stream, e->d_genomes.as<GenomeDev>(),
+                         e->plan_genome, n_units, e->prof.read_length, pl, e->u_contig.as<uint32_t>(), out->seq,
+                         out->qual, 60u + out->qual_offset);
+    } else {
+      hipLaunchKernelGGL(k_emit_stream, dim3(stream_grid(e, n_units)), dim3(64), 0, e->stream, e->prof,
+                         paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl,
+                         e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome,
+                         e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset,
+                         e->d_tables.as<Tables>(), counters);
+    }
+  }
+  HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
+  if (n_units > 0) {
+    const bool perfect = e->prof.kind == SIMMR_K_PERFECT_SHORT;
+    const bool acgt_all = perfect && !e->genomes[e->plan_genome].has_exc;
+    hipLaunchKernelGGL(k_count_plan, dim3(grid_for(n_units, 256)), dim3(256), 0, e->stream, paired ? 1u : 0u,
+                       n_units, pl, perfect ? 60u : 0u, acgt_all ? 1u : 0u, counters);
+  }
+  hipError_t s = hipGetLastError();
+  if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "emit launch failed: %s", hipGetErrorString(s));
+  return SIMMR_OK;
+}
+
+int simmr_pe_emit(simmr_engine* e, uint32_t read_id_base, const simmr_reads_out* out) {
+  if (!e) return SIMMR_EINVAL;
+  if (e->plan_kind != PLAN_PE) return e->fail(SIMMR_ESTATE, "simmr_pe_emit called without a paired-end plan");
+  HIP_TRY(e, hipSetDevice(e->device));
+  return emit_common(e, read_id_base, out);
+}
+
+// ---- long reads -------------------------------------------------------------------
+int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_idx,
+                    const uint64_t* genome_reads, const simmr_error_profile* profile, int has_seed,
+                    uint64_t seed, simmr_range shard, simmr_plan_info* info) {
+  if (!e) return SIMMR_EINVAL;
+  e->plan_kind = PLAN_NONE;
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (!genome_idx || !genome_reads || n_genomes == 0) return e->fail(SIMMR_EINVAL, "no genomes");
+  int rc;
+  ProfileDev prof;
+  if ((rc = make_profile(e, profile, true, &prof))) return rc;
+  uint64_t total_reads = 0;
+  for (uint32_t g = 0; g < n_genomes; g++) {
+    if ((rc = check_genome(e, genome_idx[g]))) return rc;
+    total_reads += genome_reads[g];
+  }
+  uint64_t first = std::min(shard.first, total_reads);
+  uint64_t count = std::min(shard.count, total_reads - first);
+  const bool per_read = !has_seed || profile->length_mode == SIMMR_LEN_PER_READ;
+  if (!has_seed) seed = os_entropy_u64();
+  if ((rc = ensure_plan_arrays(e, count, false, true))) return rc;
+  HIP_TRY(e, hipEventRecord(e->ev_a, e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
+
+  // runs of consecutive reads per genome (simulate.rs:353-356)
+  std::vector<LongGenomeRun> runs;
+  {
+    uint64_t acc = 0;
+    for (uint32_t g = 0; g < n_genomes; g++) {
+      if (genome_reads[g] == 0) continue;
+      LongGenomeRun r{};
+      r.first_read = acc;
+      r.n_reads = genome_reads[g];
+      r.genome = genome_idx[g];
+      r.max_size = e->genomes[genome_idx[g]].max_size;
+      runs.push_back(r);
+      acc += genome_reads[g];
+    }
+  }
+  uint32_t L0 = 0;
+  uint64_t end_slot = 0, total = 0;
+  if (count > 0 && !per_read) {
+    // get_random_read_length(seed): the same value for every read (simulate.rs:358)
+    uint32_t* d_L0 = e->d_scalars.as<uint32_t>();
+    hipLaunchKernelGGL(k_const_length, dim3(1), dim3(64), 0, e->stream, prof, seed, e->d_tables.as<Tables>(), d_L0);
+    HIP_TRY(e, hipMemcpyAsync(&L0, d_L0, 4, hipMemcpyDeviceToHost, e->stream));
+    if ((rc = sync_check(e, "k_const_length"))) return rc;
+    if (L0 == 0) return e->fail(SIMMR_ERANGE, "the run-wide read length drew 0 (the reference panics in gen_range(0..0))");
+    // usable sequences per genome (simulate.rs:362-367)
+    std::vector<uint32_t> usable;
+    std::vector<size_t> uoff(runs.size());
+    for (size_t r = 0; r < runs.size(); r++) {
+      const GenomeHost& g = e->genomes[runs[r].genome];
+      uoff[r] = usable.size();
+      uint32_t n = 0;
+      for (size_t c = 0; c < g.contigs.size(); c++)
+        if (g.contigs[c].size > L0) { usable.push_back((uint32_t)c); n++; }
+      runs[r].n_usable = n;
+      if (n == 0)
+        return e->fail(SIMMR_EGENOME,
+                       "genome %u has no sequence longer than the read length %u (the reference loops forever, simulate.rs:370)",
+                       runs[r].genome, L0);
+    }
+    if (!e->d_usable.ensure(std::max<size_t>(usable.size(), 1) * 4)) return e->fail(SIMMR_ENOMEM, "usable table allocation failed");
+    HIP_TRY(e, hipMemcpyAsync(e->d_usable.p, usable.data(), usable.size() * 4, hipMemcpyHostToDevice, e->stream));
+    for (size_t r = 0; r < runs.size(); r++) runs[r].usable = e->d_usable.as<uint32_t>() + uoff[r];
+    // ONE StdRng across all genomes (simulate.rs:348): walk it segment by
+    // segment; a segment is a maximal range of runs with the same gen_range bound.
+    uint64_t slot = 0;
+    size_t r = 0;
+    while (r < runs.size()) {
+      size_t r2 = r;
+      uint64_t seg_reads = 0;
+      while (r2 < runs.size() && runs[r2].n_usable == runs[r].n_usable) { seg_reads += runs[r2].n_reads; r2++; }
+      const uint64_t seg_first = runs[r].first_read;
+      if (seg_first >= first + count) break;  // nothing of the shard lies beyond
+      // intersection of the shard with this segment, relative to the segment
+      const uint64_t lo = std::max(first, seg_first), hi = std::min(first + count, seg_first + seg_reads);
+      const uint64_t e_first = lo > seg_first ? lo - seg_first : 0;
+      const uint64_t e_count = hi > lo ? hi - lo : 0;
+      // units needed from this segment: all of it if the shard continues past it
+      const uint64_t n_total = (first + count > seg_first + seg_reads) ? seg_reads : (hi - seg_first);
+      rc = run_outer(e, seed, runs[r].n_usable, slot, n_total, e_first, e_count,
+                     e->u_contig.as<uint32_t>() + (lo - first), e->u_seed.as<uint64_t>() + (lo - first), &slot);
+      if (rc) return rc;
+      r = r2;
+    }
+    end_slot = slot;
+  }
+  if (!e->d_runs.ensure(std::max<size_t>(runs.size(), 1) * sizeof(LongGenomeRun))) return e->fail(SIMMR_ENOMEM, "run table allocation failed");
+  HIP_TRY(e, hipMemcpyAsync(e->d_runs.p, runs.data(), runs.size() * sizeof(LongGenomeRun), hipMemcpyHostToDevice, e->stream));
+  if (count > 0) {
+    if (!per_read) {
+      hipLaunchKernelGGL(k_plan_long_ref, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream,
+                         e->d_genomes.as<GenomeDev>(), e->d_runs.as<LongGenomeRun>(), (uint32_t)runs.size(), first,
+                         count, L0, e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
+                         e->u_seed.as<uint64_t>(), plan_arrays(e, false), e->d_err.as<uint32_t>());
+    } else {
+      hipLaunchKernelGGL(k_plan_long_per_read, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0,
+                         e->stream, prof, e->d_genomes.as<GenomeDev>(), e->d_runs.as<LongGenomeRun>(),
+                         (uint32_t)runs.size(), seed, first, count, e->u_contig.as<uint32_t>(),
+                         e->u_genome.as<uint32_t>(), e->u_seed.as<uint64_t>(), plan_arrays(e, false),
+                         e->d_tables.as<Tables>(), e->d_err.as<uint32_t>());
+    }
+  }
+  if ((rc = scan_offsets(e, count, &total))) return rc;
+  HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
+  uint32_t errw = 0;
+  if ((rc = read_err_word(e, &errw))) return rc;
+  if (errw & SIMMR_ERRBIT_GENOME) return e->fail(SIMMR_EGENOME, "no usable sequence for a drawn read length");
+  if (errw & SIMMR_ERRBIT_SLICE)
+    return e->fail(SIMMR_ERANGE, "a read would extend past its sequence (the reference panics on this slice)");
+  (void)hipEventElapsedTime(&e->last_plan_ms, e->ev_a, e->ev_b);
+  e->plan_kind = PLAN_LONG;
+  e->prof = prof;
+  e->plan_genome = 0;
+  e->plan_first = first;
+  e->plan_units = count;
+  e->plan_total_bases = total;
+  e->plan_paired = false;
+  if (info) {
+    memset(info, 0, sizeof *info);
+    info->n_units = count;
+    info->n_reads = count;
+    info->total_bases = total;
+    info->seed_used = seed;
+    info->outer_slots = end_slot;
+    info->const_read_length = per_read ? 0 : L0;
+  }
+  return SIMMR_OK;
+}
+
+int simmr_long_emit(simmr_engine* e, uint32_t read_id_base, const simmr_reads_out* out) {
+  if (!e) return SIMMR_EINVAL;
+  if (e->plan_kind != PLAN_LONG) return e->fail(SIMMR_ESTATE, "simmr_long_emit called without a long-read plan");
+  HIP_TRY(e, hipSetDevice(e->device));
+  return emit_common(e, read_id_base, out);
+}
+
+// ---- counters / timing ---------------------------------------------------------------
+int simmr_counters(simmr_engine* e, uint64_t* dst_device, uint64_t* dst_host) {
+  if (!e) return SIMMR_EINVAL;
+  if (dst_device)
+    HIP_TRY(e, hipMemcpyAsync(dst_device, e->d_counters.p, 8 * SIMMR_N_COUNTERS, hipMemcpyDeviceToDevice, e->stream));
+  if (dst_host) {
+    HIP_TRY(e, hipMemcpyAsync(dst_host, e->d_counters.p, 8 * SIMMR_N_COUNTERS, hipMemcpyDeviceToHost, e->stream));
+    return sync_check(e, "counter readback");
+  }
+  return SIMMR_OK;
+}
+
+int simmr_counters_reset(simmr_engine* e) {
+  if (!e) return SIMMR_EINVAL;
+  HIP_TRY(e, hipMemsetAsync(e->d_counters.p, 0, 8 * SIMMR_N_COUNTERS, e->stream));
+  return SIMMR_OK;
+}
+
+int simmr_last_emit_kernel_ms(simmr_engine* e, float* ms) {
+  if (!e || !ms) return SIMMR_EINVAL;
+  int rc = sync_check(e, "emit");
+  if (rc) return rc;
+  HIP_TRY(e, hipEventElapsedTime(&e->last_emit_ms, e->ev_c, e->ev_d));
+  *ms = e->last_emit_ms;
+  return SIMMR_OK;
+}
+
+int simmr_last_plan_ms(simmr_engine* e, float* ms) {
+  if (!e || !ms) return SIMMR_EINVAL;
+  *ms = e->last_plan_ms;
+  return SIMMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1038 @@
+// kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the
+// simmr hot path: reference staging, outer seed stream, per-unit planning,
+// offset scan and the emit kernels.  See DESIGN.md for the data layout and the
+// roofline of each kernel.  Reference behaviour being reproduced:
+//   simmr/src/simulate.rs:165-302 (paired-end), :323-523 (long reads)
+//   simmr/src/error_profiles/{perfect_short,minimal_short,perfect_long,minimal_long}.rs
+//   simmr/src/util.rs:15-37 (reverse complement), :69-111 (Phred conversions)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.hpp"
+#include "rng_device.hpp"
+
+namespace simmr {
+
+// ===========================================================================
+// 1. Reference staging
+// ===========================================================================
+
+// ASCII -> (2-bit code, exception bit).  Exceptions keep a 1-bit payload in the
+// code plane: 0 = 'N', 1 = '-'.  Lower-case and U follow needletail's
+// normalize(false) as used at genome.rs:114.
+SIMMR_DEV uint32_t ascii_to_code3(uint32_t ch) {
+  switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': case 'U': case 'u': return 3;
+    case '-': case '.': case '~': return 4 | 1;
+    default: return 4 | 0;  // 'N' and everything needletail maps to N
+  }
+}
+
+// One thread packs 32 bases: two code words + one exception word.
+// `dst_base` (in bases, multiple of 64) is where ascii[0] lands.
+extern "C" __global__ void __launch_bounds__(256)
+k_pack_ascii(const uint8_t* __restrict__ ascii, uint64_t n, uint64_t dst_base,
+             uint32_t* __restrict__ packed, uint32_t* __restrict__ mask,
+             uint32_t* __restrict__ any_exc) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t b0 = t * 32;
+  if (b0 >= n) return;
+  uint32_t w0 = 0, w1 = 0, m = 0;
+  uint32_t cnt = (uint32_t)((n - b0) < 32 ? (n - b0) : 32);
+  for (uint32_t i = 0; i < cnt; i++) {
+    uint32_t c = ascii_to_code3(ascii[b0 + i]);
+    uint32_t code = c & 3u;
+    if (i < 16) w0 |= code << (2 * i); else w1 |= code << (2 * (i - 16));
+    m |= (c >> 2) << i;
+  }
+  uint64_t d = dst_base + b0;
+  packed[d >> 4] = w0;
+  packed[(d >> 4) + 1] = w1;
+  mask[d >> 5] = m;
+  if (m) atomicOr(any_exc, 1u);
+}
+
+// Synthetic reference: u64 word k of the packed plane = SplitMix64 output k.
+extern "C" __global__ void __launch_bounds__(256)
+k_synth(uint64_t* __restrict__ packed64, uint64_t n_words64, uint64_t seed) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_words64) packed64[t] = splitmix64_at(seed, t);
+}
+
+// Packed -> ASCII (tests / debugging only; not on the hot path).
+extern "C" __global__ void __launch_bounds__(256)
+k_unpack(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ mask, uint64_t base,
+         uint64_t n, uint8_t* __restrict__ dst) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint64_t p = base + t;
+  uint32_t code = (packed[p >> 4] >> ((p & 15) * 2)) & 3u;
+  if (mask) code |= ((mask[p >> 5] >> (p & 31)) & 1u) << 2;
+  dst[t] = (uint8_t)"ACGTN-N-"[code];
+}
+
+// ===========================================================================
+// 2. Outer seed stream (simulate.rs:172-184 and :348-378)
+//
+// The reference walks ONE StdRng sequentially: gen_range(0..n) (which rejects
+// and redraws — half of the time when n == 1) and then gen::<u64>() per unit.
+// ChaCha is counter based, so every 8-slot block is generated independently;
+// the sequential part is a two-state transducer (NEED_IDX / NEED_SEED) whose
+// per-block transfer functions compose associatively:
+//   classify  -> per-block function, reduced per workgroup
+//   scan      -> one workgroup resolves workgroup start states + unit bases
+//   emit      -> every block re-derives its words and writes its units.
+// ===========================================================================
+
+// f: state -> (state, units emitted).  e0/c0 for start NEED_IDX, e1/c1 for
+// start NEED_SEED.  Packed: e0 | e1<<1 | c0<<2 (15 bits) | c1<<17 (15 bits).
+SIMMR_DEV uint32_t fs_make(uint32_t e0, uint32_t c0, uint32_t e1, uint32_t c1) {
+  return e0 | (e1 << 1) | (c0 << 2) | (c1 << 17);
+}
+SIMMR_DEV uint32_t fs_compose(uint32_t f, uint32_t g) {  // f first, then g
+  uint32_t ge0 = g & 1u, ge1 = (g >> 1) & 1u, gc0 = (g >> 2) & 0x7fffu, gc1 = g >> 17;
+  uint32_t fe0 = f & 1u, fe1 = (f >> 1) & 1u, fc0 = (f >> 2) & 0x7fffu, fc1 = f >> 17;
+  uint32_t e0 = fe0 ? ge1 : ge0, c0 = fc0 + (fe0 ? gc1 : gc0);
+  uint32_t e1 = fe1 ? ge1 : ge0, c1 = fc1 + (fe1 ? gc1 : gc0);
+  return fs_make(e0, c0, e1, c1);
+}
+#define FS_IDENTITY 0x2u /* e0 = 0, e1 = 1, no units */
+
+struct BlockWords {
+  uint64_t v[8];
+};
+
+SIMMR_DEV void outer_block(const OuterParams& P, uint64_t b, BlockWords& w, uint32_t& accmask) {
+  uint32_t o[16];
+  chacha12_block(P.key, b, o);
+  accmask = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    w.v[j] = ((uint64_t)o[2 * j + 1] << 32) | o[2 * j];
+    uint64_t lo = w.v[j] * P.range;
+    accmask |= (lo <= P.zone ? 1u : 0u) << j;
+  }
+}
+
+// transfer function of one block; slots below `skip` are not part of the run.
+SIMMR_DEV uint32_t outer_summary(uint32_t accmask, uint32_t skip) {
+  uint32_t s0 = 0, c0 = 0, s1 = 1, c1 = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if ((uint32_t)j < skip) continue;
+    uint32_t a = (accmask >> j) & 1u;
+    if (s0) { c0++; s0 = 0; } else { s0 = a; }
+    if (s1) { c1++; s1 = 0; } else { s1 = a; }
+  }
+  return fs_make(s0, c0, s1, c1);
+}
+
+// ordered reduction / exclusive scan of transfer functions inside a 256-thread
+// workgroup.  Returns this thread's exclusive prefix; *total = whole workgroup.
+SIMMR_DEV uint32_t wg_fs_exclusive_scan(uint32_t f, uint32_t* lds4, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = f;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc = fs_compose(o, inc);
+  }
+  uint32_t exc = __shfl_up(inc, 1, 64);
+  if (lane == 0) exc = FS_IDENTITY;
+  if (lane == 63) lds4[wave] = inc;
+  __syncthreads();
+  uint32_t pre = FS_IDENTITY, tot = FS_IDENTITY;
+  for (uint32_t wv = 0; wv < 4; wv++) {
+    uint32_t t = lds4[wv];
+    if (wv < wave) pre = fs_compose(pre, t);
+    tot = fs_compose(tot, t);
+  }
+  __syncthreads();
+  *total = tot;
+  return fs_compose(pre, exc);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_outer_classify(OuterParams P, uint64_t first_block, uint64_t n_blocks, uint32_t first_skip,
+                 uint32_t* __restrict__ last_idx, uint32_t* __restrict__ wg_sums) {
+  __shared__ uint32_t lds4[4];
+  uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t f = FS_IDENTITY;
+  if (t < n_blocks) {
+    BlockWords w;
+    uint32_t acc;
+    outer_block(P, first_block + t, w, acc);
+    f = outer_summary(acc, t == 0 ? first_skip : 0);
+    last_idx[t] = (uint32_t)__umul64hi(w.v[7], P.range);
+  }
+  uint32_t total;
+  (void)wg_fs_exclusive_scan(f, lds4, &total);
+  if (threadIdx.x == 0) wg_sums[blockIdx.x] = total;
+}
+
+// One workgroup: resolves (start state, unit base) of every classify workgroup,
+// the totals, and which workgroups hold units [first, first+count).
+extern "C" __global__ void __launch_bounds__(256)
+k_outer_scan(const uint32_t* __restrict__ wg_sums, uint64_t n_wg, uint64_t first, uint64_t count,
+             OuterPrefix* __restrict__ wg_prefix, OuterScanResult* __restrict__ res) {
+  __shared__ uint64_t s_c0[256], s_c1[256];
+  __shared__ uint32_t s_e0[256], s_e1[256];
+  __shared__ uint64_t s_base[256];
+  __shared__ uint32_t s_state[256];
+  const uint32_t t = threadIdx.x;
+  const uint64_t chunk = (n_wg + 255) / 256;
+  const uint64_t lo = (uint64_t)t * chunk, hi = (lo + chunk < n_wg) ? lo + chunk : n_wg;
+  // compose my chunk with 64-bit counts
+  uint32_t e0 = 0, e1 = 1;
+  uint64_t c0 = 0, c1 = 0;
+  for (uint64_t w = lo; w < hi; w++) {
+    uint32_t g = wg_sums[w];
+    uint32_t ge0 = g & 1u, ge1 = (g >> 1) & 1u;
+    uint64_t gc0 = (g >> 2) & 0x7fffu, gc1 = g >> 17;
+    c0 += e0 ? gc1 : gc0; e0 = e0 ? ge1 : ge0;
+    c1 += e1 ? gc1 : gc0; e1 = e1 ? ge1 : ge0;
+  }
+  s_e0[t] = e0; s_e1[t] = e1; s_c0[t] = c0; s_c1[t] = c1;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t st = 0;  // the run starts in NEED_IDX
+    uint64_t base = 0;
+    for (int i = 0; i < 256; i++) {
+      s_state[i] = st; s_base[i] = base;
+      base += st ? s_c1[i] : s_c0[i];
+      st = st ? s_e1[i] : s_e0[i];
+    }
+    res->total_units = base;
+    res->end_state = st;
+  }
+  __syncthreads();
+  uint32_t st = s_state[t];
+  uint64_t base = s_base[t];
+  const uint64_t last = first + count;  // exclusive
+  for (uint64_t w = lo; w < hi; w++) {
+    OuterPrefix p; p.base = base; p.state = st; p.pad = 0;
+    wg_prefix[w] = p;
+    uint32_t g = wg_sums[w];
+    uint64_t gc = st ? (uint64_t)(g >> 17) : (uint64_t)((g >> 2) & 0x7fffu);
+    uint32_t ge = st ? ((g >> 1) & 1u) : (g & 1u);
+    uint64_t nb = base + gc;
+    if (count > 0) {
+      if (base <= first && first < nb) res->wg_lo = w;
+      if (base < last && last <= nb) res->wg_hi = w;
+    }
+    base = nb; st = ge;
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_outer_emit(OuterParams P, uint64_t first_block, uint64_t n_blocks, uint32_t first_skip,
+             uint64_t wg_lo, const uint32_t* __restrict__ last_idx,
+             const OuterPrefix* __restrict__ wg_prefix, uint64_t first, uint64_t count,
+             uint32_t* __restrict__ out_idx, uint64_t* __restrict__ out_seed,
+             uint64_t* __restrict__ end_slot) {
+  __shared__ uint32_t lds4[4];
+  const uint64_t wg = wg_lo + blockIdx.x;
+  const uint64_t t = wg * 256 + threadIdx.x;
+  uint32_t f = FS_IDENTITY, acc = 0, skip = 0;
+  BlockWords w;
+  if (t < n_blocks) {
+    outer_block(P, first_block + t, w, acc);
+    skip = (t == 0) ? first_skip : 0;
+    f = outer_summary(acc, skip);
+  }
+  uint32_t total;
+  uint32_t pre = wg_fs_exclusive_scan(f, lds4, &total);
+  if (t >= n_blocks) return;
+  OuterPrefix wp = wg_prefix[wg];
+  uint32_t st = wp.state ? ((pre >> 1) & 1u) : (pre & 1u);
+  uint64_t c = wp.base + (wp.state ? (uint64_t)(pre >> 17) : (uint64_t)((pre >> 2) & 0x7fffu));
+  uint32_t idx = 0;
+  if (st) idx = last_idx[t - 1];  // the accepted index draw sits in the previous block
+  const uint64_t last = first + count;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if ((uint32_t)j < skip) continue;
+    if (st) {
+      if (c >= first && c < last) {
+        out_idx[c - first] = idx;
+        out_seed[c - first] = w.v[j];
+        if (c == last - 1) *end_slot = (first_block + t) * 8 + (uint64_t)j + 1;
+      }
+      c++;
+      st = 0;
+    } else if ((acc >> j) & 1u) {
+      idx = (uint32_t)__umul64hi(w.v[j], P.range);
+      st = 1;
+    }
+  }
+}
+
+// ===========================================================================
+// 3. Per-unit planning (simulate.rs:211-258 for pairs, :478-491 for long reads)
+//    One lane per unit; each lane owns a LaneRng (one ChaCha block in LDS).
+// ===========================================================================
+
+#define PLAN_THREADS 256
+
+extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
+k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
+          const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
+          PlanArrays pl, const Tables* __restrict__ T, uint32_t* __restrict__ err) {
+  __shared__ uint32_t rows[PLAN_THREADS * 17];
+  uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
+  if (k >= n_units) return;
+  const GenomeDev G = genomes[genome];
+  const uint64_t size = G.contigs[u_contig[k]].size;
+  const uint64_t pe_seed = u_seed[k];
+  LaneRng rng;
+  rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);
+  uint64_t L = prof.read_length, I = prof.insert_size;
+  if (prof.kind == SIMMR_K_MINIMAL_SHORT) {
+    // minimal_short.rs:33-42 and :58-67: both re-seed with pe_seed, so both see
+    // the same standard-normal draw.
+    double z = rng.standard_normal(T);
+    L = sat_u16_f64(floor(__dadd_rn((double)prof.read_length, __dmul_rn(prof.read_length_std, z))));
+    I = sat_u16_f64(floor(__dadd_rn((double)prof.insert_size, __dmul_rn(prof.insert_size_std, z))));
+    rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);  // simulate.rs:227: fresh StdRng
+  }
+  const uint64_t required = prof.required;
+  if (size <= required) { atomicOr(err, SIMMR_ERRBIT_GENOME); return; }
+  uint8_t flags = SIMMR_FLAG_REVCOMP;
+  uint64_t fs = rng.gen_range_u64(0, size - required);  // simulate.rs:233
+  uint64_t re;
+  if (fs + I >= size || fs + I + L >= size) {           // simulate.rs:241-247
+    re = rng.gen_range_u64(fs, size - required);
+    flags |= SIMMR_FLAG_REDRAWN;
+  } else if ((int32_t)((uint32_t)(fs + I) - (uint32_t)L) < 0) {  // simulate.rs:250-251
+    re = 0;
+  } else {
+    re = fs + I - L;                                    // simulate.rs:253-256
+  }
+  // simulate.rs:266,270: rng.gen::<Option<u64>>() twice (bool, then u64 if Some)
+  uint64_t qs, ms;
+  if (rng.gen_bool()) qs = rng.next_u64(); else { qs = entropy_substitute(pe_seed, 1); flags |= SIMMR_FLAG_QSEED_SUBST; }
+  if (rng.gen_bool()) ms = rng.next_u64(); else { ms = entropy_substitute(pe_seed, 2); flags |= SIMMR_FLAG_MSEED_SUBST; }
+  if (prof.kind == SIMMR_K_PERFECT_SHORT) flags &= (uint8_t)~(SIMMR_FLAG_QSEED_SUBST | SIMMR_FLAG_MSEED_SUBST);
+  // Rust would panic on an out-of-range slice; never silently read out of bounds.
+  const uint64_t len = G.contigs[u_contig[k]].len;
+  if (fs + L > len || re + L > len) { atomicOr(err, SIMMR_ERRBIT_SLICE); L = 0; }
+  pl.len[k] = (uint32_t)L;
+  pl.a[k] = fs;
+  pl.b[k] = re;
+  pl.bytes[k] = 2 * L;
+  pl.flags[k] = flags;
+  if (pl.qs2) { pl.qs2[k] = qs; pl.ms2[k] = ms; }
+}
+
+// long reads, reference mode: contig + read_seed come from the outer stream,
+// the length is the run-wide constant (simulate.rs:358 with Some(seed)).
+extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
+k_plan_long_ref(const GenomeDev* __restrict__ genomes, const LongGenomeRun* __restrict__ runs,
+                uint32_t n_runs, uint64_t first_unit, uint64_t n_units, uint32_t L0,
+                uint32_t* __restrict__ u_contig, uint32_t* __restrict__ u_genome,
+                const uint64_t* __restrict__ u_seed, PlanArrays pl, uint32_t* __restrict__ err) {
+  __shared__ uint32_t rows[PLAN_THREADS * 17];
+  uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
+  if (k >= n_units) return;
+  const uint64_t gi = first_unit + k;  // global read index
+  uint32_t r = 0;
+  while (r + 1 < n_runs && gi >= runs[r + 1].first_read) r++;
+  const LongGenomeRun run = runs[r];
+  const GenomeDev G = genomes[run.genome];
+  const uint32_t contig = run.usable[u_contig[k]];  // idx-th usable sequence (simulate.rs:375)
+  const uint64_t size = G.contigs[contig].size;
+  LaneRng rng;
+  rng.seed_from_u64(u_seed[k], rows + threadIdx.x * 17);
+  uint64_t s = rng.gen_range_u64(0, L0);          // simulate.rs:484
+  uint64_t e = s + L0;                            // :485
+  if (e >= size) e = rng.gen_range_u64(s, size);  // :488-491
+  if (e > G.contigs[contig].len) { atomicOr(err, SIMMR_ERRBIT_SLICE); e = s; }
+  u_contig[k] = contig;
+  u_genome[k] = run.genome;
+  pl.len[k] = (uint32_t)(e - s);
+  pl.a[k] = s;
+  pl.b[k] = e;
+  pl.bytes[k] = e - s;
+  pl.flags[k] = 0;
+}
+
+// long reads, per-read mode (include/simmr_hip.h SIMMR_LEN_PER_READ): length,
+// contig and read seed all come from StdRng(per_read_seed(seed, read index)).
+extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
+k_plan_long_per_read(ProfileDev prof, const GenomeDev* __restrict__ genomes,
+                     const LongGenomeRun* __restrict__ runs, uint32_t n_runs, uint64_t seed,
+                     uint64_t first_unit, uint64_t n_units, uint32_t* __restrict__ u_contig,
+                     uint32_t* __restrict__ u_genome, uint64_t* __restrict__ u_seed, PlanArrays pl,
+                     const Tables* __restrict__ T, uint32_t* __restrict__ err) {
+  __shared__ uint32_t rows[PLAN_THREADS * 17];
+  uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
+  if (k >= n_units) return;
+  const uint64_t gi = first_unit + k;
+  uint32_t r = 0;
+  while (r + 1 < n_runs && gi >= runs[r + 1].first_read) r++;
+  const LongGenomeRun run = runs[r];
+  const GenomeDev G = genomes[run.genome];
+  LaneRng rng;
+  rng.seed_from_u64(per_read_seed(seed, gi), rows + threadIdx.x * 17);
+  uint32_t L = 0, contig = 0;
+  uint64_t read_seed = 0;
+  for (int tries = 0;; tries++) {
+    L = sat_u16_f32(floorf(rng.gamma_f32(T, prof.gamma_shape, prof.gamma_scale)));
+    if (L == 0 || run.max_size <= L) {
+      if (tries > 1000) { atomicOr(err, SIMMR_ERRBIT_GENOME); L = 0; break; }
+      continue;
+    }
+    uint64_t n_us = 0;
+    for (uint32_t c = 0; c < G.n_contigs; c++) n_us += (G.contigs[c].size > L) ? 1u : 0u;
+    uint64_t idx = rng.gen_range_u64(0, n_us);
+    read_seed = rng.next_u64();
+    uint64_t seen = 0;
+    for (contig = 0; contig < G.n_contigs; contig++)
+      if (G.contigs[contig].size > L) { if (seen == idx) break; seen++; }
+    break;
+  }
+  uint64_t s = 0, e = 0;
+  if (L) {
+    const uint64_t size = G.contigs[contig].size;
+    rng.seed_from_u64(read_seed, rows + threadIdx.x * 17);
+    s = rng.gen_range_u64(0, L);
+    e = s + L;
+    if (e >= size) e = rng.gen_range_u64(s, size);
+    if (e > G.contigs[contig].len) { atomicOr(err, SIMMR_ERRBIT_SLICE); e = s; }
+  }
+  u_contig[k] = contig;
+  u_genome[k] = run.genome;
+  u_seed[k] = read_seed;
+  pl.len[k] = (uint32_t)(e - s);
+  pl.a[k] = s;
+  pl.b[k] = e;
+  pl.bytes[k] = e - s;
+  pl.flags[k] = 0;
+}
+
+// get_random_read_length(seed) for the whole run (simulate.rs:358): one lane.
+extern "C" __global__ void k_const_length(ProfileDev prof, uint64_t seed,
+                                          const Tables* __restrict__ T, uint32_t* __restrict__ out) {
+  __shared__ uint32_t row[17];
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  LaneRng rng;
+  rng.seed_from_u64(seed, row);
+  *out = sat_u16_f32(floorf(rng.gamma_f32(T, prof.gamma_shape, prof.gamma_scale)));
+}
+
+// ===========================================================================
+// 4. Exclusive scan of per-unit byte counts -> CSR unit offsets
+// ===========================================================================
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8 /* per thread */
+
+SIMMR_DEV uint64_t wg_exclusive_scan_u64(uint64_t v, uint64_t* lds4, uint64_t* total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint64_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t o = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc += o;
+  }
+  if (lane == 63) lds4[wave] = inc;
+  __syncthreads();
+  uint64_t pre = 0, tot = 0;
+  for (uint32_t wv = 0; wv < 4; wv++) {
+    uint64_t t = lds4[wv];
+    if (wv < wave) pre += t;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return pre + inc - v;
+}
+
+extern "C" __global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_reduce(const uint64_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ wg_tot) {
+  __shared__ uint64_t lds4[4];
+  uint64_t base = ((uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
+  uint64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) s += in[base + i];
+  uint64_t tot;
+  (void)wg_exclusive_scan_u64(s, lds4, &tot);
+  if (threadIdx.x == 0) wg_tot[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of wg_tot in place; writes the grand total.
+extern "C" __global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_tops(uint64_t* __restrict__ wg_tot, uint64_t n_wg, uint64_t* __restrict__ grand) {
+  __shared__ uint64_t lds4[4];
+  __shared__ uint64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < n_wg; base += SCAN_THREADS) {
+    uint64_t i = base + threadIdx.x;
+    uint64_t v = (i < n_wg) ? wg_tot[i] : 0;
+    uint64_t tot;
+    uint64_t ex = wg_exclusive_scan_u64(v, lds4, &tot);
+    uint64_t carry = carry_s;
+    if (i < n_wg) wg_tot[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *grand = carry_s;
+}
+
+extern "C" __global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_apply(const uint64_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ wg_tot,
+             uint64_t* __restrict__ out /* n + 1 */) {
+  __shared__ uint64_t lds4[4];
+  uint64_t base = ((uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
+  uint64_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : 0; s += v[i]; }
+  uint64_t tot;
+  uint64_t ex = wg_exclusive_scan_u64(s, lds4, &tot) + wg_tot[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (base + i < n) out[base + i] = ex;
+    ex += v[i];
+    if (base + i == n - 1) out[n] = ex;
+  }
+}
+
+// ===========================================================================
+// 5. Emit: metadata columns
+// ===========================================================================
+extern "C" __global__ void __launch_bounds__(256)
+k_write_meta(uint32_t paired, uint64_t n_units, uint64_t first_unit, uint32_t read_id_base,
+             uint32_t genome_const, PlanArrays pl, const uint64_t* __restrict__ u_off,
+             const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
+             OutCols o) {
+  uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k > n_units) return;
+  if (k == n_units) {  // closing CSR offset
+    o.seq_off[paired ? 2 * n_units : n_units] = u_off[n_units];
+    return;
+  }
+  const uint64_t off = u_off[k];
+  const uint32_t L = pl.len[k];
+  const uint32_t id = read_id_base + (uint32_t)(first_unit + k);  // simulate.rs:85-89,274
+  const uint32_t contig = u_contig[k];
+  const uint32_t genome = u_genome ? u_genome[k] : genome_const;
+  if (paired) {
+    const uint64_t fs = pl.a[k], re = pl.b[k];
+    const uint64_t r0 = 2 * k, r1 = 2 * k + 1;
+    o.seq_off[r0] = off;
+    o.seq_off[r1] = off + L;
+    if (o.start) { o.start[r0] = fs; o.start[r1] = re + L; }  // simulate.rs:289,295
+    if (o.end) { o.end[r0] = fs + L; o.end[r1] = re; }        // simulate.rs:290,296
+    if (o.contig) { o.contig[r0] = contig; o.contig[r1] = contig; }
+    if (o.genome) { o.genome[r0] = genome; o.genome[r1] = genome; }
+    if (o.read_id) { o.read_id[r0] = id; o.read_id[r1] = id; }
+    if (o.flags) { o.flags[r0] = 0; o.flags[r1] = pl.flags[k]; }
+  } else {
+    o.seq_off[k] = off;
+    if (o.start) o.start[k] = pl.a[k];  // simulate.rs:515
+    if (o.end) o.end[k] = pl.b[k];      // simulate.rs:516
+    if (o.contig) o.contig[k] = contig;
+    if (o.genome) o.genome[k] = genome;
+    if (o.read_id) o.read_id[k] = id;
+    if (o.flags) o.flags[k] = pl.flags[k];
+  }
+}
+
+// ===========================================================================
+// 6. Emit: perfect-short pairs (perfect_short.rs:42-54) — pure data movement.
+//
+// Every thread produces one ALIGNED 16-byte chunk of the compact seq[] stream
+// and the matching chunk of qual[].  A chunk may straddle two reads (L is not a
+// multiple of 16): both pieces are gathered as 2-bit codes (mate 2 complement-
+// reversed in the code domain), spliced with shifts, and only then expanded to
+// ASCII with v_perm_b32 — so all stores are global_store_dwordx4.
+// ===========================================================================
+
+// 16 bases (32 bits of codes) starting at absolute base position p (may be
+// slightly negative: the plane has front padding).
+SIMMR_DEV uint32_t fetch_codes16(const uint32_t* __restrict__ packed, int64_t p) {
+  int64_t wi = p >> 4;
+  uint32_t sh = (uint32_t)(p & 15) * 2u;
+  uint32_t lo = packed[wi], hi = packed[wi + 1];
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+SIMMR_DEV uint32_t fetch_mask16(const uint32_t* __restrict__ mask, int64_t p) {
+  int64_t wi = p >> 5;
+  uint32_t sh = (uint32_t)(p & 31);
+  uint32_t lo = mask[wi], hi = mask[wi + 1];
+  return __builtin_amdgcn_alignbit(hi, lo, sh) & 0xffffu;
+}
+// reverse the order of the sixteen 2-bit groups
+SIMMR_DEV uint32_t reverse_groups16(uint32_t x) {
+  uint32_t y = __builtin_bitreverse32(x);
+  return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+// 16 mask bits -> 16 two-bit groups (each bit duplicated)
+SIMMR_DEV uint32_t spread16(uint32_t m) {
+  m = (m | (m << 8)) & 0x00FF00FFu;
+  m = (m | (m << 4)) & 0x0F0F0F0Fu;
+  m = (m | (m << 2)) & 0x33333333u;
+  m = (m | (m << 1)) & 0x55555555u;
+  return m * 3u;
+}
+// 4 codes (8 bits) + 4 exception bits -> 4 ASCII bytes
+SIMMR_DEV uint32_t expand4(uint32_t c8, uint32_t m4) {
+  uint32_t sel = (c8 | (c8 << 6) | (c8 << 12) | (c8 << 18)) & 0x03030303u;
+  uint32_t ms = (m4 | (m4 << 7) | (m4 << 14) | (m4 << 21)) & 0x01010101u;
+  sel |= ms << 2;
+  // selector 0-3 -> "ACGT" (src1), 4-7 -> "N-N-" (src0)
+  return __builtin_amdgcn_perm(0x2D4E2D4Eu, 0x54474341u, sel);
+}
+
+struct PieceSrc {
+  int64_t pos;   // absolute base position of output byte 0's source
+  uint32_t rev;  // mate 2: byte k comes from pos - k, complemented
+};
+
+SIMMR_DEV void gather_piece(const GenomeDev& G, const PieceSrc& s, uint32_t k, uint32_t& codes,
+                            uint32_t& exc) {
+  // codes for output bytes k .. k+15 of this read (garbage past the read end)
+  if (!s.rev) {
+    int64_t p = s.pos + (int64_t)k;
+    codes = fetch_codes16(G.packed, p);
+    exc = G.has_exc ? fetch_mask16(G.mask, p) : 0u;
+  } else {
+    int64_t p = s.pos - (int64_t)k - 15;
+    uint32_t c = fetch_codes16(G.packed, p);
+    codes = ~reverse_groups16(c);  // complement = 3 - code
+    if (G.has_exc) {
+      uint32_t m = fetch_mask16(G.mask, p);
+      exc = __builtin_bitreverse32(m) >> 16;
+      codes ^= spread16(exc);  // exceptions ('N', '-') are their own complement
+    } else {
+      exc = 0u;
+    }
+  }
+}
+
+#define PERFECT_GROUP 256u /* reads per workgroup iteration: 256*L is a multiple of 16 */
+
+SIMMR_DEV PieceSrc perfect_src(const GenomeDev& G, const PlanArrays& pl,
+                               const uint32_t* __restrict__ u_contig, uint64_t r, uint32_t L) {
+  const uint64_t u = r >> 1;
+  const uint64_t base = G.contigs[u_contig[u]].base;
+  PieceSrc s;
+  s.rev = (uint32_t)(r & 1u);
+  s.pos = (int64_t)(base + (s.rev ? pl.b[u] + L - 1 : pl.a[u]));
+  return s;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
+                  uint32_t L, PlanArrays pl, const uint32_t* __restrict__ u_contig,
+                  uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_byte) {
+  const GenomeDev G = genomes[genome];
+  const uint64_t n_reads = 2 * n_units;
+  const uint64_t n_groups = (n_reads + PERFECT_GROUP - 1) / PERFECT_GROUP;
+  const uint32_t q4 = qual_byte * 0x01010101u;
+  const uint4 qv = make_uint4(q4, q4, q4, q4);
+  for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const uint64_t r_base = g * PERFECT_GROUP;
+    const uint32_t n_in = (n_reads - r_base) < PERFECT_GROUP ? (uint32_t)(n_reads - r_base) : PERFECT_GROUP;
+    const uint32_t gbytes = n_in * L;  // < 2^24
+    const uint32_t n_chunks = (gbytes + 15u) >> 4;
+    const uint64_t gbyte0 = r_base * L;  // multiple of 16
+    for (uint32_t cl = threadIdx.x; cl < n_chunks; cl += 256) {
+      const uint32_t lb = cl << 4;
+      const uint32_t rl = lb / L;
+      const uint32_t k0 = lb - rl * L;
+      const uint32_t na = (L - k0) < 16u ? (L - k0) : 16u;  // bytes taken from read r_base + rl
+      uint32_t codes, exc;
+      gather_piece(G, perfect_src(G, pl, u_contig, r_base + rl, L), k0, codes, exc);
+      if (na < 16u) {
+        // splice in the following read(s) (several only if L < 16)
+        uint32_t filled = na, r = rl + 1;
+        codes &= (1u << (2 * filled)) - 1u;
+        exc &= (1u << filled) - 1u;
+        while (filled < 16u && r < n_in) {
+          uint32_t c2, e2;
+          gather_piece(G, perfect_src(G, pl, u_contig, r_base + r, L), 0, c2, e2);
+          const uint32_t take = (16u - filled) < L ? (16u - filled) : L;
+          if (take < 16u) { c2 &= (1u << (2 * take)) - 1u; e2 &= (1u << take) - 1u; }
+          codes |= c2 << (2 * filled);
+          exc |= e2 << filled;
+          filled += take;
+          r++;
+        }
+      }
+      uint4 out;
+      out.x = expand4(codes & 0xffu, exc & 0xfu);
+      out.y = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
+      out.z = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu);
+      out.w = expand4(codes >> 24, (exc >> 12) & 0xfu);
+      const uint64_t byte0 = gbyte0 + lb;
+      if (lb + 16u <= gbytes) {
+        *reinterpret_cast<uint4*>(seq + byte0) = out;
+        *reinterpret_cast<uint4*>(qual + byte0) = qv;
+      } else {  // last partial chunk of the shard
+        const uint32_t words[4] = {out.x, out.y, out.z, out.w};
+        for (uint32_t i = 0; lb + i < gbytes; i++) {
+          seq[byte0 + i] = (uint8_t)(words[i >> 2] >> (8 * (i & 3)));
+          qual[byte0 + i] = (uint8_t)qual_byte;
+        }
+      }
+    }
+  }
+}
+
+// ===========================================================================
+// 7. Emit: stream kernel for every profile that draws per-base numbers
+//    (minimal-short pairs, minimal-long / perfect-long reads).
+//
+// One wavefront per unit (pair or long read), persistent over a grid-stride
+// range of units.  Per 256-base tile the wave
+//   (a) generates, one ChaCha12 block per lane, every block of every StdRng
+//       stream the tile will read (mate-1 Phred + mutation stream, mate-2 Phred
+//       stream, mate-2 mutation stream) into LDS windows;
+//   (b) resolves the sequential ziggurat / gen_range consumption with ballots:
+//       all lanes assume "no extra words", the first lane that needed more
+//       (ziggurat slow path: 1.2 %; a substitution: ~1.3 %) is handled
+//       uniformly, and the lanes after it restart from the new stream position;
+//   (c) writes bases and qualities coalesced along the read.
+// ===========================================================================
+
+#define TB 256          /* bases per tile                                    */
+#define WPITCH 17       /* LDS words per block row (conflict-free pitch)     */
+#define WCAP_Q 40       /* blocks in a Phred window   (slots: 8 per block)   */
+#define WCAP_M 24       /* blocks in a mutation window (words: 16 per block) */
+#define SLACK_Q 16      /* extra u64 slots generated per tile                */
+#define SLACK_M 16      /* extra u32 words generated per tile                */
+#define LDS_BLOCKS (2 * WCAP_Q + 2 * WCAP_M)
+
+struct Win {
+  uint64_t seed;       // StdRng::seed_from_u64 argument of this stream
+  uint32_t first_blk;  // first block held
+  uint32_t nblk;       // blocks held (0 = invalid)
+  uint32_t slot;       // LDS row of first_blk
+  uint32_t home;       // LDS row of this window's own region
+  uint32_t cap;        // rows in the own region
+};
+
+struct Seg {
+  uint64_t seed;
+  uint32_t first_blk, nblk, slot;
+};
+
+// Lanes cooperatively generate up to 4 segments of blocks in as few ChaCha
+// passes as possible (one block per lane per pass).
+SIMMR_DEV void gen_segments(uint32_t* __restrict__ lds, const Seg* segs, int nseg) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t pre[5];
+  pre[0] = 0;
+#pragma unroll
+  for (int s = 0; s < 4; s++) pre[s + 1] = pre[s] + (s < nseg ? segs[s].nblk : 0u);
+  const uint32_t total = pre[4];
+  for (uint32_t base = 0; base < total; base += 64) {
+    const uint32_t j = base + lane;
+    if (j < total) {
+      uint64_t seed = segs[0].seed;
+      uint32_t fb = segs[0].first_blk, slot = segs[0].slot, p0 = 0;
+#pragma unroll
+      for (int s = 1; s < 4; s++)
+        if (s < nseg && j >= pre[s]) { seed = segs[s].seed; fb = segs[s].first_blk; slot = segs[s].slot; p0 = pre[s]; }
+      const Key key = pcg32_expand(seed);
+      uint32_t o[16];
+      chacha12_block(key, (uint64_t)(fb + (j - p0)), o);
+      uint32_t* row = lds + (slot + (j - p0)) * WPITCH;
+#pragma unroll
+      for (int i = 0; i < 16; i++) row[i] = o[i];
+    }
+  }
+  __syncthreads();
+}
+
+SIMMR_DEV uint32_t win_u32(const uint32_t* __restrict__ lds, const Win& w, uint32_t word) {
+  return lds[(w.slot + ((word >> 4) - w.first_blk)) * WPITCH + (word & 15u)];
+}
+SIMMR_DEV uint64_t win_u64(const uint32_t* __restrict__ lds, const Win& w, uint32_t slot) {
+  const uint32_t* row = lds + (w.slot + ((slot >> 3) - w.first_blk)) * WPITCH + (slot & 7u) * 2u;
+  return ((uint64_t)row[1] << 32) | row[0];
+}
+// (uniform) make sure blocks [blk_lo, blk_hi] are in the window; regenerate
+// the window from blk_lo into its own region otherwise.
+SIMMR_DEV void win_ensure(uint32_t* __restrict__ lds, Win& w, uint32_t blk_lo, uint32_t blk_hi) {
+  if (w.nblk != 0 && blk_lo >= w.first_blk && blk_hi < w.first_blk + w.nblk) return;
+  __syncthreads();
+  Seg s;
+  s.seed = w.seed; s.first_blk = blk_lo; s.slot = w.home;
+  s.nblk = w.cap < 64u ? w.cap : 64u;
+  w.first_blk = blk_lo; w.nblk = s.nblk; w.slot = w.home;
+  gen_segments(lds, &s, 1);
+}
+
+// Phred value of one accepted standard-normal draw.
+SIMMR_DEV uint32_t phred_of_z(const ProfileDev& prof, const Tables* __restrict__ T, double x) {
+  const float z = (float)x;  // StandardNormal for f32 = f64 sample cast down
+  if (prof.kind == SIMMR_K_PERFECT_LONG) {
+    // perfect_long.rs:68-77: acc = N(0.99, 0.05).min(0.9999); round(-10 log10(1 - acc)).
+    // The log is replaced by the host-libm-derived threshold table on (1 - acc).
+    float acc = __fadd_rn(prof.pl_mean, __fmul_rn(0.05f, z));
+    acc = fminf(acc, 0.9999f);
+    const float d = __fsub_rn(1.0f, acc);
+    uint32_t q = T->pl_first;
+    for (uint32_t i = 0; i < T->pl_count; i++) q += (d <= T->pl_thresh[i]) ? 1u : 0u;
+    return q;
+  }
+  // minimal_short.rs:90-101 / minimal_long.rs:88-98: floor(mean + 10 z) as u8
+  return sat_u8_f32(floorf(__fadd_rn(prof.mean_phred_f, __fmul_rn(10.0f, z))));
+}
+
+// simulate_phred_scores for bases [0, nb) of a tile; qpos = next u64 slot of the
+// stream.  Writes raw Phred to qout (LDS).
+SIMMR_DEV void phred_tile(uint32_t* __restrict__ lds, Win& w, uint32_t& qpos, uint32_t nb,
+                          uint8_t* __restrict__ qout, const ProfileDev& prof,
+                          const Tables* __restrict__ T) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t i = 0;
+  while (i < nb) {
+    const uint32_t nact = (nb - i) < 64u ? (nb - i) : 64u;
+    win_ensure(lds, w, qpos >> 3, (qpos + nact) >> 3);
+    const bool active = lane < nact;
+    uint64_t bits = 0;
+    if (active) bits = win_u64(lds, w, qpos + lane);
+    const uint32_t zi = (uint32_t)bits & 0xffu;
+    const double u = __longlong_as_double((long long)((bits >> 12) | 0x4000000000000000ULL)) - 3.0;
+    const double x = __dmul_rn(u, T->zig_x[zi]);
+    const bool fast = fabs(x) < T->zig_x[zi + 1];
+    const uint64_t ex = __ballot(active && !fast);
+    const uint32_t n_ok = ex ? (uint32_t)__builtin_ctzll(ex) : nact;
+    if (lane < n_ok) qout[i + lane] = (uint8_t)phred_of_z(prof, T, x);
+    i += n_ok;
+    qpos += n_ok;
+    if (ex) {
+      // ziggurat slow path for the attempt at slot qpos, executed uniformly.
+      const uint64_t b2 = win_u64(lds, w, qpos);
+      qpos++;
+      const uint32_t zj = (uint32_t)b2 & 0xffu;
+      const double u2 = __longlong_as_double((long long)((b2 >> 12) | 0x4000000000000000ULL)) - 3.0;
+      const double x2 = __dmul_rn(u2, T->zig_x[zj]);
+      bool got = false;
+      double xr = 0.0;
+      if (zj == 0) {
+        double xx = 1.0, yy = 0.0;
+        while (__dmul_rn(-2.0, yy) < __dmul_rn(xx, xx)) {
+          win_ensure(lds, w, qpos >> 3, (qpos + 1) >> 3);
+          const uint64_t a = win_u64(lds, w, qpos), b = win_u64(lds, w, qpos + 1);
+          qpos += 2;
+          const double x_ = __longlong_as_double((long long)((a >> 12) | 0x3FF0000000000000ULL)) - (1.0 - 2.220446049250313e-16 / 2.0);
+          const double y_ = __longlong_as_double((long long)((b >> 12) | 0x3FF0000000000000ULL)) - (1.0 - 2.220446049250313e-16 / 2.0);
+          xx = log(x_) / SIMMR_ZIG_R;
+          yy = log(y_);
+        }
+        xr = u2 < 0.0 ? xx - SIMMR_ZIG_R : SIMMR_ZIG_R - xx;
+        got = true;
+      } else {
+        win_ensure(lds, w, qpos >> 3, qpos >> 3);
+        const uint64_t a = win_u64(lds, w, qpos);
+        qpos++;
+        const double r = (double)(a >> 11) * (1.0 / 9007199254740992.0);
+        const double f1 = T->zig_f[zj + 1], f0 = T->zig_f[zj];
+        const double t = __dadd_rn(f1, __dmul_rn(__dsub_rn(f0, f1), r));
+        if (t < exp(__dmul_rn(__dmul_rn(-x2, x2), 0.5))) { got = true; xr = x2; }
+      }
+      if (got) {
+        if (lane == 0) qout[i] = (uint8_t)phred_of_z(prof, T, xr);
+        i++;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// simulate_point_mutations for a tile.  codes[]: 0-3 = ACGT, >= 4 = 'N' / '-'.
+SIMMR_DEV void mutate_tile(uint32_t* __restrict__ lds, Win& w, uint32_t& mpos, uint32_t nb,
+                           const uint8_t* __restrict__ q, uint8_t* __restrict__ codes,
+                           const Tables* __restrict__ T, uint32_t& n_subst) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t i = 0;
+  while (i < nb) {
+    const uint32_t nact = (nb - i) < 64u ? (nb - i) : 64u;
+    win_ensure(lds, w, mpos >> 4, (mpos + nact + 1) >> 4);
+    const bool active = lane < nact;
+    bool need = false;
+    if (active) {
+      const uint32_t wd = win_u32(lds, w, mpos + lane);
+      const float r = (float)(wd >> 8) * (1.0f / 16777216.0f);  // Standard f32
+      need = (r > T->acc[q[i + lane]]) && (codes[i + lane] < 4u);
+    }
+    const uint64_t ex = __ballot(need);
+    const uint32_t n_ok = ex ? (uint32_t)__builtin_ctzll(ex) : nact;
+    i += n_ok;
+    mpos += n_ok;
+    if (ex) {
+      // base i mutates: its f32 word is at mpos; then choose(&[3 others]) =
+      // gen_range(0..3u32): zone 0xBFFFFFFF (minimal_short.rs:122-125)
+      mpos++;
+      uint32_t k;
+      for (;;) {
+        win_ensure(lds, w, mpos >> 4, mpos >> 4);
+        const uint32_t v = win_u32(lds, w, mpos);
+        mpos++;
+        const uint64_t m = (uint64_t)v * 3u;
+        if ((uint32_t)m <= 0xBFFFFFFFu) { k = (uint32_t)(m >> 32); break; }
+      }
+      if (lane == 0) {
+        const uint32_t c = codes[i];
+        codes[i] = (uint8_t)(k + (k >= c ? 1u : 0u));  // k-th of the three other bases, in ACGT order
+      }
+      n_subst++;
+      i++;
+    }
+  }
+  __syncthreads();
+}
+
+SIMMR_DEV void load_codes(const GenomeDev& G, uint64_t pos0, uint32_t nb, uint8_t* __restrict__ dst,
+                          uint32_t& n_acgt) {
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t b = lane; b < nb; b += 64) {
+    const uint64_t p = pos0 + b;
+    uint32_t code = (G.packed[p >> 4] >> ((p & 15u) * 2u)) & 3u;
+    if (G.has_exc) code |= ((G.mask[p >> 5] >> (p & 31u)) & 1u) << 2;
+    dst[b] = (uint8_t)code;
+    n_acgt += code < 4u ? 1u : 0u;
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_emit_stream(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes,
+              uint32_t genome_const, uint64_t n_units, PlanArrays pl,
+              const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
+              const uint32_t* __restrict__ u_genome, const uint64_t* __restrict__ u_seed,
+              uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_offset,
+              const Tables* __restrict__ T, unsigned long long* __restrict__ counters) {
+  __shared__ uint32_t lds[LDS_BLOCKS * WPITCH];
+  __shared__ uint8_t q1[TB], c1[TB], q2[TB], c2[TB];
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t n_subst = 0, n_acgt = 0;
+  uint64_t qsum = 0;
+  const bool mutates = prof.kind != SIMMR_K_PERFECT_SHORT;
+
+  for (uint64_t k = blockIdx.x; k < n_units; k += gridDim.x) {
+    const uint32_t L = pl.len[k];
+    if (L == 0) continue;
+    const GenomeDev G = genomes[u_genome ? u_genome[k] : genome_const];
+    const uint64_t cbase = G.contigs[u_contig[k]].base;
+    const uint64_t o1 = u_off[k];
+    const uint64_t o2 = o1 + L;
+    const uint64_t src1 = cbase + pl.a[k];  // forward slice start
+    const uint64_t src2 = cbase + pl.b[k];  // mate-2 slice start (forward strand)
+
+    Win Aq, Am, Bq, Cm;
+    Aq.seed = u_seed[k]; Aq.home = 0; Aq.cap = WCAP_Q; Aq.nblk = 0; Aq.slot = 0; Aq.first_blk = 0;
+    Am.seed = Aq.seed; Am.home = 2 * WCAP_Q; Am.cap = WCAP_M; Am.nblk = 0; Am.slot = Am.home; Am.first_blk = 0;
+    Bq.seed = paired ? pl.qs2[k] : 0; Bq.home = WCAP_Q; Bq.cap = WCAP_Q; Bq.nblk = 0; Bq.slot = Bq.home; Bq.first_blk = 0;
+    Cm.seed = paired ? pl.ms2[k] : 0; Cm.home = 2 * WCAP_Q + WCAP_M; Cm.cap = WCAP_M; Cm.nblk = 0; Cm.slot = Cm.home; Cm.first_blk = 0;
+    uint32_t qposA = 0, mposA = 0, qposB = 0, mposC = 0;
+
+    for (uint32_t t0 = 0; t0 < L; t0 += TB) {
+      const uint32_t nb = (L - t0) < TB ? (L - t0) : TB;
+      // (a) one batched generation pass for everything this tile should need
+      Seg segs[4];
+      int ns = 0;
+      {
+        const uint32_t qlo = qposA >> 3, qhi = (qposA + nb + SLACK_Q) >> 3;
+        uint32_t n = qhi - qlo + 1; if (n > WCAP_Q) n = WCAP_Q;
+        Aq.first_blk = qlo; Aq.nblk = n; Aq.slot = Aq.home;
+        segs[ns].seed = Aq.seed; segs[ns].first_blk = qlo; segs[ns].nblk = n; segs[ns].slot = Aq.home; ns++;
+        const uint32_t mlo = mposA >> 4, mhi = (mposA + nb + SLACK_M) >> 4;
+        if (mlo >= qlo && mhi < qlo + n) {  // same stream: the Phred window already holds these blocks
+          Am.first_blk = Aq.first_blk; Am.nblk = Aq.nblk; Am.slot = Aq.slot;
+        } else {
+          uint32_t m = mhi - mlo + 1; if (m > WCAP_M) m = WCAP_M;
+          Am.first_blk = mlo; Am.nblk = m; Am.slot = Am.home;
+          segs[ns].seed = Am.seed; segs[ns].first_blk = mlo; segs[ns].nblk = m; segs[ns].slot = Am.home; ns++;
+        }
+      }
+      if (paired) {
+        const uint32_t qlo = qposB >> 3, qhi = (qposB + nb + SLACK_Q) >> 3;
+        uint32_t n = qhi - qlo + 1; if (n > WCAP_Q) n = WCAP_Q;
+        Bq.first_blk = qlo; Bq.nblk = n; Bq.slot = Bq.home;
+        segs[ns].seed = Bq.seed; segs[ns].first_blk = qlo; segs[ns].nblk = n; segs[ns].slot = Bq.home; ns++;
+        const uint32_t mlo = mposC >> 4, mhi = (mposC + nb + SLACK_M) >> 4;
+        uint32_t m = mhi - mlo + 1; if (m > WCAP_M) m = WCAP_M;
+        Cm.first_blk = mlo; Cm.nblk = m; Cm.slot = Cm.home;
+        segs[ns].seed = Cm.seed; segs[ns].first_blk = mlo; segs[ns].nblk = m; segs[ns].slot = Cm.home; ns++;
+      }
+      __syncthreads();
+      gen_segments(lds, segs, ns);
+
+      // (b) mate 1 / the long read
+      const bool alias = (Am.slot == Aq.slot);
+      phred_tile(lds, Aq, qposA, nb, q1, prof, T);
+      if (alias && (Aq.slot != Am.slot || Aq.first_blk != Am.first_blk)) Am.nblk = 0;  // window moved
+      load_codes(G, src1 + t0, nb, c1, n_acgt);
+      __syncthreads();
+      if (mutates) mutate_tile(lds, Am, mposA, nb, q1, c1, T, n_subst);
+      for (uint32_t b = lane; b < nb; b += 64) {
+        seq[o1 + t0 + b] = (uint8_t)"ACGTN-N-"[c1[b]];
+        const uint32_t qv = q1[b];
+        qual[o1 + t0 + b] = (uint8_t)(qv + qual_offset);
+        qsum += qv;
+      }
+      // (c) mate 2: mutate the forward-strand slice, then reverse-complement
+      if (paired) {
+        phred_tile(lds, Bq, qposB, nb, q2, prof, T);
+        load_codes(G, src2 + t0, nb, c2, n_acgt);
+        __syncthreads();
+        if (mutates) mutate_tile(lds, Cm, mposC, nb, q2, c2, T, n_subst);
+        for (uint32_t b = lane; b < nb; b += 64) {
+          seq[o2 + (L - 1 - (t0 + b))] = (uint8_t)"TGCAN-N-"[c2[b]];  // simulate.rs:283
+          const uint32_t qv = q2[b];
+          qual[o2 + t0 + b] = (uint8_t)(qv + qual_offset);              // quality is NOT reversed
+          qsum += qv;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // counters: one atomic per wave per counter
+  for (int d = 32; d > 0; d >>= 1) {
+    n_acgt += __shfl_down(n_acgt, d, 64);
+    qsum += __shfl_down(qsum, d, 64);
+  }
+  if (lane == 0 && counters) {
+    atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
+    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
+    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
+  }
+}
+
+// perfect-short has no per-base draws: its counters come from the plan.
+extern "C" __global__ void __launch_bounds__(256)
+k_count_plan(uint32_t paired, uint64_t n_units, PlanArrays pl, uint32_t const_q, uint32_t acgt_all,
+             unsigned long long* __restrict__ counters) {
+  __shared__ uint64_t lds4[4];
+  uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t bases = 0, redrawn = 0, subst = 0;
+  if (k < n_units) {
+    bases = pl.bytes[k];
+    const uint32_t f = pl.flags[k];
+    redrawn = (f & SIMMR_FLAG_REDRAWN) ? 1 : 0;
+    subst = ((f & SIMMR_FLAG_QSEED_SUBST) ? 1 : 0) + ((f & SIMMR_FLAG_MSEED_SUBST) ? 1 : 0);
+  }
+  uint64_t tb, tr, ts;
+  (void)wg_exclusive_scan_u64(bases, lds4, &tb);
+  (void)wg_exclusive_scan_u64(redrawn, lds4, &tr);
+  (void)wg_exclusive_scan_u64(subst, lds4, &ts);
+  if (threadIdx.x == 0) {
+    uint64_t nu = (uint64_t)blockIdx.x * 256 + 256 <= n_units ? 256 : (n_units - (uint64_t)blockIdx.x * 256);
+    atomicAdd(&counters[SIMMR_CNT_READS], (unsigned long long)(paired ? 2 * nu : nu));
+    atomicAdd(&counters[SIMMR_CNT_BASES], (unsigned long long)tb);
+    if (tr) atomicAdd(&counters[SIMMR_CNT_REDRAWN], (unsigned long long)tr);
+    if (ts) atomicAdd(&counters[SIMMR_CNT_SEED_SUBST], (unsigned long long)ts);
+    if (acgt_all) atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)tb);
+    if (const_q) atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)(tb * const_q));
+  }
+}
+
+}  // namespace simmr

@@ -1,0 +1,223 @@
+"""Thin Python host over the C ABI (include/simmr_hip.h).
+
+PyTorch is used only for device memory, streams and torch.distributed; every
+byte of simulated read content is produced by the HIP kernels in
+simmr_amd/csrc through libsimmr_hip.so.  No fallback path exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from ._abi import (ErrorProfilePOD, PlanInfo, Range, ReadsOut, SimmrError, U64_MAX)
+
+
+def _torch():
+    import torch  # deferred: importing the package must not need a GPU
+    return torch
+
+
+@dataclass
+class Reads:
+    """SoA replacement of Vec<SimulatedRead> (simulate.rs:27-75) in HBM.
+
+    PE shards interleave mates: read r is mate (r & 1) of pair (r >> 1)."""
+    seq: "object"
+    qual: "object"
+    seq_off: "object"
+    start: "object"
+    end: "object"
+    contig: "object"
+    genome: "object"
+    read_id: "object"
+    flags: "object"
+    n_reads: int
+    total_bases: int
+    qual_offset: int = 0
+
+    @classmethod
+    def allocate(cls, n_reads: int, total_bases: int, device, qual_offset: int = 0) -> "Reads":
+        torch = _torch()
+        n = max(int(n_reads), 1)
+        # seq/qual padded so 16-byte vector stores of the last chunk stay in bounds
+        nb = (int(total_bases) + 15) // 16 * 16 + 16
+        return cls(
+            seq=torch.empty(nb, dtype=torch.uint8, device=device),
+            qual=torch.empty(nb, dtype=torch.uint8, device=device),
+            seq_off=torch.empty(n + 1, dtype=torch.int64, device=device),
+            start=torch.empty(n, dtype=torch.int64, device=device),
+            end=torch.empty(n, dtype=torch.int64, device=device),
+            contig=torch.empty(n, dtype=torch.int32, device=device),
+            genome=torch.empty(n, dtype=torch.int32, device=device),
+            read_id=torch.empty(n, dtype=torch.int32, device=device),
+            flags=torch.empty(n, dtype=torch.uint8, device=device),
+            n_reads=int(n_reads), total_bases=int(total_bases), qual_offset=int(qual_offset))
+
+    def pod(self) -> ReadsOut:
+        o = ReadsOut()
+        o.seq = self.seq.data_ptr()
+        o.qual = self.qual.data_ptr()
+        o.seq_off = self.seq_off.data_ptr()
+        o.start = self.start.data_ptr()
+        o.end = self.end.data_ptr()
+        o.contig = self.contig.data_ptr()
+        o.genome = self.genome.data_ptr()
+        o.read_id = self.read_id.data_ptr()
+        o.flags = self.flags.data_ptr()
+        o.seq_capacity = self.seq.numel()
+        o.reads_capacity = self.start.numel()
+        o.qual_offset = self.qual_offset
+        return o
+
+    def to_host(self) -> dict:
+        """numpy copies, trimmed to the planned sizes."""
+        n, tb = self.n_reads, self.total_bases
+        return {
+            "seq": self.seq[:tb].cpu().numpy(),
+            "qual": self.qual[:tb].cpu().numpy(),
+            "seq_off": self.seq_off[: n + 1].cpu().numpy().astype(np.uint64),
+            "start": self.start[:n].cpu().numpy().astype(np.uint64),
+            "end": self.end[:n].cpu().numpy().astype(np.uint64),
+            "contig": self.contig[:n].cpu().numpy().astype(np.uint32),
+            "genome": self.genome[:n].cpu().numpy().astype(np.uint32),
+            "read_id": self.read_id[:n].cpu().numpy().astype(np.uint32),
+            "flags": self.flags[:n].cpu().numpy(),
+        }
+
+
+class Engine:
+    """One engine == one GPU == one host thread (include/simmr_hip.h)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _abi.load()
+        h = C.c_void_p()
+        rc = self.lib.simmr_engine_create(int(device), C.byref(h))
+        if rc != 0:
+            raise SimmrError(rc, (self.lib.simmr_last_error(None) or b"").decode())
+        self._h = h
+        self.device_index = int(device)
+        self._keep = []
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.simmr_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise SimmrError(rc, (self.lib.simmr_last_error(self._h) or b"").decode())
+
+    @property
+    def device(self):
+        return _torch().device("cuda", self.device_index)
+
+    def use_current_torch_stream(self):
+        s = _torch().cuda.current_stream(self.device)
+        self._check(self.lib.simmr_engine_set_stream(self._h, C.c_void_p(s.cuda_stream)))
+
+    # -- staging ------------------------------------------------------------
+    def stage_genome(self, genome_idx: int, contigs: Sequence, sizes: Optional[Sequence[int]] = None):
+        """contigs: normalised ASCII sequences (bytes or uint8 arrays), Seq.seq
+        of genome.rs:17-23; sizes: Seq.size when it differs (--contiguous)."""
+        arrs = [np.ascontiguousarray(np.frombuffer(c, dtype=np.uint8) if isinstance(c, (bytes, bytearray))
+                                     else np.asarray(c, dtype=np.uint8)) for c in contigs]
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_uint64 * n)(*[a.size for a in arrs])
+        szs = (C.c_uint64 * n)(*[int(s) for s in sizes]) if sizes is not None else None
+        self._check(self.lib.simmr_stage_genome(self._h, genome_idx, n, ptrs, lens, szs))
+
+    def stage_synthetic(self, genome_idx: int, contig_lens: Sequence[int], splitmix_seed: int):
+        n = len(contig_lens)
+        lens = (C.c_uint64 * n)(*[int(x) for x in contig_lens])
+        self._check(self.lib.simmr_stage_synthetic(self._h, genome_idx, n, lens, C.c_uint64(splitmix_seed)))
+
+    def unstage(self, genome_idx: int, contig: int, first: int, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=np.uint8)
+        self._check(self.lib.simmr_unstage_contig(self._h, genome_idx, contig, first, count,
+                                                  C.c_void_p(out.ctypes.data)))
+        return out
+
+    def genome_info(self, genome_idx: int):
+        n = C.c_uint32()
+        t = C.c_uint64()
+        self._check(self.lib.simmr_genome_info(self._h, genome_idx, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+    # -- paired-end (simulate.rs:165-302) -------------------------------------
+    def pe_plan(self, genome_idx: int, profile: ErrorProfilePOD, genome_reads: int,
+                seed: Optional[int], first: int = 0, count: int = U64_MAX) -> PlanInfo:
+        info = PlanInfo()
+        self._check(self.lib.simmr_pe_plan(self._h, genome_idx, C.byref(profile), genome_reads,
+                                           0 if seed is None else 1, 0 if seed is None else seed,
+                                           Range(first, count), C.byref(info)))
+        return info
+
+    def pe_emit(self, read_id_base: int, out: Reads):
+        pod = out.pod()
+        self._check(self.lib.simmr_pe_emit(self._h, read_id_base, C.byref(pod)))
+
+    def simulate_pe_reads_from_genome(self, genome_idx: int, profile: ErrorProfilePOD, genome_reads: int,
+                                      seed: Optional[int], first: int = 0, count: int = U64_MAX,
+                                      read_id_base: int = 0, qual_offset: int = 0) -> Reads:
+        info = self.pe_plan(genome_idx, profile, genome_reads, seed, first, count)
+        out = Reads.allocate(info.n_reads, info.total_bases, self.device, qual_offset)
+        self.pe_emit(read_id_base, out)
+        return out
+
+    # -- long reads (simulate.rs:323-523) --------------------------------------
+    def long_plan(self, genome_idx: Sequence[int], genome_reads: Sequence[int], profile: ErrorProfilePOD,
+                  seed: Optional[int], first: int = 0, count: int = U64_MAX) -> PlanInfo:
+        n = len(genome_idx)
+        gi = (C.c_uint32 * n)(*[int(x) for x in genome_idx])
+        gr = (C.c_uint64 * n)(*[int(x) for x in genome_reads])
+        info = PlanInfo()
+        self._check(self.lib.simmr_long_plan(self._h, n, gi, gr, C.byref(profile),
+                                             0 if seed is None else 1, 0 if seed is None else seed,
+                                             Range(first, count), C.byref(info)))
+        return info
+
+    def long_emit(self, read_id_base: int, out: Reads):
+        pod = out.pod()
+        self._check(self.lib.simmr_long_emit(self._h, read_id_base, C.byref(pod)))
+
+    def simulate_long_reads(self, genome_idx, genome_reads, profile, seed, first=0, count=U64_MAX,
+                            read_id_base=0, qual_offset=0) -> Reads:
+        info = self.long_plan(genome_idx, genome_reads, profile, seed, first, count)
+        out = Reads.allocate(info.n_reads, info.total_bases, self.device, qual_offset)
+        self.long_emit(read_id_base, out)
+        return out
+
+    # -- counters / timing --------------------------------------------------------
+    def counters(self) -> np.ndarray:
+        host = (C.c_uint64 * _abi.N_COUNTERS)()
+        self._check(self.lib.simmr_counters(self._h, None, host))
+        return np.array(list(host), dtype=np.uint64)
+
+    def counters_to(self, tensor):
+        """Copy the counters into a CUDA int64 tensor (for one all-reduce)."""
+        self._check(self.lib.simmr_counters(self._h, C.c_void_p(tensor.data_ptr()), None))
+
+    def counters_reset(self):
+        self._check(self.lib.simmr_counters_reset(self._h))
+
+    def last_emit_kernel_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.simmr_last_emit_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def last_plan_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.simmr_last_plan_ms(self._h, C.byref(ms)))
+        return ms.value
