@@ -1,0 +1,227 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit for bit.
+
+Everything the reference makes deterministic under --seed is compared with
+equality: bases, qualities, CSR offsets, start/end, contig, read ids, flags.
+Where the reference itself falls back to OS entropy in a seeded run (mate-2
+Option<u64> == None, simulate.rs:266,270) both sides use the documented
+substitute (include/simmr_hip.h) and the reads are flagged.
+"""
+import numpy as np
+import pytest
+
+from simmr_amd import (MinimalLongErrorProfile, MinimalShortErrorProfile, PerfectLongErrorProfile,
+                       PerfectShortErrorProfile, _abi)
+from tests import _oracle, _synth
+
+pytestmark = pytest.mark.gpu
+
+COLS = ("seq_off", "start", "end", "contig", "read_id", "flags", "qual", "seq")
+
+
+def assert_same(dev: dict, ora: dict, cols=COLS, what=""):
+    for c in cols:
+        a, b = dev[c], ora[c]
+        assert a.shape == b.shape, f"{what}{c}: shape {a.shape} vs {b.shape}"
+        if not np.array_equal(a, b):
+            bad = np.flatnonzero(a != b)
+            raise AssertionError(f"{what}{c}: {bad.size} of {a.size} differ, first at {bad[:8]}: "
+                                 f"dev={a[bad[:8]]} oracle={b[bad[:8]]}")
+
+
+@pytest.fixture(scope="module")
+def genome_1m(engine):
+    contigs = _synth.synthetic_contigs([1_000_000], 1)
+    engine.stage_synthetic(0, [1_000_000], 1)
+    return _oracle.HostGenome(contigs)
+
+
+@pytest.fixture(scope="module")
+def genome_multi(engine):
+    lens = [300_000, 90_001, 30_017, 70_000, 64, 123_457]
+    contigs = _synth.synthetic_contigs(lens, 7)
+    # contig 4 is too small for any profile: the reference filters it (main.rs:117-162)
+    keep = [0, 1, 2, 3, 5]
+    engine.stage_genome(1, [contigs[i] for i in keep])
+    return _oracle.HostGenome([contigs[i] for i in keep])
+
+
+def test_staging_roundtrip(engine, genome_1m, genome_multi):
+    got = engine.unstage(0, 0, 0, 1_000_000)
+    assert np.array_equal(got, genome_1m.contigs[0])
+    for c, ref in enumerate(genome_multi.contigs):
+        assert np.array_equal(engine.unstage(1, c, 0, ref.size), ref)
+    assert engine.genome_info(1) == (5, sum(c.size for c in genome_multi.contigs))
+
+
+def test_staging_exceptions(engine):
+    rng = np.random.default_rng(5)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 5000)].copy()
+    seq[100:180] = ord("N")
+    seq[1000] = ord("-")
+    seq[4999] = ord("N")
+    engine.stage_genome(2, [seq, seq[:777].copy()])
+    assert np.array_equal(engine.unstage(2, 0, 0, 5000), seq)
+    assert np.array_equal(engine.unstage(2, 1, 3, 700), seq[3:703])
+
+
+# BASELINE.json configs[0]: perfect-short, 1 Mbp synthetic, --num-reads 10000, seed 42
+def test_c1_perfect_short_bit_exact(engine, oracle, genome_1m):
+    prof = PerfectShortErrorProfile(150, 150).pod()
+    dev = engine.simulate_pe_reads_from_genome(0, prof, 10000, 42)
+    assert dev.n_reads == 10000 and dev.total_bases == 10000 * 150
+    ora = _oracle.simulate_pe(oracle, genome_1m, prof, 10000, 42)
+    assert_same(dev.to_host(), ora.trimmed())
+    assert (dev.to_host()["qual"] == 60).all()
+    assert np.array_equal(dev.to_host()["read_id"], np.repeat(np.arange(5000, dtype=np.uint32), 2))
+
+
+@pytest.mark.parametrize("L,I", [(20, 20), (33, 5), (150, 600), (7, 3), (250, 100), (16, 16)])
+def test_perfect_short_lengths(engine, oracle, genome_multi, L, I):
+    prof = PerfectShortErrorProfile(L, I).pod()
+    dev = engine.simulate_pe_reads_from_genome(1, prof, 3001, 7, read_id_base=17, qual_offset=33)
+    ora = _oracle.simulate_pe(oracle, genome_multi, prof, 3001, 7, read_id_base=17, qual_offset=33)
+    assert_same(dev.to_host(), ora.trimmed())
+
+
+def test_perfect_short_exceptions_revcomp(engine, oracle):
+    rng = np.random.default_rng(11)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 3000)].copy()
+    seq[rng.integers(0, 3000, 300)] = ord("N")
+    seq[rng.integers(0, 3000, 100)] = ord("-")
+    engine.stage_genome(3, [seq])
+    g = _oracle.HostGenome([seq])
+    prof = PerfectShortErrorProfile(50, 70).pod()
+    dev = engine.simulate_pe_reads_from_genome(3, prof, 2000, 3)
+    ora = _oracle.simulate_pe(oracle, g, prof, 2000, 3)
+    assert_same(dev.to_host(), ora.trimmed())
+
+
+def test_pe_sharding_matches_whole(engine, oracle, genome_multi):
+    prof = PerfectShortErrorProfile(100, 150).pod()
+    whole = _oracle.simulate_pe(oracle, genome_multi, prof, 4000, 99, read_id_base=5).trimmed()
+    for first, count in [(0, 700), (700, 1), (701, 1299), (1990, 10 ** 9)]:
+        dev = engine.simulate_pe_reads_from_genome(1, prof, 4000, 99, first=first, count=count, read_id_base=5)
+        n = min(count, 2000 - first)
+        d = dev.to_host()
+        assert dev.n_reads == 2 * n
+        lo, hi = 2 * first, 2 * (first + n)
+        base = whole["seq_off"][lo]
+        assert np.array_equal(d["seq_off"], whole["seq_off"][lo:hi + 1] - base)
+        for c in ("start", "end", "contig", "read_id", "flags"):
+            assert np.array_equal(d[c], whole[c][lo:hi]), c
+        assert np.array_equal(d["seq"], whole["seq"][base:whole["seq_off"][hi]])
+
+
+# minimal-short: every draw comes from the reference's own ChaCha12 streams
+@pytest.mark.parametrize("seed,reads", [(42, 10000), (1, 2222)])
+def test_minimal_short_bit_exact(engine, oracle, genome_1m, seed, reads):
+    prof = MinimalShortErrorProfile().pod()
+    dev = engine.simulate_pe_reads_from_genome(0, prof, reads, seed)
+    ora = _oracle.simulate_pe(oracle, genome_1m, prof, reads, seed)
+    assert dev.total_bases == ora.total_bases
+    assert_same(dev.to_host(), ora.trimmed())
+
+
+@pytest.mark.parametrize("L,I,q", [(150, 150, 20), (300, 500, 30), (40, 10, 5), (600, 300, 45)])
+def test_minimal_short_params(engine, oracle, genome_multi, L, I, q):
+    prof = MinimalShortErrorProfile(read_length=L, insert_size=I, mean_phred_score=q).pod()
+    dev = engine.simulate_pe_reads_from_genome(1, prof, 1500, 5, qual_offset=33)
+    ora = _oracle.simulate_pe(oracle, genome_multi, prof, 1500, 5, qual_offset=33, max_len=4096)
+    assert_same(dev.to_host(), ora.trimmed())
+
+
+def test_minimal_short_exceptions(engine, oracle):
+    rng = np.random.default_rng(12)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 20000)].copy()
+    seq[rng.integers(0, 20000, 2000)] = ord("N")
+    seq[5000:5400] = ord("N")
+    engine.stage_genome(3, [seq])
+    g = _oracle.HostGenome([seq])
+    prof = MinimalShortErrorProfile(mean_phred_score=12).pod()
+    dev = engine.simulate_pe_reads_from_genome(3, prof, 3000, 8)
+    ora = _oracle.simulate_pe(oracle, g, prof, 3000, 8)
+    assert_same(dev.to_host(), ora.trimmed())
+
+
+def test_minimal_short_tolerances(engine, genome_1m):
+    """substitution rate 0.013404 +-2 % at mean Phred 30, Phred mean 29.5."""
+    prof = MinimalShortErrorProfile().pod()
+    engine.counters_reset()
+    dev = engine.simulate_pe_reads_from_genome(0, prof, 400_000, 2024)
+    c = engine.counters()
+    assert c[_abi.CNT_READS] == 400_000 and c[_abi.CNT_BASES] == dev.total_bases
+    rate = c[_abi.CNT_SUBSTITUTIONS] / c[_abi.CNT_ACGT_BASES]
+    assert abs(rate / 0.013404 - 1) < 0.02, rate
+    assert abs(c[_abi.CNT_QUAL_SUM] / c[_abi.CNT_BASES] - 29.5) < 0.05
+    # substitutions really are in the output: compare with the reference bases
+    d = dev.to_host()
+    ref = genome_1m.contigs[0]
+    fwd = np.flatnonzero((d["flags"] & 1) == 0)[:20000]
+    mism = tot = 0
+    for r in fwd:
+        s, e = int(d["start"][r]), int(d["end"][r])
+        o = int(d["seq_off"][r])
+        mism += int((d["seq"][o:o + e - s] != ref[s:e]).sum())
+        tot += e - s
+    assert abs(mism / tot / 0.013404 - 1) < 0.06
+
+
+# long reads
+@pytest.mark.parametrize("cls", [MinimalLongErrorProfile, PerfectLongErrorProfile])
+def test_long_reference_mode_bit_exact(engine, oracle, genome_multi, genome_1m, cls):
+    prof = cls().pod()
+    reads = [37, 0, 25]
+    engine.stage_genome(4, genome_1m.contigs)
+    dev = engine.simulate_long_reads([1, 4, 0], reads, prof, 42, read_id_base=3)
+    ora = _oracle.simulate_long(oracle, [genome_multi, genome_1m, genome_1m], reads, prof, 42, read_id_base=3)
+    d, o = dev.to_host(), ora.trimmed()
+    # the oracle numbers genomes by position in the list; the engine by staged index
+    o["genome"] = np.array([1, 4, 0], dtype=np.uint32)[o["genome"]]
+    assert_same(d, o, cols=COLS + ("genome",))
+
+
+def test_long_per_read_mode_bit_exact(engine, oracle, genome_multi):
+    prof = MinimalLongErrorProfile(gamma_mean=8000.0, gamma_std=6000.0, length_mode=_abi.LEN_PER_READ).pod()
+    dev = engine.simulate_long_reads([1], [300], prof, 77)
+    ora = _oracle.simulate_long(oracle, [genome_multi], [300], prof, 77)
+    d, o = dev.to_host(), ora.trimmed()
+    o["genome"][:] = 1
+    assert_same(d, o, cols=COLS + ("genome",))
+    lens = np.diff(d["seq_off"].astype(np.int64))
+    assert 5000 < lens.mean() < 11000
+
+
+def test_long_sharding(engine, oracle, genome_multi, genome_1m):
+    prof = MinimalLongErrorProfile().pod()
+    reads = [40, 30]
+    whole = _oracle.simulate_long(oracle, [genome_multi, genome_1m], reads, prof, 9).trimmed()
+    for first, count in [(0, 10), (35, 10), (40, 30), (69, 5)]:
+        dev = engine.simulate_long_reads([1, 0], reads, prof, 9, first=first, count=count)
+        d = dev.to_host()
+        n = min(count, 70 - first)
+        base = whole["seq_off"][first]
+        assert np.array_equal(d["seq_off"], whole["seq_off"][first:first + n + 1] - base)
+        assert np.array_equal(d["seq"], whole["seq"][base:whole["seq_off"][first + n]])
+        assert np.array_equal(d["qual"], whole["qual"][base:whole["seq_off"][first + n]])
+        assert np.array_equal(d["read_id"], whole["read_id"][first:first + n])
+
+
+def test_error_paths(engine, genome_multi):
+    from simmr_amd import SimmrError
+    with pytest.raises(SimmrError) as ei:  # contig 2 (30 017) <= 2*20000+... required
+        engine.pe_plan(1, PerfectShortErrorProfile(20000, 20000).pod(), 10, 1)
+    assert ei.value.code == _abi.EGENOME
+    with pytest.raises(SimmrError) as ei:
+        engine.pe_plan(1, PerfectShortErrorProfile(30000, 30000).pod(), 10, 1)
+    assert ei.value.code == _abi.ERANGE  # u16 overflow of minimum_genome_size
+    with pytest.raises(SimmrError) as ei:
+        engine.pe_plan(9, PerfectShortErrorProfile().pod(), 10, 1)
+    assert ei.value.code == _abi.EINVAL
+    with pytest.raises(SimmrError) as ei:
+        engine.pe_plan(1, MinimalLongErrorProfile().pod(), 10, 1)
+    assert ei.value.code == _abi.EINVAL
+    # empty and odd inputs (simulate.rs:179: num_reads / 2 pairs)
+    assert engine.pe_plan(1, PerfectShortErrorProfile().pod(), 1, 1).n_reads == 0
+    assert engine.pe_plan(1, PerfectShortErrorProfile().pod(), 7, 1).n_reads == 6
+    out = engine.simulate_pe_reads_from_genome(1, PerfectShortErrorProfile().pod(), 0, 1)
+    assert out.n_reads == 0 and out.total_bases == 0

@@ -1,0 +1,199 @@
+"""Pins the CPU oracle against every known-answer vector available offline
+(SURVEY.md §8c): public ChaCha vectors, rand 0.8's StdRng unit test, the two
+reference-authored RNG values in simmr/src/tests/simulate_tests.rs:27,:75, and
+the reference's live unit tests (util_tests.rs, abundance_profile_tests.rs,
+error_profile_tests.rs, shared/src/encoding.rs:288-314)."""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from simmr_amd import MinimalLongErrorProfile, MinimalShortErrorProfile, PerfectShortErrorProfile
+from tests import _oracle, _synth
+
+GOLDEN = Path(__file__).parent / "golden"
+
+
+def _hex_words(words):
+    return " ".join(int(w).to_bytes(4, "little").hex() for w in words)
+
+
+def test_chacha_public_vectors(oracle):
+    key = (C.c_uint32 * 8)()
+    out = (C.c_uint32 * 16)()
+    oracle.orc_chacha_block(key, 0, 20, out)
+    assert _hex_words(out[:4]) == "76b8e0ad a0f13d90 405d6ae5 5386bd28"
+    oracle.orc_chacha_block(key, 0, 12, out)
+    assert _hex_words(out[:8]) == ("9bf49a6a 0755f953 811fce12 5f2683d5 "
+                                   "0429c3bb 49e07414 7e0089a5 2eae155f")
+
+
+def test_rand_stdrng_unit_test_value(oracle):
+    r = _oracle.Rng()
+    seed = (C.c_uint8 * 32)(*([1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16))
+    oracle.orc_rng_from_seed(C.byref(r), seed)
+    assert oracle.orc_next_u64(C.byref(r)) == 10719222850664546238
+
+
+def test_reference_authored_rng_values(oracle):
+    # simulate_tests.rs:27: StdRng::seed_from_u64(42).gen::<u64>() (the comment
+    # has one duplicated digit: 97132697663989775522)
+    r = _oracle.Rng()
+    oracle.orc_rng_seed_from_u64(C.byref(r), 42)
+    assert oracle.orc_next_u64(C.byref(r)) == 9713269763989775522
+    # simulate_tests.rs:75: gen_range(0..1usize) then gen::<u64>() -> "6335..6202"
+    oracle.orc_rng_seed_from_u64(C.byref(r), 42)
+    v = C.c_uint64()
+    assert oracle.orc_gen_range_u64(C.byref(r), 0, 1, C.byref(v)) == 0 and v.value == 0
+    got = oracle.orc_next_u64(C.byref(r))
+    assert got == 633513173585076202
+    assert str(got).startswith("6335") and str(got).endswith("6202")
+
+
+def test_block_boundary_consumption(oracle):
+    """next_u64 across the 64-word refill uses consecutive words (rand_core BlockRng)."""
+    a, b = _oracle.Rng(), _oracle.Rng()
+    oracle.orc_rng_seed_from_u64(C.byref(a), 7)
+    oracle.orc_rng_seed_from_u64(C.byref(b), 7)
+    words = [oracle.orc_next_u32(C.byref(a)) for _ in range(200)]
+    got = [oracle.orc_next_u32(C.byref(b))]  # misalign by one word
+    for i in range(1, 199, 2):
+        v = oracle.orc_next_u64(C.byref(b))
+        assert v == words[i] | (words[i + 1] << 32)
+
+
+def test_ziggurat_tables_match_rand_distr_literals(oracle):
+    # first entries of rand_distr 0.4.3 ziggurat_tables.rs ZIG_NORM_X / ZIG_NORM_F
+    X, F = oracle.orc_zig_norm_x(), oracle.orc_zig_norm_f()
+    # (the crate prints its tables with 18 decimals)
+    lit_x = ["3.910757959537090045", "3.654152885361008796", "3.449278298560964462", "3.320244733839166074",
+             "3.224575052047029100", "3.147889289517149969", "3.083526132001233044", "3.027837791768635434"]
+    lit_f = ["0.000477467764586655", "0.001260285930498598", "0.002609072746106363", "0.004037972593371872"]
+    assert ["%.18f" % X[i] for i in range(8)] == lit_x
+    assert ["%.18f" % F[i] for i in range(4)] == lit_f
+    assert X[256] == 0.0 and F[256] == 1.0
+    assert all(X[i] > X[i + 1] for i in range(256))
+
+
+def test_standard_normal_moments(oracle):
+    r = _oracle.Rng()
+    oracle.orc_rng_seed_from_u64(C.byref(r), 123)
+    z = np.array([oracle.orc_standard_normal(C.byref(r)) for _ in range(200000)])
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    assert abs((np.abs(z) > 3.654152885361009).mean() - 2.58e-4) < 1.5e-4  # tail branch is exercised
+
+
+def test_gamma_moments(oracle):
+    r = _oracle.Rng()
+    oracle.orc_rng_seed_from_u64(C.byref(r), 5)
+    p = MinimalLongErrorProfile().pod()
+    out = C.c_float()
+    xs = []
+    for _ in range(100000):
+        assert oracle.orc_gamma_f32(C.byref(r), p.gamma_shape, p.gamma_scale, C.byref(out)) == 0
+        xs.append(out.value)
+    xs = np.array(xs)
+    assert abs(xs.mean() / 20000 - 1) < 0.02 and abs(xs.std() / 15000 - 1) < 0.03
+    # floor + u16 saturation: mean ~19 833, P(=65535) ~1.42 %
+    sat = np.minimum(np.floor(xs), 65535)
+    assert abs(sat.mean() - 19833) < 250 and abs((sat == 65535).mean() - 0.0142) < 0.003
+
+
+# ---- reference unit tests restated ------------------------------------------
+def test_util_tests_rs(oracle):
+    # util_tests.rs:7-50 complement, :69-109 conversions, :53-66 encoding
+    assert bytes(oracle.orc_complement(c) for c in b"aacctg") == b"ttggac"
+    assert bytes(oracle.orc_complement(c) for c in b"TAGCNNNN") == b"ATCGNNNN"
+    assert bytes(oracle.orc_complement(c) for c in b"CaTTagG") == b"GtAAtcC"
+    assert [oracle.orc_encode_quality_score(q) for q in (0, 1, 10, 41)] == list(b'!"+J')
+    f32 = np.float32
+    assert f32(oracle.orc_convert_phred_to_probability(10)) == f32(0.1)
+    assert f32(oracle.orc_convert_phred_to_probability(30)) == f32(0.001)
+    assert f32(oracle.orc_convert_phred_to_probability(60)) == f32(0.000001)
+    assert f32(oracle.orc_convert_phred_to_accuracy(10)) == f32(0.9)
+    assert f32(oracle.orc_convert_phred_to_accuracy(30)) == f32(0.999)
+    assert f32(oracle.orc_convert_phred_to_accuracy(60)) == f32(0.999999)
+    assert [oracle.orc_convert_probability_to_phred(p) for p in (0.1, 0.001, 0.000001)] == [10, 30, 60]
+    assert [oracle.orc_convert_accuracy_to_phred(a) for a in (0.9, 0.999, 0.999999)] == [10, 30, 60]
+    out = np.zeros(6, dtype=np.uint8)
+    src = np.frombuffer(b"AACGTN", dtype=np.uint8)
+    oracle.orc_reverse_complement(C.c_void_p(src.ctypes.data), 6, C.c_void_p(out.ctypes.data))
+    assert out.tobytes() == b"NACGTT"
+
+
+def test_two_bit_kmer_codes(oracle):
+    # shared/src/encoding.rs:288-314
+    for kmer, code in ((b"ACGT", 0xE4), (b"AAAAA", 0), (b"TTATC", 0x1CF), (b"GCGCATCT", 0xDC66)):
+        v = C.c_uint32()
+        assert oracle.orc_two_bit_encode_kmer(kmer, len(kmer), C.byref(v)) == 0 and v.value == code
+        buf = C.create_string_buffer(len(kmer))
+        oracle.orc_two_bit_decode_kmer(code, len(kmer), buf)
+        assert buf.raw == kmer
+
+
+def test_error_profile_tests_rs(oracle):
+    # error_profile_tests.rs:7-21
+    p = PerfectShortErrorProfile(150, 150).pod()
+    v = C.c_uint16()
+    assert oracle.orc_profile_get_read_length(C.byref(p), 0, C.byref(v)) == 0 and v.value == 150
+    assert oracle.orc_profile_get_insert_size(C.byref(p), 0, C.byref(v)) == 0 and v.value == 150
+    q = np.zeros(150, dtype=np.uint8)
+    oracle.orc_profile_simulate_phred_scores(C.byref(p), 150, 0, C.c_void_p(q.ctypes.data))
+    assert (q == 60).all()
+    assert oracle.orc_profile_minimum_genome_size(C.byref(p), C.byref(v)) == 0 and v.value == 450
+
+
+def test_abundance_profile_tests_rs(oracle):
+    # abundance_profile_tests.rs:7-30
+    reads = np.zeros(5, dtype=np.uint64)
+    ab = np.zeros(5)
+    oracle.orc_uniform_determine_abundances(100, 5, C.c_void_p(reads.ctypes.data), C.c_void_p(ab.ctypes.data))
+    assert list(reads) == [20] * 5 and list(ab) == [20.0] * 5
+
+
+def test_slicing_strings_of_ignored_simulate_tests(oracle):
+    """simulate_tests.rs:37,44,83,90 — the read strings of the two #[ignore]d tests,
+    checked as slicing / reverse-complement semantics on the committed fixture."""
+    seq = np.frombuffer((GOLDEN / "ecoli_partial_7920.txt").read_bytes().strip(), dtype=np.uint8)
+    assert seq.size == 7920
+    assert seq[38:58].tobytes() == b"TGTGGATTAAAAAAAGAGTG"
+    assert seq[8:28].tobytes() == b"ATTCTGACTGCAACGGGCAA"
+    out = np.zeros(20, dtype=np.uint8)
+    for lo, want in ((78, b"TTACTCACGGCAGGTAACCA"), (48, b"TGCTATCAGACACTCTTTTT")):
+        s = np.ascontiguousarray(seq[lo:lo + 20])
+        oracle.orc_reverse_complement(C.c_void_p(s.ctypes.data), 20, C.c_void_p(out.ctypes.data))
+        assert out.tobytes() == want
+
+
+def test_drift_anchors(oracle):
+    """Self-generated anchors recorded in SURVEY.md §8c (not reference outputs):
+    pe_seed 9713269763989775522 on a 7 920-nt contig with required 60 -> fwd_start 5092;
+    pe_seed 633513173585076202 -> 1829."""
+    p = PerfectShortErrorProfile(20, 20).pod()
+    pl = _oracle.PePlan()
+    assert oracle.orc_pe_plan_pair(C.byref(p), 7920, 9713269763989775522, C.byref(pl)) == 0
+    assert pl.fwd_start == 5092
+    assert oracle.orc_pe_plan_pair(C.byref(p), 7920, 633513173585076202, C.byref(pl)) == 0
+    assert pl.fwd_start == 1829
+
+
+def test_oracle_golden_vectors(oracle):
+    """Frozen oracle outputs (tests/golden/make_golden.py): any drift in the
+    restated RNG chain or simulate path shows up here without a GPU."""
+    gold = json.loads((GOLDEN / "oracle_golden.json").read_text())
+    import hashlib
+    for case in gold["cases"]:
+        contigs = _synth.synthetic_contigs(case["contig_lens"], case["genome_seed"])
+        g = _oracle.HostGenome(contigs)
+        if case["kind"] == "pe":
+            cls = {"perfect-short": PerfectShortErrorProfile, "minimal-short": MinimalShortErrorProfile}[case["profile"]]
+            out = _oracle.simulate_pe(oracle, g, cls().pod(), case["reads"], case["seed"])
+        else:
+            out = _oracle.simulate_long(oracle, [g], [case["reads"]], MinimalLongErrorProfile().pod(), case["seed"])
+        d = out.trimmed()
+        for col, want in case["sha256"].items():
+            assert hashlib.sha256(np.ascontiguousarray(d[col]).tobytes()).hexdigest() == want, (case["name"], col)
+        assert [int(x) for x in d["start"][:8]] == case["start_head"]
+        assert d["seq"][:60].tobytes().decode() == case["seq_head"]
