@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline workload on MI355X.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the whole hot path (outer seed stream, per-pair planning,
+offset scan, emit kernel, metadata, counters) over one batch: BASELINE.json
+configs[1] — minimal-short 150 bp PE on a 100 Mbp synthetic genome, 100 M reads
+per GPU, inputs (the 2-bit packed reference) resident in HBM.  With N GPUs the
+job is N x 100 M reads of ONE run (same seed): rank r simulates pair-index range
+[r*50M, (r+1)*50M) — weak scaling, no data-path collective; one all-reduce of
+the 8 run counters at the end of every step (RCCL over xGMI).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
+(k_emit_stream): algorithmic bytes per launch / its HIP-event duration measured
+on the engine's stream.  `cpu_baseline` is the CPU oracle (a port of the
+reference algorithm; the Rust reference cannot be built here) timed on this
+host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU per step")
+    ap.add_argument("--genome-bases", type=int, default=100_000_000)
+    ap.add_argument("--profile", default="minimal-short", choices=["minimal-short", "perfect-short"])
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from simmr_amd import MinimalShortErrorProfile, PerfectShortErrorProfile, _abi
+    from simmr_amd.engine import Engine, Reads
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    eng = Engine(local_rank)
+    eng.stage_synthetic(0, [args.genome_bases], 2)  # SplitMix64(seed=2)
+    prof = (MinimalShortErrorProfile() if args.profile == "minimal-short" else PerfectShortErrorProfile()).pod()
+
+    pairs_per_gpu = args.reads // 2
+    total_reads = 2 * pairs_per_gpu * world  # the whole job
+    first = rank * pairs_per_gpu
+    counters_dev = torch.zeros(_abi.N_COUNTERS, dtype=torch.int64, device=eng.device)
+
+    # sizes are a deterministic function of (seed, shard): plan once to allocate
+    info = eng.pe_plan(0, prof, total_reads, args.seed, first, pairs_per_gpu)
+    out = Reads.allocate(info.n_reads, info.total_bases, eng.device, qual_offset=33)
+
+    emit_ms, plan_ms = [], []
+
+    def step(record):
+        eng.counters_reset()
+        eng.pe_plan(0, prof, total_reads, args.seed, first, pairs_per_gpu)
+        eng.pe_emit(0, out)  # read ids: pair 0 of the (only) genome is id 0
+        eng.counters_to(counters_dev)
+        if world > 1:
+            dist.all_reduce(counters_dev)  # the path's only collective
+        if record:
+            emit_ms.append(eng.last_emit_kernel_ms())
+            plan_ms.append(eng.last_plan_ms())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    counters = counters_dev.cpu().numpy().astype(np.uint64)
+    n_reads_job = int(counters[_abi.CNT_READS])
+    n_bases_job = int(counters[_abi.CNT_BASES])
+    assert n_reads_job == 2 * pairs_per_gpu * world, (n_reads_job, pairs_per_gpu, world)
+
+    # algorithmic bytes of ONE emit launch on this rank:
+    # per read ceil(L/4) packed-reference bytes + L bases + L qualities + 16 metadata
+    lens = out.seq_off[1:info.n_reads + 1] - out.seq_off[:info.n_reads]
+    alg_bytes = int(((lens + 3) // 4).sum().item()) + 2 * int(info.total_bases) + 16 * int(info.n_reads)
+    emit_avg_ms = sum(emit_ms) / max(len(emit_ms), 1)
+    achieved = alg_bytes / (emit_avg_ms * 1e-3) / 1e9 if emit_avg_ms > 0 else 0.0
+
+    result = None
+    if rank == 0:
+        value = n_reads_job * args.steps / elapsed
+        subst_rate = float(counters[_abi.CNT_SUBSTITUTIONS]) / max(float(counters[_abi.CNT_ACGT_BASES]), 1.0)
+        result = {
+            "metric": "simulated_reads_per_sec",
+            "value": value,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.profile} 150 bp PE, 1 genome ({args.genome_bases} bp synthetic SplitMix64 seed 2), "
+                            f"{2 * pairs_per_gpu} reads per GPU per step, seed {args.seed}",
+                "rng": "reference StdRng streams (ChaCha12), bit-exact mode",
+                "reads_per_gpu": 2 * pairs_per_gpu,
+                "sharding": "pair-index range per GPU",
+            },
+            "gbases_per_sec": n_bases_job * args.steps / elapsed / 1e9,
+            "substitution_rate": subst_rate,
+            "mean_phred": float(counters[_abi.CNT_QUAL_SUM]) / max(float(counters[_abi.CNT_BASES]), 1.0),
+            "plan_ms_per_step": sum(plan_ms) / max(len(plan_ms), 1),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_emit_stream" if args.profile == "minimal-short" else "k_emit_perfect_pe",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "alg_bytes_per_launch": alg_bytes,
+                "kernel_ms": emit_avg_ms,
+                "note": "integer-ALU bound (ChaCha12), see DESIGN.md",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, prof)
+        print(json.dumps(result), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, prof):
+    """The CPU oracle (port of the reference algorithm) on a bounded sample of
+    the same workload, on this host's cores."""
+    import numpy as np
+    from tests import _oracle, _synth
+    lib = _oracle.load()
+    contigs = _synth.synthetic_contigs([args.genome_bases], 2)
+    genome = _oracle.HostGenome(contigs)
+    cores = len(os.sched_getaffinity(0))
+    n1 = min(args.cpu_sample_reads // 8, 250_000)
+    t = time.perf_counter()
+    _oracle.simulate_pe(lib, genome, prof, n1, args.seed, max_len=320, threads=1)
+    t1 = time.perf_counter() - t
+    n = args.cpu_sample_reads
+    t = time.perf_counter()
+    o = _oracle.simulate_pe(lib, genome, prof, n, args.seed, max_len=320, threads=cores)
+    tn = time.perf_counter() - t
+    return {
+        "value": n / tn,
+        "unit": "reads/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {n} reads of the same run (same genome, profile, seed), OpenMP over pairs on {cores} threads, {tn:.1f} s",
+        "single_thread_value": n1 / t1,
+        "single_thread_sample": f"first {n1} reads, 1 thread, {t1:.1f} s",
+        "gbases_per_sec": o.total_bases / tn / 1e9,
+    }
+
+
+if __name__ == "__main__":
+    main()

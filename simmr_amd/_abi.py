@@ -133,6 +133,15 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 / HSA
+    # runtime.  If libsimmr_hip.so is dlopen'ed first it binds (RTLD_NOW) to
+    # /opt/rocm's copy and the second runtime to initialise finds no device.
+    # Loading torch first puts its runtime in the global scope, and ours binds
+    # to that one.  Without torch in the process the /opt/rocm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     p = Path(path) if path else LIB_PATH
     if not p.exists():
         raise ImportError(
