@@ -148,7 +148,7 @@ def main():
             "plan_ms_per_step": sum(plan_ms) / max(len(plan_ms), 1),
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_emit_stream" if args.profile == "minimal-short" else "k_emit_perfect_pe",
+                "kernel": "k_emit_lanes" if args.profile == "minimal-short" else "k_emit_perfect_pe",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -75,7 +76,9 @@ struct simmr_engine {
   uint64_t plan_first = 0, plan_units = 0, plan_total_bases = 0;
   bool plan_paired = false;
   DevBuf u_contig, u_genome, u_seed, u_len, u_a, u_b, u_bytes, u_qs2, u_ms2, u_flags, u_off;
-  DevBuf scan_tmp;
+  DevBuf scan_tmp, u_order, len_hist;
+  bool plan_sorted = false;
+  int emit_variant = 0;  // 0 = lane-per-read kernel for short reads, 1 = wave-per-unit kernel
   // outer-stream scratch
   DevBuf o_last_idx, o_wg_sums, o_wg_prefix, o_result;
   // long-read runs
@@ -470,6 +473,7 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
   simmr_engine* e = new simmr_engine();
   e->device = device_ordinal;
   e->n_cu = prop.multiProcessorCount;
+  if (const char* v = getenv("SIMMR_EMIT_VARIANT")) e->emit_variant = atoi(v);
   bool ok = e->d_tables.ensure(sizeof(Tables)) && e->d_counters.ensure(8 * SIMMR_N_COUNTERS) &&
             e->d_err.ensure(64) && e->d_scalars.ensure(256);
   ok = ok && hipEventCreate(&e->ev_a) == hipSuccess && hipEventCreate(&e->ev_b) == hipSuccess &&
@@ -499,7 +503,7 @@ void simmr_engine_destroy(simmr_engine* e) {
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_bytes, &e->u_qs2,
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
-                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable};
+                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist};
   for (DevBuf* b : bufs) b->release();
   if (e->ev_a) (void)hipEventDestroy(e->ev_a);
   if (e->ev_b) (void)hipEventDestroy(e->ev_b);
@@ -641,6 +645,22 @@ int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profil
                        e->u_seed.as<uint64_t>(), plan_arrays(e, seeds2), e->d_tables.as<Tables>(),
                        e->d_err.as<uint32_t>());
   }
+  e->plan_sorted = false;
+  if (count > 0 && seeds2 && e->emit_variant == 0) {
+    // processing order by read length, so the lanes of a wave finish together
+    if (count > 0xffffffffULL) return e->fail(SIMMR_ERANGE, "more than 2^32 pairs in one shard");
+    if (!e->u_order.ensure(count * 4) || !e->len_hist.ensure(LBINS * 4))
+      return e->fail(SIMMR_ENOMEM, "order allocation failed");
+    HIP_TRY(e, hipMemsetAsync(e->len_hist.p, 0, LBINS * 4, e->stream));
+    const uint32_t g1 = (uint32_t)std::min<uint64_t>(grid_for(count, 256), (uint64_t)e->n_cu * 8);
+    hipLaunchKernelGGL(k_len_hist, dim3(g1), dim3(256), 0, e->stream, e->u_len.as<uint32_t>(), count,
+                       e->len_hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, e->stream, e->len_hist.as<uint32_t>());
+    const uint32_t g2 = (uint32_t)std::min<uint64_t>(grid_for(count, 4096), (uint64_t)e->n_cu * 8);
+    hipLaunchKernelGGL(k_len_scatter, dim3(g2), dim3(256), 0, e->stream, e->u_len.as<uint32_t>(), count,
+                       e->len_hist.as<uint32_t>(), e->u_order.as<uint32_t>());
+    e->plan_sorted = true;
+  }
   if ((rc = scan_offsets(e, count, &total))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;
@@ -688,6 +708,15 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       hipLaunchKernelGGL(k_emit_perfect_pe, dim3(grid), dim3(256), 0, e->stream, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, e->prof.read_length, pl, e->u_contig.as<uint32_t>(), out->seq,
                          out->qual, 60u + out->qual_offset);
+    } else if (paired && e->prof.kind == SIMMR_K_MINIMAL_SHORT && e->emit_variant == 0) {
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_emit_lanes, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+      const uint64_t wgs = (2 * n_units + 255) / 256;
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(wgs, (uint64_t)e->n_cu * (uint64_t)per_cu);
+      hipLaunchKernelGGL(k_emit_lanes, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
+                         e->plan_genome, n_units, e->plan_sorted ? e->u_order.as<uint32_t>() : (const uint32_t*)nullptr,
+                         pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(), out->seq,
+                         out->qual, out->qual_offset, e->d_tables.as<Tables>(), counters);
     } else {
       hipLaunchKernelGGL(k_emit_stream, dim3(stream_grid(e, n_units)), dim3(64), 0, e->stream, e->prof,
                          paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl,
@@ -700,7 +729,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
   if (n_units > 0) {
     const bool perfect = e->prof.kind == SIMMR_K_PERFECT_SHORT;
     const bool acgt_all = perfect && !e->genomes[e->plan_genome].has_exc;
-    hipLaunchKernelGGL(k_count_plan, dim3(grid_for(n_units, 256)), dim3(256), 0, e->stream, paired ? 1u : 0u,
+    hipLaunchKernelGGL(k_count_plan, dim3(std::min<uint32_t>(grid_for(n_units, 256), (uint32_t)e->n_cu * 4)), dim3(256), 0, e->stream, paired ? 1u : 0u,
                        n_units, pl, perfect ? 60u : 0u, acgt_all ? 1u : 0u, counters);
   }
   hipError_t s = hipGetLastError();

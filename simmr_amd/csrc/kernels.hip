@@ -1007,26 +1007,360 @@ k_emit_stream(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   }
 }
 
+// ===========================================================================
+// 8. Emit, lane-per-read form (the fast path for short reads)
+//
+// Every LANE owns one read (mate) and walks its own StdRng streams exactly as
+// the reference does, one u64 (Phred) or one u32 (mutation) per step:
+//   phase Q: ChaCha12 block b of the Phred stream in registers, 8 ziggurat
+//            steps, qualities stored 8 bytes at a time;
+//   phase M: ChaCha12 block b of the mutation stream, 16 substitution steps,
+//            bases stored 8 bytes at a time (mate 2 complement-reversed).
+// All 64 lanes compute ChaCha blocks of 64 different streams at once (100 %
+// lane use, no LDS traffic, no cross-lane dependency); the block loop is
+// wave-uniform because every step consumes exactly one slot.  Reads are
+// processed in order of length (k_len_* below) so the lanes of a wave finish
+// together; the output position of a read does not depend on that order.
+// The ziggurat wedge test exp(-x^2/2) is decided by rigorous Taylor bounds
+// around the layer's table value and only falls back to exp() inside a
+// 1e-13-wide band, so decisions equal the reference's.
+// ===========================================================================
+
+#define LBINS 1024u
+
+extern "C" __global__ void __launch_bounds__(256)
+k_len_hist(const uint32_t* __restrict__ len, uint64_t n, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[LBINS];
+  for (uint32_t i = threadIdx.x; i < LBINS; i += 256) h[i] = 0;
+  __syncthreads();
+  for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) {
+    uint32_t L = len[k];
+    atomicAdd(&h[L < LBINS ? L : LBINS - 1], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < LBINS; i += 256)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// single workgroup: hist -> exclusive prefix (cursor)
+extern "C" __global__ void __launch_bounds__(256)
+k_len_scan(uint32_t* __restrict__ hist_cursor) {
+  __shared__ uint64_t lds4[4];
+  uint32_t v[4], s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { v[i] = hist_cursor[threadIdx.x * 4 + i]; s += v[i]; }
+  uint64_t tot;
+  uint32_t ex = (uint32_t)wg_exclusive_scan_u64(s, lds4, &tot);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { hist_cursor[threadIdx.x * 4 + i] = ex; ex += v[i]; }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_len_scatter(const uint32_t* __restrict__ len, uint64_t n, uint32_t* __restrict__ cursor,
+              uint32_t* __restrict__ order) {
+  __shared__ uint32_t h[LBINS];
+  __shared__ uint32_t base[LBINS];
+  const uint64_t per_wg = 256ull * 16ull;
+  for (uint64_t start = (uint64_t)blockIdx.x * per_wg; start < n; start += (uint64_t)gridDim.x * per_wg) {
+    for (uint32_t i = threadIdx.x; i < LBINS; i += 256) h[i] = 0;
+    __syncthreads();
+    uint32_t bin[16], rank[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      uint64_t k = start + (uint64_t)i * 256 + threadIdx.x;
+      bin[i] = 0xffffffffu;
+      if (k < n) {
+        uint32_t L = len[k];
+        bin[i] = L < LBINS ? L : LBINS - 1;
+        rank[i] = atomicAdd(&h[bin[i]], 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < LBINS; i += 256)
+      if (h[i]) base[i] = atomicAdd(&cursor[i], h[i]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      uint64_t k = start + (uint64_t)i * 256 + threadIdx.x;
+      if (bin[i] != 0xffffffffu) order[base[bin[i]] + rank[i]] = (uint32_t)k;
+    }
+    __syncthreads();
+  }
+}
+
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+
+SIMMR_DEV void store_bytes(uint8_t* __restrict__ p, uint64_t v, uint32_t n) {
+  if (n == 8) {
+    *reinterpret_cast<u64_unaligned*>(p) = v;
+  } else {
+    for (uint32_t i = 0; i < n; i++) p[i] = (uint8_t)(v >> (8 * i));
+  }
+}
+
+struct LaneQ {
+  uint32_t i;      // next base index
+  uint32_t st;     // 0 FRESH, 1 WEDGE (need the f64 draw), 2 TAIL_X, 3 TAIL_Y
+  uint32_t pidx;   // layer of the pending wedge
+  double px;       // pending x (WEDGE) / u (TAIL) 
+  double tx;       // TAIL: x_ draw waiting for its y_
+  uint64_t acc;    // up to 8 quality bytes not yet stored
+  uint64_t qsum;
+};
+
+// rare: exact wedge decision and the tail loop (rand_distr zero_case)
+__device__ __attribute__((noinline)) bool wedge_exact(double t, double x) {
+  return t < exp(__dmul_rn(__dmul_rn(-x, x), 0.5));
+}
+__device__ __attribute__((noinline)) bool tail_try(double x_, double y_, double u, double* out) {
+  const double xx = log(x_) / SIMMR_ZIG_R;
+  const double yy = log(y_);
+  if (__dmul_rn(-2.0, yy) < __dmul_rn(xx, xx)) return false;  // loop again
+  *out = u < 0.0 ? xx - SIMMR_ZIG_R : SIMMR_ZIG_R - xx;
+  return true;
+}
+
+SIMMR_DEV void q_emit(LaneQ& s, double x, const ProfileDev& prof, const Tables* __restrict__ T,
+                      uint8_t* __restrict__ qdst, uint32_t qoff) {
+  // minimal_short.rs:90-101: floor(Normal<f32>(mean, 10).sample()) as u8
+  (void)T;
+  const uint32_t q = sat_u8_f32(floorf(__fadd_rn(prof.mean_phred_f, __fmul_rn(10.0f, (float)x))));
+  s.qsum += q;
+  s.acc |= (uint64_t)((q + qoff) & 0xffu) << (8 * (s.i & 7u));
+  s.i++;
+  if ((s.i & 7u) == 0) {
+    *reinterpret_cast<u64_unaligned*>(qdst + s.i - 8) = s.acc;
+    s.acc = 0;
+  }
+}
+
+SIMMR_DEV void q_step(LaneQ& s, uint64_t bits, const double2* __restrict__ zx2,
+                      const double2* __restrict__ zf2, const ProfileDev& prof,
+                      const Tables* __restrict__ T, uint8_t* __restrict__ qdst, uint32_t qoff) {
+  if (s.st == 0) {
+    const uint32_t zi = (uint32_t)bits & 0xffu;
+    const double u = __longlong_as_double((long long)((bits >> 12) | 0x4000000000000000ULL)) - 3.0;
+    const double2 X = zx2[zi];
+    const double x = __dmul_rn(u, X.x);
+    if (fabs(x) < X.y) {
+      q_emit(s, x, prof, T, qdst, qoff);
+    } else if (zi == 0) {
+      s.st = 2; s.px = u;
+    } else {
+      s.st = 1; s.px = x; s.pidx = zi;
+    }
+  } else if (s.st == 1) {
+    // f_tab[i+1] + (f_tab[i] - f_tab[i+1]) * gen::<f64>() < pdf(x)
+    const double r = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+    const double2 F = zf2[s.pidx];  // {F[i], F[i+1]}
+    const double t = __dadd_rn(F.y, __dmul_rn(__dsub_rn(F.x, F.y), r));
+    // pdf(x) = F[i] * e^d, d = (X[i]^2 - x^2)/2 in [0, 0.73]; Taylor bounds
+    const double Xi = zx2[s.pidx].x, ax = fabs(s.px);
+    const double d = (Xi - ax) * (Xi + ax) * 0.5;
+    const double d2 = d * d;
+    const double lo = F.x * (1.0 + d + 0.5 * d2 + d2 * d * (1.0 / 6.0));
+    const double hi = lo + F.x * (0.06 * d2 * d2);
+    bool accept;
+    if (t < lo * (1.0 - 1e-13)) accept = true;
+    else if (t > hi * (1.0 + 1e-13)) accept = false;
+    else accept = wedge_exact(t, s.px);
+    s.st = 0;
+    if (accept) q_emit(s, s.px, prof, T, qdst, qoff);
+  } else if (s.st == 2) {
+    s.tx = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ULL)) - (1.0 - 2.220446049250313e-16 / 2.0);
+    s.st = 3;
+  } else {
+    const double y_ = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ULL)) - (1.0 - 2.220446049250313e-16 / 2.0);
+    double x;
+    if (tail_try(s.tx, y_, s.px, &x)) { s.st = 0; q_emit(s, x, prof, T, qdst, qoff); }
+    else s.st = 2;
+  }
+}
+
+struct LaneM {
+  uint32_t i;       // next base index (forward-strand slice order)
+  uint32_t st;      // 0 FRESH, 1 CHOOSE (base i mutates, waiting for an accepted u32)
+  uint32_t creg;    // 16 reference codes of bases (i & ~15) ..
+  uint32_t ereg;    // their exception bits
+  uint64_t qreg;    // 8 qualities of bases (i & ~7) ..
+  uint64_t acc;     // output bytes not yet stored
+  uint32_t n_subst, n_acgt;
+};
+
+SIMMR_DEV void m_emit(LaneM& s, uint32_t code, uint32_t L, uint32_t rev, uint8_t* __restrict__ sdst) {
+  // code 0-3 = ACGT, 4 = 'N', 5 = '-'
+  const uint32_t lut_f = 0x54474341u, lut_r = 0x41434754u;  // "ACGT", "TGCA"
+  const uint32_t ch = code < 4u ? ((rev ? lut_r : lut_f) >> (8 * code)) & 0xffu : (code == 4u ? 'N' : '-');
+  // forward mate: byte i.  Mate 2 (simulate.rs:283): byte L-1-i; 8-byte groups
+  // are counted from the END of the read so that every in-loop store is full.
+  const uint32_t p = s.i & 7u;
+  s.acc |= (uint64_t)ch << (8 * (rev ? 7u - p : p));
+  s.i++;
+  if (p == 7u) {
+    const uint32_t at = rev ? (L - s.i) : (s.i - 8);
+    *reinterpret_cast<u64_unaligned*>(sdst + at) = s.acc;
+    s.acc = 0;
+  }
+}
+
+// after the loop: the last (s.i & 7) bytes
+SIMMR_DEV void m_flush(const LaneM& s, uint32_t rev, uint8_t* __restrict__ sdst) {
+  const uint32_t n = s.i & 7u;
+  if (n == 0) return;
+  if (!rev) {
+    for (uint32_t b = 0; b < n; b++) sdst[(s.i & ~7u) + b] = (uint8_t)(s.acc >> (8 * b));
+  } else {
+    // bytes sit at positions 7, 6, ... 8-n of acc and belong to addresses n-1 ... 0
+    for (uint32_t b = 0; b < n; b++) sdst[b] = (uint8_t)(s.acc >> (8 * (8 - n + b)));
+  }
+}
+
+__device__ __attribute__((noinline)) uint64_t load_q_tail(const uint8_t* __restrict__ qsrc, uint32_t i, uint32_t L) {
+  uint64_t v = 0;
+  for (uint32_t b = 0; i + b < L; b++) v |= (uint64_t)qsrc[i + b] << (8 * b);
+  return v;
+}
+
+SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const GenomeDev& G, uint64_t src,
+                      const uint32_t* __restrict__ thr, const uint8_t* __restrict__ qsrc, uint32_t qoff,
+                      uint8_t* __restrict__ sdst) {
+  if (s.st == 0) {
+    const uint32_t i = s.i;
+    if ((i & 7u) == 0) {
+      if (i + 8 <= L) s.qreg = *reinterpret_cast<const u64_unaligned*>(qsrc + i);
+      else if (L >= 8) s.qreg = *reinterpret_cast<const u64_unaligned*>(qsrc + L - 8) >> (8 * (i + 8 - L));
+      else s.qreg = load_q_tail(qsrc, i, L);
+    }
+    if ((i & 15u) == 0) {
+      s.creg = fetch_codes16(G.packed, (int64_t)(src + i));
+      s.ereg = G.has_exc ? fetch_mask16(G.mask, (int64_t)(src + i)) : 0u;
+    }
+    const uint32_t q = ((uint32_t)(s.qreg >> (8 * (i & 7u))) - qoff) & 0xffu;
+    uint32_t code = (s.creg >> (2 * (i & 15u))) & 3u;
+    const uint32_t exc = (s.ereg >> (i & 15u)) & 1u;
+    if (exc) code = 4u + (code & 1u);
+    s.n_acgt += exc ? 0u : 1u;
+    // gen::<f32>() > accuracy(q)  <=>  (w >> 8) > floor(acc * 2^24)
+    if ((w >> 8) > thr[q] && !exc) {
+      s.st = 1;
+    } else {
+      m_emit(s, code, L, rev, sdst);
+    }
+  } else {
+    // choose(&[3 alternatives]) = gen_range(0..3u32), zone 0xBFFFFFFF
+    const uint64_t m = (uint64_t)w * 3u;
+    if ((uint32_t)m <= 0xBFFFFFFFu) {
+      const uint32_t k = (uint32_t)(m >> 32);
+      const uint32_t c = (s.creg >> (2 * (s.i & 15u))) & 3u;
+      s.st = 0;
+      s.n_subst++;
+      m_emit(s, k + (k >= c ? 1u : 0u), L, rev, sdst);
+    }
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
+             const uint32_t* __restrict__ order, PlanArrays pl, const uint64_t* __restrict__ u_off,
+             const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
+             uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_offset,
+             const Tables* __restrict__ T, unsigned long long* __restrict__ counters) {
+  __shared__ double2 zx2[256];
+  __shared__ double2 zf2[256];
+  __shared__ uint32_t thr[256];
+  {
+    const uint32_t t = threadIdx.x;
+    zx2[t] = make_double2(T->zig_x[t], T->zig_x[t + 1]);
+    zf2[t] = make_double2(T->zig_f[t], T->zig_f[t + 1]);
+    thr[t] = (uint32_t)floorf(T->acc[t] * 16777216.0f);
+  }
+  __syncthreads();
+  const GenomeDev G = genomes[genome];
+  const uint64_t n_tasks = 2 * n_units;
+  uint64_t qsum_tot = 0;
+  uint32_t subst_tot = 0, acgt_tot = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t task0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); task0 < n_tasks; task0 += stride) {
+    const uint64_t task = task0 + (threadIdx.x & 63u);
+    const bool live = task < n_tasks;
+    uint32_t L = 0, rev = 0;
+    uint64_t seed_q = 0, seed_m = 0, src = 0, off = 0;
+    if (live) {
+      const uint64_t u = order ? (uint64_t)order[task >> 1] : (task >> 1);
+      rev = (uint32_t)(task & 1u);
+      L = pl.len[u];
+      off = u_off[u] + (rev ? L : 0u);
+      src = G.contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]);
+      seed_q = rev ? pl.qs2[u] : u_seed[u];
+      seed_m = rev ? pl.ms2[u] : u_seed[u];
+    }
+    // ---- phase Q: simulate_phred_scores (minimal_short.rs:83-102)
+    {
+      const Key key = pcg32_expand(seed_q);
+      LaneQ s;
+      s.i = 0; s.st = 0; s.pidx = 0; s.px = 0.0; s.tx = 0.0; s.acc = 0; s.qsum = 0;
+      uint8_t* qdst = qual + off;
+      for (uint32_t blk = 0; __any(s.i < L); blk++) {
+        uint32_t w[16];
+        chacha12_block(key, blk, w);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (s.i < L) q_step(s, ((uint64_t)w[2 * j + 1] << 32) | w[2 * j], zx2, zf2, prof, T, qdst, qual_offset);
+        }
+      }
+      if (s.i & 7u) store_bytes(qdst + (s.i & ~7u), s.acc, s.i & 7u);
+      qsum_tot += s.qsum;
+    }
+    // ---- phase M: simulate_point_mutations (minimal_short.rs:104-140) + output
+    {
+      const Key key = pcg32_expand(seed_m);
+      LaneM s;
+      s.i = 0; s.st = 0; s.creg = 0; s.ereg = 0; s.qreg = 0; s.acc = 0; s.n_subst = 0; s.n_acgt = 0;
+      const uint8_t* qsrc = qual + off;
+      uint8_t* sdst = seq + off;
+      for (uint32_t blk = 0; __any(s.i < L); blk++) {
+        uint32_t w[16];
+        chacha12_block(key, blk, w);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          if (s.i < L) m_step(s, w[j], L, rev, G, src, thr, qsrc, qual_offset, sdst);
+        }
+      }
+      m_flush(s, rev, sdst);
+      subst_tot += s.n_subst;
+      acgt_tot += s.n_acgt;
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    subst_tot += __shfl_down(subst_tot, d, 64);
+    acgt_tot += __shfl_down(acgt_tot, d, 64);
+    qsum_tot += __shfl_down(qsum_tot, d, 64);
+  }
+  if ((threadIdx.x & 63u) == 0 && counters) {
+    atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)subst_tot);
+    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)acgt_tot);
+    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum_tot);
+  }
+}
+
 // perfect-short has no per-base draws: its counters come from the plan.
 extern "C" __global__ void __launch_bounds__(256)
 k_count_plan(uint32_t paired, uint64_t n_units, PlanArrays pl, uint32_t const_q, uint32_t acgt_all,
              unsigned long long* __restrict__ counters) {
   __shared__ uint64_t lds4[4];
-  uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t bases = 0, redrawn = 0, subst = 0;
-  if (k < n_units) {
-    bases = pl.bytes[k];
+  for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n_units; k += (uint64_t)gridDim.x * 256) {
+    bases += pl.bytes[k];
     const uint32_t f = pl.flags[k];
-    redrawn = (f & SIMMR_FLAG_REDRAWN) ? 1 : 0;
-    subst = ((f & SIMMR_FLAG_QSEED_SUBST) ? 1 : 0) + ((f & SIMMR_FLAG_MSEED_SUBST) ? 1 : 0);
+    redrawn += (f & SIMMR_FLAG_REDRAWN) ? 1 : 0;
+    subst += ((f & SIMMR_FLAG_QSEED_SUBST) ? 1 : 0) + ((f & SIMMR_FLAG_MSEED_SUBST) ? 1 : 0);
   }
   uint64_t tb, tr, ts;
   (void)wg_exclusive_scan_u64(bases, lds4, &tb);
   (void)wg_exclusive_scan_u64(redrawn, lds4, &tr);
   (void)wg_exclusive_scan_u64(subst, lds4, &ts);
   if (threadIdx.x == 0) {
-    uint64_t nu = (uint64_t)blockIdx.x * 256 + 256 <= n_units ? 256 : (n_units - (uint64_t)blockIdx.x * 256);
-    atomicAdd(&counters[SIMMR_CNT_READS], (unsigned long long)(paired ? 2 * nu : nu));
+    if (blockIdx.x == 0) atomicAdd(&counters[SIMMR_CNT_READS], (unsigned long long)(paired ? 2 * n_units : n_units));
     atomicAdd(&counters[SIMMR_CNT_BASES], (unsigned long long)tb);
     if (tr) atomicAdd(&counters[SIMMR_CNT_REDRAWN], (unsigned long long)tr);
     if (ts) atomicAdd(&counters[SIMMR_CNT_SEED_SUBST], (unsigned long long)ts);

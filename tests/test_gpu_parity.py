@@ -130,6 +130,21 @@ def test_minimal_short_params(engine, oracle, genome_multi, L, I, q):
     assert_same(dev.to_host(), ora.trimmed())
 
 
+def test_minimal_short_wave_per_pair_variant(oracle, genome_1m, monkeypatch):
+    """The wave-per-unit emit kernel (used for long reads) on pairs: same bytes."""
+    from simmr_amd.engine import Engine
+    monkeypatch.setenv("SIMMR_EMIT_VARIANT", "1")
+    e2 = Engine(0)
+    try:
+        e2.stage_synthetic(0, [1_000_000], 1)
+        prof = MinimalShortErrorProfile(read_length=170, insert_size=90).pod()
+        dev = e2.simulate_pe_reads_from_genome(0, prof, 3000, 11)
+        ora = _oracle.simulate_pe(oracle, genome_1m, prof, 3000, 11)
+        assert_same(dev.to_host(), ora.trimmed())
+    finally:
+        e2.close()
+
+
 def test_minimal_short_exceptions(engine, oracle):
     rng = np.random.default_rng(12)
     seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 20000)].copy()
