@@ -1183,6 +1183,8 @@ struct LaneM {
   uint32_t creg;    // 16 reference codes of bases (i & ~15) ..
   uint32_t ereg;    // their exception bits
   uint64_t qreg;    // 8 qualities of bases (i & ~7) ..
+  uint64_t qnext;   // prefetched: the following 8 qualities
+  uint32_t cnext, enext;  // prefetched: the following 16 codes / exception bits
   uint64_t acc;     // output bytes not yet stored
   uint32_t n_subst, n_acgt;
 };
@@ -1221,25 +1223,34 @@ __device__ __attribute__((noinline)) uint64_t load_q_tail(const uint8_t* __restr
   return v;
 }
 
+SIMMR_DEV uint64_t load_q8(const uint8_t* __restrict__ qsrc, uint32_t i, uint32_t L) {
+  if (i + 8 <= L) return *reinterpret_cast<const u64_unaligned*>(qsrc + i);
+  if (i >= L) return 0;
+  if (L >= 8) return *reinterpret_cast<const u64_unaligned*>(qsrc + L - 8) >> (8 * (i + 8 - L));
+  return load_q_tail(qsrc, i, L);
+}
+
+template <bool HAS_EXC>
 SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const GenomeDev& G, uint64_t src,
                       const uint32_t* __restrict__ thr, const uint8_t* __restrict__ qsrc, uint32_t qoff,
                       uint8_t* __restrict__ sdst) {
   if (s.st == 0) {
     const uint32_t i = s.i;
-    if ((i & 7u) == 0) {
-      if (i + 8 <= L) s.qreg = *reinterpret_cast<const u64_unaligned*>(qsrc + i);
-      else if (L >= 8) s.qreg = *reinterpret_cast<const u64_unaligned*>(qsrc + L - 8) >> (8 * (i + 8 - L));
-      else s.qreg = load_q_tail(qsrc, i, L);
-    }
+    // registers are refilled one chunk ahead so the loads overlap the steps
+    if ((i & 7u) == 0) { s.qreg = s.qnext; s.qnext = load_q8(qsrc, i + 8, L); }
     if ((i & 15u) == 0) {
-      s.creg = fetch_codes16(G.packed, (int64_t)(src + i));
-      s.ereg = G.has_exc ? fetch_mask16(G.mask, (int64_t)(src + i)) : 0u;
+      s.creg = s.cnext;
+      s.cnext = fetch_codes16(G.packed, (int64_t)(src + i + 16));
+      if (HAS_EXC) { s.ereg = s.enext; s.enext = fetch_mask16(G.mask, (int64_t)(src + i + 16)); }
     }
     const uint32_t q = ((uint32_t)(s.qreg >> (8 * (i & 7u))) - qoff) & 0xffu;
     uint32_t code = (s.creg >> (2 * (i & 15u))) & 3u;
-    const uint32_t exc = (s.ereg >> (i & 15u)) & 1u;
-    if (exc) code = 4u + (code & 1u);
-    s.n_acgt += exc ? 0u : 1u;
+    uint32_t exc = 0;
+    if (HAS_EXC) {
+      exc = (s.ereg >> (i & 15u)) & 1u;
+      if (exc) code = 4u + (code & 1u);
+      s.n_acgt += exc ? 0u : 1u;
+    }
     // gen::<f32>() > accuracy(q)  <=>  (w >> 8) > floor(acc * 2^24)
     if ((w >> 8) > thr[q] && !exc) {
       s.st = 1;
@@ -1259,7 +1270,8 @@ SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const Geno
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+template <bool HAS_EXC>
+__global__ void __launch_bounds__(256)
 k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
              const uint32_t* __restrict__ order, PlanArrays pl, const uint64_t* __restrict__ u_off,
              const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
@@ -1318,17 +1330,19 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
       s.i = 0; s.st = 0; s.creg = 0; s.ereg = 0; s.qreg = 0; s.acc = 0; s.n_subst = 0; s.n_acgt = 0;
       const uint8_t* qsrc = qual + off;
       uint8_t* sdst = seq + off;
+      s.qnext = load_q8(qsrc, 0, L);
+      s.cnext = fetch_codes16(G.packed, (int64_t)src);
+      s.enext = HAS_EXC ? fetch_mask16(G.mask, (int64_t)src) : 0u;
       for (uint32_t blk = 0; __any(s.i < L); blk++) {
         uint32_t w[16];
         chacha12_block(key, blk, w);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-          if (s.i < L) m_step(s, w[j], L, rev, G, src, thr, qsrc, qual_offset, sdst);
-        }
+        for (int j = 0; j < 16; j++)
+          if (s.i < L) m_step<HAS_EXC>(s, w[j], L, rev, G, src, thr, qsrc, qual_offset, sdst);
       }
       m_flush(s, rev, sdst);
       subst_tot += s.n_subst;
-      acgt_tot += s.n_acgt;
+      acgt_tot += HAS_EXC ? s.n_acgt : L;
     }
   }
   for (int d = 32; d > 0; d >>= 1) {
