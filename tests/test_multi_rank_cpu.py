@@ -1,0 +1,126 @@
+"""N > 1 path on CPU (gloo, world_size 2): the host sharding logic of
+simmr_amd.simulate driven with an oracle-backed stand-in for the GPU engine
+(test infrastructure), checked against the single-rank whole run, plus the one
+collective of the path (all-reduce of the run counters)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from simmr_amd import (ExactAbundanceProfile, MinimalLongErrorProfile, MinimalShortErrorProfile,
+                       PerfectShortErrorProfile, UniformAbundanceProfile)
+from simmr_amd.simulate import (GenomeRef, all_reduce_counters, pe_shards, simulate_long_reads,
+                                simulate_pe_reads, split_range)
+from tests import _oracle, _synth
+
+GENOMES = [([40_000, 30_000], 3), ([25_000], 4), ([60_000, 22_000, 21_000], 5)]
+
+
+class OracleBackend:
+    """Engine look-alike that computes shards with the CPU oracle (tests only)."""
+
+    def __init__(self):
+        self.lib = _oracle.load()
+        self.genomes = [_oracle.HostGenome(_synth.synthetic_contigs(lens, seed)) for lens, seed in GENOMES]
+
+    def simulate_pe_reads_from_genome(self, idx, pod, reads, seed, first=0, count=(1 << 64) - 1, read_id_base=0,
+                                      qual_offset=0):
+        return _oracle.simulate_pe(self.lib, self.genomes[idx], pod, reads, seed, first, count, read_id_base,
+                                   qual_offset=qual_offset)
+
+    def simulate_long_reads(self, idxs, reads, pod, seed, first=0, count=(1 << 64) - 1, read_id_base=0,
+                            qual_offset=0):
+        return _oracle.simulate_long(self.lib, [self.genomes[i] for i in idxs], reads, pod, seed, first, count,
+                                     read_id_base, qual_offset=qual_offset)
+
+
+def _refs():
+    return [GenomeRef(i, sum(l), f"g{i}.fna", f"id{i}") for i, (l, _) in enumerate(GENOMES)]
+
+
+def test_split_and_shards_cover_everything():
+    for total in (0, 1, 7, 1000, 10 ** 9 + 7):
+        for world in (1, 2, 3, 8):
+            parts = [split_range(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == total
+            assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+    reads = [10, 7, 0, 25]  # pairs 5, 3, 0, 12
+    seen = [0] * 4
+    for r in range(3):
+        for g, (first, count, base) in enumerate(pe_shards(reads, r, 3)):
+            assert base == [0, 5, 8, 8][g]
+            seen[g] += count
+    assert seen == [5, 3, 0, 12]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    be = OracleBackend()
+    prof = MinimalShortErrorProfile()
+    res = simulate_pe_reads(be, 3000, _refs(), prof, UniformAbundanceProfile(), 42, rank, world)
+    payload = []
+    counters = torch.zeros(4, dtype=torch.int64)
+    for (path, uuid, reads, abund, r) in res:
+        if r is None:
+            payload.append(None)
+            continue
+        d = r.trimmed()
+        payload.append({k: v.copy() for k, v in d.items()})
+        counters[0] += r.n_reads
+        counters[1] += r.total_bases
+    meta, lr = simulate_long_reads(be, 40, _refs(), MinimalLongErrorProfile(), ExactAbundanceProfile(), 9, rank, world)
+    counters[2] += lr.n_reads
+    counters[3] += lr.total_bases
+    all_reduce_counters(counters)
+    q.put((rank, payload, {k: v.copy() for k, v in lr.trimmed().items()}, counters.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one_rank():
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+    be = OracleBackend()
+    whole = simulate_pe_reads(be, 3000, _refs(), MinimalShortErrorProfile(), UniformAbundanceProfile(), 42, 0, 1)
+    tot_reads = tot_bases = 0
+    for g, (path, uuid, reads, abund, r) in enumerate(whole):
+        assert reads == 1000 and abund == 100.0 / 3
+        w = r.trimmed()
+        tot_reads += r.n_reads
+        tot_bases += r.total_bases
+        parts = [got[rk][1][g] for rk in range(world) if got[rk][1][g] is not None]
+        for col in ("start", "end", "contig", "read_id", "flags", "seq", "qual"):
+            assert np.array_equal(np.concatenate([p[col] for p in parts]), w[col]), (g, col)
+        lens = np.concatenate([np.diff(p["seq_off"].astype(np.int64)) for p in parts])
+        assert np.array_equal(lens, np.diff(w["seq_off"].astype(np.int64)))
+    # read ids run across genomes in generation order (simulate.rs:85-89)
+    ids = np.concatenate([r.trimmed()["read_id"] for *_, r in whole])
+    assert np.array_equal(ids, np.repeat(np.arange(1500, dtype=np.uint32), 2))
+    # long reads: one stream across genomes, shard = global read-index range
+    meta, lw = simulate_long_reads(be, 40, _refs(), MinimalLongErrorProfile(), ExactAbundanceProfile(), 9, 0, 1)
+    w = lw.trimmed()
+    assert lw.n_reads == 120
+    for col in ("start", "end", "contig", "genome", "read_id", "seq", "qual"):
+        assert np.array_equal(np.concatenate([got[rk][2][col] for rk in range(world)]), w[col]), col
+    # the all-reduced counters equal the whole-run totals on every rank
+    for rk in range(world):
+        assert got[rk][3] == [tot_reads, tot_bases, lw.n_reads, lw.total_bases]
