@@ -712,10 +712,10 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       int per_cu = 0;
       const bool exc = e->genomes[e->plan_genome].has_exc;
       auto kern = exc ? k_emit_lanes<true> : k_emit_lanes<false>;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-      const uint64_t wgs = (2 * n_units + 255) / 256;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, LANES_WG, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+      const uint64_t wgs = (2 * n_units + LANES_WG - 1) / LANES_WG;
       const uint32_t grid = (uint32_t)std::min<uint64_t>(wgs, (uint64_t)e->n_cu * (uint64_t)per_cu);
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(LANES_WG), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, e->plan_sorted ? e->u_order.as<uint32_t>() : (const uint32_t*)nullptr,
                          pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(), out->seq,
                          out->qual, out->qual_offset, e->d_tables.as<Tables>(), counters);

@@ -1104,14 +1104,97 @@ struct LaneQ {
   uint32_t pidx;   // layer of the pending wedge
   double px;       // pending x (WEDGE) / u (TAIL) 
   double tx;       // TAIL: x_ draw waiting for its y_
-  uint64_t acc;    // up to 8 quality bytes not yet stored
   uint64_t qsum;
 };
+
+// Per-lane output staging: a 128-byte ring in LDS holding the two 64-byte
+// global sectors the lane is currently filling.  Sectors are flushed whole
+// (global_store_dwordx4 x4 on a 64-byte aligned address) once per ChaCha
+// block, so HBM sees full-sector writes instead of scattered 8-byte pieces.
+#define RING_PITCH 136u
+struct OutRing {
+  uint8_t* ring;    // LDS row of this lane
+  uint8_t* g;       // global address of byte 0 of this read
+  uint32_t a0;      // (address of byte 0) & 127
+  uint32_t L;
+  uint32_t mark;    // forward: bytes [0, mark) are flushed; reverse: bytes [mark, L) are flushed
+};
+
+SIMMR_DEV void ring_init(OutRing& r, uint8_t* lds_row, uint8_t* g, uint32_t L, bool descending) {
+  r.ring = lds_row; r.g = g; r.L = L;
+  r.a0 = (uint32_t)(reinterpret_cast<uintptr_t>(g) & 127u);
+  r.mark = descending ? L : 0u;
+}
+SIMMR_DEV void ring_put(const OutRing& r, uint32_t k, uint32_t byte) { r.ring[(r.a0 + k) & 127u] = (uint8_t)byte; }
+
+// copy bytes [lo, hi) of the read (all inside one 64-byte sector) ring -> global
+SIMMR_DEV void ring_copy(const OutRing& r, uint32_t lo, uint32_t hi) {
+  const uint32_t p = r.a0 + lo;
+  if (hi - lo == 64u && (p & 63u) == 0u) {
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(r.ring + (p & 127u));
+    uint4* dst = reinterpret_cast<uint4*>(r.g + lo);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint64_t a = src[2 * c], b = src[2 * c + 1];
+      dst[c] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    }
+  } else {
+    uint32_t k = lo;
+    while (k < hi) {
+      const uint32_t q = r.a0 + k;
+      if ((q & 7u) == 0u && k + 8u <= hi) {
+        *reinterpret_cast<uint64_t*>(r.g + k) = *reinterpret_cast<const uint64_t*>(r.ring + (q & 127u));
+        k += 8;
+      } else {
+        r.g[k] = r.ring[q & 127u];
+        k++;
+      }
+    }
+  }
+}
+// forward stream: `done` bytes [0, done) are in the ring or flushed
+SIMMR_DEV void ring_flush_fwd(OutRing& r, uint32_t done) {
+  while (r.mark < done) {
+    const uint32_t sector_end = (((r.a0 + r.mark) >> 6) + 1u) * 64u - r.a0;
+    const uint32_t kend = sector_end < r.L ? sector_end : r.L;
+    if (done < kend) break;
+    ring_copy(r, r.mark, kend);
+    r.mark = kend;
+  }
+}
+// descending stream: bytes [low, L) are in the ring or flushed
+SIMMR_DEV void ring_flush_rev(OutRing& r, uint32_t low) {
+  while (r.mark > 0u) {
+    const int32_t sector_start = (int32_t)(((r.a0 + r.mark - 1u) >> 6) * 64u) - (int32_t)r.a0;
+    const uint32_t ks = sector_start > 0 ? (uint32_t)sector_start : 0u;
+    if (low > ks) break;
+    ring_copy(r, ks, r.mark);
+    r.mark = ks;
+  }
+}
 
 // rare: exact wedge decision and the tail loop (rand_distr zero_case)
 __device__ __attribute__((noinline)) bool wedge_exact(double t, double x) {
   return t < exp(__dmul_rn(__dmul_rn(-x, x), 0.5));
 }
+// Decision of the ziggurat wedge test  f1 + (f0 - f1) r < exp(-x^2/2)  in f64:
+// Taylor bounds of pdf(x) = F[i] e^d, d = (X[i]^2 - x^2)/2 in [0, 0.73], with a
+// 1e-13 guard band, exp() only inside the band.
+__device__ __attribute__((noinline)) bool wedge_f64(const Tables* __restrict__ T, uint32_t zi, double x,
+                                                    uint64_t bits) {
+  const double r = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+  const double f0 = T->zig_f[zi], f1 = T->zig_f[zi + 1];
+  const double t = __dadd_rn(f1, __dmul_rn(__dsub_rn(f0, f1), r));
+  const double Xi = T->zig_x[zi], ax = fabs(x);
+  const double d = (Xi - ax) * (Xi + ax) * 0.5;
+  const double d2 = d * d;
+  const double lo = f0 * (1.0 + d + 0.5 * d2 + d2 * d * (1.0 / 6.0));
+  const double hi = lo + f0 * (0.06 * d2 * d2);
+  if (t < lo * (1.0 - 1e-13)) return true;
+  if (t > hi * (1.0 + 1e-13)) return false;
+  return wedge_exact(t, x);
+}
+
 __device__ __attribute__((noinline)) bool tail_try(double x_, double y_, double u, double* out) {
   const double xx = log(x_) / SIMMR_ZIG_R;
   const double yy = log(y_);
@@ -1120,59 +1203,51 @@ __device__ __attribute__((noinline)) bool tail_try(double x_, double y_, double 
   return true;
 }
 
-SIMMR_DEV void q_emit(LaneQ& s, double x, const ProfileDev& prof, const Tables* __restrict__ T,
-                      uint8_t* __restrict__ qdst, uint32_t qoff) {
+SIMMR_DEV void q_emit(LaneQ& s, double x, const ProfileDev& prof, const OutRing& ring, uint32_t qoff) {
   // minimal_short.rs:90-101: floor(Normal<f32>(mean, 10).sample()) as u8
-  (void)T;
   const uint32_t q = sat_u8_f32(floorf(__fadd_rn(prof.mean_phred_f, __fmul_rn(10.0f, (float)x))));
   s.qsum += q;
-  s.acc |= (uint64_t)((q + qoff) & 0xffu) << (8 * (s.i & 7u));
+  ring_put(ring, s.i, q + qoff);
   s.i++;
-  if ((s.i & 7u) == 0) {
-    *reinterpret_cast<u64_unaligned*>(qdst + s.i - 8) = s.acc;
-    s.acc = 0;
-  }
 }
 
 SIMMR_DEV void q_step(LaneQ& s, uint64_t bits, const double2* __restrict__ zx2,
-                      const double2* __restrict__ zf2, const ProfileDev& prof,
-                      const Tables* __restrict__ T, uint8_t* __restrict__ qdst, uint32_t qoff) {
+                      const float2* __restrict__ zf2f, const Tables* __restrict__ T,
+                      const ProfileDev& prof, const OutRing& ring, uint32_t qoff) {
   if (s.st == 0) {
     const uint32_t zi = (uint32_t)bits & 0xffu;
     const double u = __longlong_as_double((long long)((bits >> 12) | 0x4000000000000000ULL)) - 3.0;
     const double2 X = zx2[zi];
     const double x = __dmul_rn(u, X.x);
     if (fabs(x) < X.y) {
-      q_emit(s, x, prof, T, qdst, qoff);
+      q_emit(s, x, prof, ring, qoff);
     } else if (zi == 0) {
       s.st = 2; s.px = u;
     } else {
       s.st = 1; s.px = x; s.pidx = zi;
     }
   } else if (s.st == 1) {
-    // f_tab[i+1] + (f_tab[i] - f_tab[i+1]) * gen::<f64>() < pdf(x)
-    const double r = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
-    const double2 F = zf2[s.pidx];  // {F[i], F[i+1]}
-    const double t = __dadd_rn(F.y, __dmul_rn(__dsub_rn(F.x, F.y), r));
-    // pdf(x) = F[i] * e^d, d = (X[i]^2 - x^2)/2 in [0, 0.73]; Taylor bounds
-    const double Xi = zx2[s.pidx].x, ax = fabs(s.px);
-    const double d = (Xi - ax) * (Xi + ax) * 0.5;
-    const double d2 = d * d;
-    const double lo = F.x * (1.0 + d + 0.5 * d2 + d2 * d * (1.0 / 6.0));
-    const double hi = lo + F.x * (0.06 * d2 * d2);
+    // f_tab[i+1] + (f_tab[i] - f_tab[i+1]) * gen::<f64>() < pdf(x):
+    // an f32 estimate settles it unless the two sides are within 1e-4 (the
+    // f32 error is < 1e-5); only then the f64 decision runs.
+    const float2 Ff = zf2f[s.pidx];  // {F[i], F[i+1]} rounded to f32
+    const float rf = (float)(uint32_t)(bits >> 40) * (1.0f / 16777216.0f);
+    const float tf = Ff.y + (Ff.x - Ff.y) * rf;
+    const float xf = (float)s.px;
+    const float pf = __builtin_amdgcn_exp2f(xf * xf * -0.72134752044448170f);  // exp(-x^2/2)
     bool accept;
-    if (t < lo * (1.0 - 1e-13)) accept = true;
-    else if (t > hi * (1.0 + 1e-13)) accept = false;
-    else accept = wedge_exact(t, s.px);
+    if (tf < pf * (1.0f - 1e-4f)) accept = true;
+    else if (tf > pf * (1.0f + 1e-4f)) accept = false;
+    else accept = wedge_f64(T, s.pidx, s.px, bits);
     s.st = 0;
-    if (accept) q_emit(s, s.px, prof, T, qdst, qoff);
+    if (accept) q_emit(s, s.px, prof, ring, qoff);
   } else if (s.st == 2) {
     s.tx = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ULL)) - (1.0 - 2.220446049250313e-16 / 2.0);
     s.st = 3;
   } else {
     const double y_ = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ULL)) - (1.0 - 2.220446049250313e-16 / 2.0);
     double x;
-    if (tail_try(s.tx, y_, s.px, &x)) { s.st = 0; q_emit(s, x, prof, T, qdst, qoff); }
+    if (tail_try(s.tx, y_, s.px, &x)) { s.st = 0; q_emit(s, x, prof, ring, qoff); }
     else s.st = 2;
   }
 }
@@ -1185,36 +1260,16 @@ struct LaneM {
   uint64_t qreg;    // 8 qualities of bases (i & ~7) ..
   uint64_t qnext;   // prefetched: the following 8 qualities
   uint32_t cnext, enext;  // prefetched: the following 16 codes / exception bits
-  uint64_t acc;     // output bytes not yet stored
   uint32_t n_subst, n_acgt;
 };
 
-SIMMR_DEV void m_emit(LaneM& s, uint32_t code, uint32_t L, uint32_t rev, uint8_t* __restrict__ sdst) {
+SIMMR_DEV void m_emit(LaneM& s, uint32_t code, uint32_t L, uint32_t rev, const OutRing& ring) {
   // code 0-3 = ACGT, 4 = 'N', 5 = '-'
   const uint32_t lut_f = 0x54474341u, lut_r = 0x41434754u;  // "ACGT", "TGCA"
   const uint32_t ch = code < 4u ? ((rev ? lut_r : lut_f) >> (8 * code)) & 0xffu : (code == 4u ? 'N' : '-');
-  // forward mate: byte i.  Mate 2 (simulate.rs:283): byte L-1-i; 8-byte groups
-  // are counted from the END of the read so that every in-loop store is full.
-  const uint32_t p = s.i & 7u;
-  s.acc |= (uint64_t)ch << (8 * (rev ? 7u - p : p));
+  // forward mate: byte i.  Mate 2 is reverse-complemented AFTER mutation (simulate.rs:283): byte L-1-i
+  ring_put(ring, rev ? (L - 1u - s.i) : s.i, ch);
   s.i++;
-  if (p == 7u) {
-    const uint32_t at = rev ? (L - s.i) : (s.i - 8);
-    *reinterpret_cast<u64_unaligned*>(sdst + at) = s.acc;
-    s.acc = 0;
-  }
-}
-
-// after the loop: the last (s.i & 7) bytes
-SIMMR_DEV void m_flush(const LaneM& s, uint32_t rev, uint8_t* __restrict__ sdst) {
-  const uint32_t n = s.i & 7u;
-  if (n == 0) return;
-  if (!rev) {
-    for (uint32_t b = 0; b < n; b++) sdst[(s.i & ~7u) + b] = (uint8_t)(s.acc >> (8 * b));
-  } else {
-    // bytes sit at positions 7, 6, ... 8-n of acc and belong to addresses n-1 ... 0
-    for (uint32_t b = 0; b < n; b++) sdst[b] = (uint8_t)(s.acc >> (8 * (8 - n + b)));
-  }
 }
 
 __device__ __attribute__((noinline)) uint64_t load_q_tail(const uint8_t* __restrict__ qsrc, uint32_t i, uint32_t L) {
@@ -1233,7 +1288,7 @@ SIMMR_DEV uint64_t load_q8(const uint8_t* __restrict__ qsrc, uint32_t i, uint32_
 template <bool HAS_EXC>
 SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const GenomeDev& G, uint64_t src,
                       const uint32_t* __restrict__ thr, const uint8_t* __restrict__ qsrc, uint32_t qoff,
-                      uint8_t* __restrict__ sdst) {
+                      const OutRing& ring) {
   if (s.st == 0) {
     const uint32_t i = s.i;
     // registers are refilled one chunk ahead so the loads overlap the steps
@@ -1255,7 +1310,7 @@ SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const Geno
     if ((w >> 8) > thr[q] && !exc) {
       s.st = 1;
     } else {
-      m_emit(s, code, L, rev, sdst);
+      m_emit(s, code, L, rev, ring);
     }
   } else {
     // choose(&[3 alternatives]) = gen_range(0..3u32), zone 0xBFFFFFFF
@@ -1265,34 +1320,37 @@ SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const Geno
       const uint32_t c = (s.creg >> (2 * (s.i & 15u))) & 3u;
       s.st = 0;
       s.n_subst++;
-      m_emit(s, k + (k >= c ? 1u : 0u), L, rev, sdst);
+      m_emit(s, k + (k >= c ? 1u : 0u), L, rev, ring);
     }
   }
 }
 
+#define LANES_WG 512
 template <bool HAS_EXC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LANES_WG)
 k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
              const uint32_t* __restrict__ order, PlanArrays pl, const uint64_t* __restrict__ u_off,
              const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
              uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_offset,
              const Tables* __restrict__ T, unsigned long long* __restrict__ counters) {
   __shared__ double2 zx2[256];
-  __shared__ double2 zf2[256];
+  __shared__ float2 zf2f[256];
   __shared__ uint32_t thr[256];
-  {
+  __shared__ __attribute__((aligned(16))) uint8_t rings[LANES_WG * RING_PITCH];
+  if (threadIdx.x < 256) {
     const uint32_t t = threadIdx.x;
     zx2[t] = make_double2(T->zig_x[t], T->zig_x[t + 1]);
-    zf2[t] = make_double2(T->zig_f[t], T->zig_f[t + 1]);
+    zf2f[t] = make_float2((float)T->zig_f[t], (float)T->zig_f[t + 1]);
     thr[t] = (uint32_t)floorf(T->acc[t] * 16777216.0f);
   }
   __syncthreads();
+  uint8_t* my_ring = rings + threadIdx.x * RING_PITCH;
   const GenomeDev G = genomes[genome];
   const uint64_t n_tasks = 2 * n_units;
   uint64_t qsum_tot = 0;
   uint32_t subst_tot = 0, acgt_tot = 0;
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  for (uint64_t task0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); task0 < n_tasks; task0 += stride) {
+  const uint64_t stride = (uint64_t)gridDim.x * LANES_WG;
+  for (uint64_t task0 = (uint64_t)blockIdx.x * LANES_WG + (threadIdx.x & ~63u); task0 < n_tasks; task0 += stride) {
     const uint64_t task = task0 + (threadIdx.x & 63u);
     const bool live = task < n_tasks;
     uint32_t L = 0, rev = 0;
@@ -1310,26 +1368,28 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
     {
       const Key key = pcg32_expand(seed_q);
       LaneQ s;
-      s.i = 0; s.st = 0; s.pidx = 0; s.px = 0.0; s.tx = 0.0; s.acc = 0; s.qsum = 0;
-      uint8_t* qdst = qual + off;
+      s.i = 0; s.st = 0; s.pidx = 0; s.px = 0.0; s.tx = 0.0; s.qsum = 0;
+      OutRing ring;
+      ring_init(ring, my_ring, qual + off, L, false);
       for (uint32_t blk = 0; __any(s.i < L); blk++) {
         uint32_t w[16];
         chacha12_block(key, blk, w);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          if (s.i < L) q_step(s, ((uint64_t)w[2 * j + 1] << 32) | w[2 * j], zx2, zf2, prof, T, qdst, qual_offset);
+          if (s.i < L) q_step(s, ((uint64_t)w[2 * j + 1] << 32) | w[2 * j], zx2, zf2f, T, prof, ring, qual_offset);
         }
+        ring_flush_fwd(ring, s.i);
       }
-      if (s.i & 7u) store_bytes(qdst + (s.i & ~7u), s.acc, s.i & 7u);
       qsum_tot += s.qsum;
     }
     // ---- phase M: simulate_point_mutations (minimal_short.rs:104-140) + output
     {
       const Key key = pcg32_expand(seed_m);
       LaneM s;
-      s.i = 0; s.st = 0; s.creg = 0; s.ereg = 0; s.qreg = 0; s.acc = 0; s.n_subst = 0; s.n_acgt = 0;
+      s.i = 0; s.st = 0; s.creg = 0; s.ereg = 0; s.qreg = 0; s.n_subst = 0; s.n_acgt = 0;
       const uint8_t* qsrc = qual + off;
-      uint8_t* sdst = seq + off;
+      OutRing ring;
+      ring_init(ring, my_ring, seq + off, L, rev != 0);
       s.qnext = load_q8(qsrc, 0, L);
       s.cnext = fetch_codes16(G.packed, (int64_t)src);
       s.enext = HAS_EXC ? fetch_mask16(G.mask, (int64_t)src) : 0u;
@@ -1338,9 +1398,9 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
         chacha12_block(key, blk, w);
 #pragma unroll
         for (int j = 0; j < 16; j++)
-          if (s.i < L) m_step<HAS_EXC>(s, w[j], L, rev, G, src, thr, qsrc, qual_offset, sdst);
+          if (s.i < L) m_step<HAS_EXC>(s, w[j], L, rev, G, src, thr, qsrc, qual_offset, ring);
+        if (rev) ring_flush_rev(ring, L - s.i); else ring_flush_fwd(ring, s.i);
       }
-      m_flush(s, rev, sdst);
       subst_tot += s.n_subst;
       acgt_tot += HAS_EXC ? s.n_acgt : L;
     }
