@@ -1,0 +1,193 @@
+// main.cpp — `simmr-hip`: the reference's run_main (simmr/src/main.rs:20-268)
+// over the C ABI of libsimmr_hip.so.  Same flags, same output files:
+// interleaved FASTQ (fastq.rs) and "<output>.tsv" metadata (files.rs:100-134).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <sys/stat.h>
+
+#include <string>
+#include <vector>
+
+#include "simmr_host.hpp"
+
+using namespace simmr_host;
+
+static void info(const char* msg) { fprintf(stderr, " INFO simmr-hip: %s\n", msg); }
+static void warn(const std::string& msg) { fprintf(stderr, " WARN simmr-hip: %s\n", msg.c_str()); }
+static int die(const std::string& msg) { fprintf(stderr, "ERROR simmr-hip: %s\n", msg.c_str()); return 1; }
+static bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+struct DeviceOut {
+  simmr_reads_out o{};
+  std::vector<void*> allocs;
+  ~DeviceOut() { for (void* p : allocs) (void)hipFree(p); }
+  template <class T> bool alloc(T** dst, size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return false;
+    allocs.push_back(p);
+    *dst = (T*)p;
+    return true;
+  }
+  bool init(uint64_t n_reads, uint64_t total_bases) {
+    o.seq_capacity = total_bases + 32;
+    o.reads_capacity = n_reads;
+    o.qual_offset = 33;  // util::encode_quality_scores (util.rs:46-57)
+    return alloc(&o.seq, o.seq_capacity) && alloc(&o.qual, o.seq_capacity) && alloc(&o.seq_off, n_reads + 1) &&
+           alloc(&o.start, n_reads) && alloc(&o.end, n_reads) && alloc(&o.contig, n_reads) &&
+           alloc(&o.genome, n_reads) && alloc(&o.read_id, n_reads) && alloc(&o.flags, n_reads);
+  }
+  bool to_host(uint64_t n_reads, uint64_t total_bases, bool paired, HostReads* h) {
+    h->n_reads = n_reads; h->paired = paired;
+    h->seq.resize(total_bases); h->qual.resize(total_bases);
+    h->seq_off.resize(n_reads + 1); h->start.resize(n_reads); h->end.resize(n_reads);
+    h->contig.resize(n_reads); h->genome.resize(n_reads); h->read_id.resize(n_reads); h->flags.resize(n_reads);
+    auto cp = [](void* d, const void* s, size_t n) { return n == 0 || hipMemcpy(d, s, n, hipMemcpyDeviceToHost) == hipSuccess; };
+    return cp(h->seq.data(), o.seq, total_bases) && cp(h->qual.data(), o.qual, total_bases) &&
+           cp(h->seq_off.data(), o.seq_off, (n_reads + 1) * 8) && cp(h->start.data(), o.start, n_reads * 8) &&
+           cp(h->end.data(), o.end, n_reads * 8) && cp(h->contig.data(), o.contig, n_reads * 4) &&
+           cp(h->genome.data(), o.genome, n_reads * 4) && cp(h->read_id.data(), o.read_id, n_reads * 4) &&
+           cp(h->flags.data(), o.flags, n_reads);
+  }
+};
+
+static int run_main(int argc, char** argv) {
+  CliArgs args;
+  std::string err;
+  bool help = false;
+  if (!parse_cli_args(argc, argv, &args, &err, &help)) { fprintf(stderr, "error: %s\n\n%s", err.c_str(), usage().c_str()); return 2; }
+  if (help) { fputs(usage().c_str(), stdout); return 0; }
+
+  std::unique_ptr<ErrorProfile> eprofile = determine_error_profile(args, &err);  // main.rs:27
+  if (!eprofile) return die(err);
+
+  info("Loading genomes");
+  std::vector<Genome> genomes;
+  if (args.genome_file) {  // main.rs:38-100
+    std::vector<GenomeRecord> records;
+    if (!parse_genome_file(*args.genome_file, &records, &err)) return die("Failed to read genome file: " + err);
+    for (const auto& rec : records)
+      if (!exists(rec.filepath)) return die("Genome (" + rec.filepath + ") does not exist");
+    for (const auto& rec : records) {
+      Genome g;
+      if (!Genome::from_fasta(rec.filepath, args.contiguous, &g, &err)) return die("Failed to parse " + rec.filepath + ": " + err);
+      if (rec.uuid) g.uuid = *rec.uuid;
+      if (args.abundance_profile == AbundanceProfileKind::Custom && !rec.abundance)
+        return die("You used a custom abundance profile but didn't provide abundances for genome " + g.filepath);
+      g.abundance = rec.abundance;
+      genomes.push_back(std::move(g));
+    }
+  } else {  // main.rs:101-117
+    for (const auto& path : args.genome) {
+      Genome g;
+      if (!Genome::from_fasta(path, args.contiguous, &g, &err)) return die("Failed to parse " + path + ": " + err);
+      genomes.push_back(std::move(g));
+    }
+  }
+  if (args.abundance_profile == AbundanceProfileKind::Custom && !args.genome_file)
+    return die("a custom abundance profile needs a --genome-file with abundances");
+
+  info("Ensuring genomes meet minimum sequence length requirements for simulation");
+  if (!args.contiguous) {  // main.rs:117-162
+    const uint64_t min_size = eprofile->minimum_genome_size();
+    std::vector<Genome> kept;
+    for (Genome& g : genomes) {
+      std::vector<Seq> seqs;
+      for (Seq& s : g.sequence) {
+        if (s.size <= min_size)
+          warn("(" + g.filepath + ") Sequence " + s.id + " doesn't meet size requirements, size = " +
+               std::to_string(s.size) + ", min size = " + std::to_string(min_size));
+        else
+          seqs.push_back(std::move(s));
+      }
+      g.sequence = std::move(seqs);
+      if (g.sequence.empty()) { warn("Removing " + g.filepath + " from simulation, it doesn't have usable sequences"); continue; }
+      g.num_seqs = g.sequence.size();
+      kept.push_back(std::move(g));
+    }
+    genomes = std::move(kept);
+  }
+  if (genomes.empty()) return die("no usable genomes");
+
+  std::optional<std::vector<double>> custom_ab;
+  if (args.abundance_profile == AbundanceProfileKind::Custom) {
+    custom_ab.emplace();
+    for (const Genome& g : genomes) custom_ab->push_back(*g.abundance);
+  }
+  std::unique_ptr<AbundanceProfile> aprofile = determine_abundance_profile(args, custom_ab);
+
+  // ---- stage the references once (replaces keeping Vec<Seq> in RAM for the loop)
+  simmr_engine* eng = nullptr;
+  if (simmr_engine_create(args.device, &eng) != SIMMR_OK) return die(std::string("cannot create engine: ") + simmr_last_error(nullptr));
+  for (size_t gi = 0; gi < genomes.size(); gi++) {
+    const Genome& g = genomes[gi];
+    std::vector<const uint8_t*> ptrs;
+    std::vector<uint64_t> lens, sizes;
+    for (const Seq& s : g.sequence) { ptrs.push_back((const uint8_t*)s.seq.data()); lens.push_back(s.seq.size()); sizes.push_back(s.size); }
+    if (simmr_stage_genome(eng, (uint32_t)gi, (uint32_t)ptrs.size(), ptrs.data(), lens.data(), sizes.data()) != SIMMR_OK)
+      return die(std::string("staging failed: ") + simmr_last_error(eng));
+  }
+
+  // abundances (simulate.rs:121-132 / :334-343)
+  const bool is_long = eprofile->is_long_read();
+  Abundances ab = aprofile->determine_abundances(args.num_reads, genomes.size());
+  if (aprofile->is_size_aware()) ab = aprofile->adjust_for_size(genomes, ab, is_long ? 20000 : args.read_length, !is_long);
+
+  // main.rs:191-198: remove previous outputs
+  if (exists(args.output)) remove(args.output.c_str());
+  const std::string meta_path = args.output + ".tsv";
+  if (exists(meta_path)) remove(meta_path.c_str());
+
+  const simmr_error_profile pod = eprofile->pod();
+  const int has_seed = args.seed ? 1 : 0;
+  const uint64_t seed = args.seed.value_or(0);
+  const simmr_range all{0, UINT64_MAX};
+
+  if (!is_long) {
+    info("Simulating short reads");
+    uint32_t id_base = 0;  // the global AtomicU32 of simulate.rs:85-89
+    for (size_t gi = 0; gi < genomes.size(); gi++) {
+      simmr_plan_info pi{};
+      if (simmr_pe_plan(eng, (uint32_t)gi, &pod, ab[gi].first, has_seed, seed, all, &pi) != SIMMR_OK)
+        return die(simmr_last_error(eng));  // the reference unwrap()s this Err (simulate.rs:137)
+      DeviceOut d;
+      if (!d.init(pi.n_reads, pi.total_bases)) return die("device allocation failed");
+      if (simmr_pe_emit(eng, id_base, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
+      HostReads h;
+      if (!d.to_host(pi.n_reads, pi.total_bases, true, &h)) return die("copy back failed");
+      if (!write_to_fastq(genomes[gi].uuid, genomes[gi], h, 0, pi.n_reads, args.output, args.read_header_format, true, &err))
+        fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+      id_base += (uint32_t)pi.n_units;
+    }
+  } else {
+    info("Simulating long reads");
+    std::vector<uint32_t> idx(genomes.size());
+    std::vector<uint64_t> reads(genomes.size());
+    for (size_t gi = 0; gi < genomes.size(); gi++) { idx[gi] = (uint32_t)gi; reads[gi] = ab[gi].first; }
+    simmr_plan_info pi{};
+    if (simmr_long_plan(eng, (uint32_t)genomes.size(), idx.data(), reads.data(), &pod, has_seed, seed, all, &pi) != SIMMR_OK)
+      return die(simmr_last_error(eng));
+    DeviceOut d;
+    if (!d.init(pi.n_reads, pi.total_bases)) return die("device allocation failed");
+    if (simmr_long_emit(eng, 0, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
+    HostReads h;
+    if (!d.to_host(pi.n_reads, pi.total_bases, false, &h)) return die("copy back failed");
+    uint64_t first = 0;
+    for (size_t gi = 0; gi < genomes.size(); gi++) {
+      if (!write_to_fastq(genomes[gi].uuid, genomes[gi], h, first, reads[gi], args.output, args.read_header_format, true, &err))
+        fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+      first += reads[gi];
+    }
+  }
+  info(("Writing simulated reads to " + args.output).c_str());
+
+  // main.rs:213-258
+  std::vector<MetadataRow> rows;
+  for (size_t gi = 0; gi < genomes.size(); gi++) rows.push_back({genomes[gi].uuid, genomes[gi].filepath, ab[gi].first, ab[gi].second});
+  info(("Writing simulation metadata to " + meta_path).c_str());
+  if (!write_metadata(rows, meta_path, &err)) fprintf(stderr, "ERROR simmr-hip: Failed to write metadata file: %s\n", err.c_str());
+  simmr_engine_destroy(eng);
+  return 0;
+}
+
+int main(int argc, char** argv) { return run_main(argc, argv); }

@@ -1,0 +1,105 @@
+"""End-to-end on the GPU box: the simmr-hip CLI (C++ host over the C ABI) must
+write the FASTQ / metadata TSV the reference would write for the same seed —
+expected bytes are built here from the CPU oracle plus a restatement of
+fastq.rs:32-121 and files.rs:100-134."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from simmr_amd import MinimalLongErrorProfile, MinimalShortErrorProfile, PerfectShortErrorProfile
+from tests import _oracle, _synth
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+EXE = ROOT / "simmr_amd" / "host" / "simmr-hip"
+FMT = ("@{:read_id:}|{:genome_id:}/{:pair:} metadata:sid={:sequence_id:}|sp={:start_position:}"
+       "|ep={:end_position:}|rc={:reverse_complement:}")
+
+
+def fastq_of(d, n_reads, names, genome_id, paired, fmt=FMT):
+    out = bytearray()
+    for r in range(n_reads):
+        rc = bool(d["flags"][r] & 1)
+        h = fmt
+        for k, v in (("{:genome_id:}", genome_id), ("{:read_id:}", str(int(d["read_id"][r]))),
+                     ("{:sequence_id:}", names[int(d["contig"][r])]), ("{:start_position:}", str(int(d["start"][r]))),
+                     ("{:end_position:}", str(int(d["end"][r]))), ("{:reverse_complement:}", "t" if rc else "f"),
+                     ("{:pair:}", "2" if (paired and r & 1) else "1")):
+            h = h.replace(k, v)
+        a, b = int(d["seq_off"][r]), int(d["seq_off"][r + 1])
+        out += h.encode() + b"\n" + d["seq"][a:b].tobytes() + b"\n+\n" + d["qual"][a:b].tobytes() + b"\n"
+    return bytes(out)
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    subprocess.check_call(["make", "-s", "-C", str(ROOT / "simmr_amd" / "host")])
+    d = tmp_path_factory.mktemp("cli")
+    specs = [([120_000, 300, 40_000], 21, ["chr1 test genome", "tiny", "plasmid pX"]), ([90_000], 22, ["only"])]
+    genomes = []
+    for gi, (lens, seed, names) in enumerate(specs):
+        contigs = _synth.synthetic_contigs(lens, seed)
+        contigs[0] = contigs[0].copy()
+        contigs[0][1000:1100] = ord("N")
+        _synth.write_fasta(d / f"g{gi}.fna", contigs, names)
+        genomes.append((contigs, names))
+    (d / "genomes.tsv").write_text("path\tid\n" + "".join(f"{d}/g{gi}.fna\tgenome{gi}\n" for gi in range(2)))
+    return d, genomes
+
+
+@pytest.mark.parametrize("profile,cls", [("perfect-short", PerfectShortErrorProfile), ("minimal-short", MinimalShortErrorProfile)])
+def test_cli_pe_fastq_bytes(workdir, oracle, profile, cls):
+    d, genomes = workdir
+    out = d / f"{profile}.fq"
+    subprocess.check_call([str(EXE), "--genome-file", str(d / "genomes.tsv"), "--output", str(out), "--num-reads", "3001",
+                           "--seed", "42", "--error-profile", profile])
+    expected = bytearray()
+    id_base = 0
+    for gi, (contigs, names) in enumerate(genomes):
+        keep = [i for i, c in enumerate(contigs) if c.size > 450]  # main.rs:117-162 size filter
+        g = _oracle.HostGenome([contigs[i] for i in keep])
+        reads = 1501  # uniform: ceil(3001 / 2)
+        o = _oracle.simulate_pe(oracle, g, cls().pod(), reads, 42, read_id_base=id_base, qual_offset=33)
+        expected += fastq_of(o.trimmed(), o.n_reads, [names[i] for i in keep], f"genome{gi}", True)
+        id_base += reads // 2
+    assert out.read_bytes() == bytes(expected)
+    meta = (d / f"{profile}.fq.tsv").read_text().split("\n")
+    assert meta[0] == "genome_id\tfilepath\tnum_reads\tabundance"
+    assert meta[1] == f"genome0\t{d}/g0.fna\t1501\t50" and meta[2] == f"genome1\t{d}/g1.fna\t1501\t50"
+
+
+def test_cli_long_fastq_bytes(workdir, oracle):
+    d, genomes = workdir
+    out = d / "long.fq"
+    subprocess.check_call([str(EXE), "--genome-file", str(d / "genomes.tsv"), "--output", str(out), "--num-reads", "25",
+                           "--seed", "7", "--error-profile", "minimal-long", "--abundance-profile", "exact",
+                           "--read-header-format", "@r{:read_id:} {:genome_id:} {:sequence_id:} {:start_position:}-{:end_position:}"])
+    hosts, names_all = [], []
+    for contigs, names in genomes:
+        keep = [i for i, c in enumerate(contigs) if c.size > 20000]
+        hosts.append(_oracle.HostGenome([contigs[i] for i in keep]))
+        names_all.append([names[i] for i in keep])
+    o = _oracle.simulate_long(oracle, hosts, [25, 25], MinimalLongErrorProfile().pod(), 7, qual_offset=33)
+    dd = o.trimmed()
+    expected = bytearray()
+    for r in range(o.n_reads):
+        g = int(dd["genome"][r])
+        a, b = int(dd["seq_off"][r]), int(dd["seq_off"][r + 1])
+        h = f"@r{int(dd['read_id'][r])} genome{g} {names_all[g][int(dd['contig'][r])]} {int(dd['start'][r])}-{int(dd['end'][r])}"
+        expected += h.encode() + b"\n" + dd["seq"][a:b].tobytes() + b"\n+\n" + dd["qual"][a:b].tobytes() + b"\n"
+    assert out.read_bytes() == bytes(expected)
+
+
+def test_cli_contiguous(workdir, oracle):
+    d, genomes = workdir
+    out = d / "contig.fq"
+    subprocess.check_call([str(EXE), "--genome", str(d / "g0.fna"), "--output", str(out), "--num-reads", "400",
+                           "--seed", "3", "--contiguous", "--read-header-format", "@{:read_id:}/{:pair:} {:sequence_id:}"])
+    contigs, _ = genomes[0]
+    whole = np.concatenate([np.concatenate([c, np.frombuffer(b"N", dtype=np.uint8)]) for c in contigs])
+    g = _oracle.HostGenome([whole], sizes=[sum(c.size for c in contigs)])
+    o = _oracle.simulate_pe(oracle, g, PerfectShortErrorProfile().pod(), 400, 3, qual_offset=33)
+    exp = fastq_of(o.trimmed(), o.n_reads, ["whole genome"], "x", True, fmt="@{:read_id:}/{:pair:} {:sequence_id:}")
+    assert out.read_bytes() == exp
