@@ -38,17 +38,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU per step")
     ap.add_argument("--genome-bases", type=int, default=100_000_000)
-    ap.add_argument("--profile", default="minimal-short", choices=["minimal-short", "perfect-short"])
+    ap.add_argument("--profile", default="minimal-short", choices=["minimal-short", "perfect-short", "minimal-long"])
+    ap.add_argument("--gamma", default="8000,6000", help="minimal-long: gamma mean,std of the read length (BASELINE config 3)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo only for rehearsing N>1 on a single GPU (all ranks then share --rehearse-device)")
+    ap.add_argument("--rehearse-device", type=int, default=None)
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    from simmr_amd import MinimalShortErrorProfile, PerfectShortErrorProfile, _abi
+    from simmr_amd import MinimalLongErrorProfile, MinimalShortErrorProfile, PerfectShortErrorProfile, _abi
     from simmr_amd.engine import Engine, Reads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -56,33 +60,56 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.rehearse_device is not None:
+        local_rank = args.rehearse_device
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     eng = Engine(local_rank)
     eng.stage_synthetic(0, [args.genome_bases], 2)  # SplitMix64(seed=2)
-    prof = (MinimalShortErrorProfile() if args.profile == "minimal-short" else PerfectShortErrorProfile()).pod()
+    long_mode = args.profile == "minimal-long"
+    if long_mode:
+        gm, gs = (float(x) for x in args.gamma.split(","))
+        prof = MinimalLongErrorProfile(gamma_mean=gm, gamma_std=gs, length_mode=_abi.LEN_PER_READ).pod()
+    else:
+        prof = (MinimalShortErrorProfile() if args.profile == "minimal-short" else PerfectShortErrorProfile()).pod()
 
     pairs_per_gpu = args.reads // 2
     total_reads = 2 * pairs_per_gpu * world  # the whole job
-    first = rank * pairs_per_gpu
+    first = rank * (2 * pairs_per_gpu if long_mode else pairs_per_gpu)
     counters_dev = torch.zeros(_abi.N_COUNTERS, dtype=torch.int64, device=eng.device)
 
+    def plan():
+        if long_mode:  # shard = range of global read indices
+            return eng.long_plan([0], [total_reads], prof, args.seed, first, 2 * pairs_per_gpu)
+        return eng.pe_plan(0, prof, total_reads, args.seed, first, pairs_per_gpu)
+
     # sizes are a deterministic function of (seed, shard): plan once to allocate
-    info = eng.pe_plan(0, prof, total_reads, args.seed, first, pairs_per_gpu)
+    info = plan()
     out = Reads.allocate(info.n_reads, info.total_bases, eng.device, qual_offset=33)
 
     emit_ms, plan_ms = [], []
 
     def step(record):
         eng.counters_reset()
-        eng.pe_plan(0, prof, total_reads, args.seed, first, pairs_per_gpu)
-        eng.pe_emit(0, out)  # read ids: pair 0 of the (only) genome is id 0
+        plan()
+        if long_mode:
+            eng.long_emit(0, out)
+        else:
+            eng.pe_emit(0, out)  # read ids: pair 0 of the (only) genome is id 0
         eng.counters_to(counters_dev)
-        if world > 1:
-            dist.all_reduce(counters_dev)  # the path's only collective
+        if world > 1:  # the path's only collective: RCCL over xGMI
+            if args.backend == "nccl":
+                dist.all_reduce(counters_dev)
+            else:
+                c = counters_dev.cpu()
+                dist.all_reduce(c)
+                counters_dev.copy_(c)
         if record:
             emit_ms.append(eng.last_emit_kernel_ms())
             plan_ms.append(eng.last_plan_ms())
@@ -101,7 +128,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -136,7 +163,8 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.profile} 150 bp PE, 1 genome ({args.genome_bases} bp synthetic SplitMix64 seed 2), "
+                "workload": (f"{args.profile} gamma({args.gamma}) long reads" if long_mode else f"{args.profile} 150 bp PE")
+                            + f", 1 genome ({args.genome_bases} bp synthetic SplitMix64 seed 2), "
                             f"{2 * pairs_per_gpu} reads per GPU per step, seed {args.seed}",
                 "rng": "reference StdRng streams (ChaCha12), bit-exact mode",
                 "reads_per_gpu": 2 * pairs_per_gpu,
@@ -148,7 +176,7 @@ def main():
             "plan_ms_per_step": sum(plan_ms) / max(len(plan_ms), 1),
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_emit_lanes" if args.profile == "minimal-short" else "k_emit_perfect_pe",
+                "kernel": "k_emit_perfect_pe" if args.profile == "perfect-short" else "k_emit_lanes",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -159,7 +187,7 @@ def main():
                 "note": "integer-ALU bound (ChaCha12), see DESIGN.md",
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not long_mode:
             result["cpu_baseline"] = cpu_baseline(args, prof)
         print(json.dumps(result), flush=True)
     eng.close()
@@ -178,11 +206,11 @@ def cpu_baseline(args, prof):
     cores = len(os.sched_getaffinity(0))
     n1 = min(args.cpu_sample_reads // 8, 250_000)
     t = time.perf_counter()
-    _oracle.simulate_pe(lib, genome, prof, n1, args.seed, max_len=320, threads=1)
+    _oracle.simulate_pe(lib, genome, prof, n1, args.seed, max_len=176, threads=1)
     t1 = time.perf_counter() - t
     n = args.cpu_sample_reads
     t = time.perf_counter()
-    o = _oracle.simulate_pe(lib, genome, prof, n, args.seed, max_len=320, threads=cores)
+    o = _oracle.simulate_pe(lib, genome, prof, n, args.seed, max_len=176, threads=cores)
     tn = time.perf_counter() - t
     return {
         "value": n / tn,

@@ -350,6 +350,25 @@ int run_outer(simmr_engine* e, uint64_t seed, uint64_t range, uint64_t start_slo
   return SIMMR_OK;
 }
 
+// processing order by unit length (granularity 2^shift), so the lanes of a wave finish together
+int sort_by_length(simmr_engine* e, uint64_t count, uint32_t shift) {
+  e->plan_sorted = false;
+  if (count == 0) return SIMMR_OK;
+  if (count > 0xffffffffULL) return e->fail(SIMMR_ERANGE, "more than 2^32 units in one shard");
+  if (!e->u_order.ensure(count * 4) || !e->len_hist.ensure(LBINS * 4))
+    return e->fail(SIMMR_ENOMEM, "order allocation failed");
+  HIP_TRY(e, hipMemsetAsync(e->len_hist.p, 0, LBINS * 4, e->stream));
+  const uint32_t g1 = (uint32_t)std::min<uint64_t>(grid_for(count, 256), (uint64_t)e->n_cu * 8);
+  hipLaunchKernelGGL(k_len_hist, dim3(g1), dim3(256), 0, e->stream, e->u_len.as<uint32_t>(), count, shift,
+                     e->len_hist.as<uint32_t>());
+  hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, e->stream, e->len_hist.as<uint32_t>());
+  const uint32_t g2 = (uint32_t)std::min<uint64_t>(grid_for(count, 4096), (uint64_t)e->n_cu * 8);
+  hipLaunchKernelGGL(k_len_scatter, dim3(g2), dim3(256), 0, e->stream, e->u_len.as<uint32_t>(), count, shift,
+                     e->len_hist.as<uint32_t>(), e->u_order.as<uint32_t>());
+  e->plan_sorted = true;
+  return SIMMR_OK;
+}
+
 // exclusive scan of u_bytes -> u_off (n + 1 entries); returns the total
 int scan_offsets(simmr_engine* e, uint64_t n, uint64_t* total) {
   if (!e->u_off.ensure((n + 1) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
@@ -646,21 +665,7 @@ int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profil
                        e->d_err.as<uint32_t>());
   }
   e->plan_sorted = false;
-  if (count > 0 && seeds2 && e->emit_variant == 0) {
-    // processing order by read length, so the lanes of a wave finish together
-    if (count > 0xffffffffULL) return e->fail(SIMMR_ERANGE, "more than 2^32 pairs in one shard");
-    if (!e->u_order.ensure(count * 4) || !e->len_hist.ensure(LBINS * 4))
-      return e->fail(SIMMR_ENOMEM, "order allocation failed");
-    HIP_TRY(e, hipMemsetAsync(e->len_hist.p, 0, LBINS * 4, e->stream));
-    const uint32_t g1 = (uint32_t)std::min<uint64_t>(grid_for(count, 256), (uint64_t)e->n_cu * 8);
-    hipLaunchKernelGGL(k_len_hist, dim3(g1), dim3(256), 0, e->stream, e->u_len.as<uint32_t>(), count,
-                       e->len_hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, e->stream, e->len_hist.as<uint32_t>());
-    const uint32_t g2 = (uint32_t)std::min<uint64_t>(grid_for(count, 4096), (uint64_t)e->n_cu * 8);
-    hipLaunchKernelGGL(k_len_scatter, dim3(g2), dim3(256), 0, e->stream, e->u_len.as<uint32_t>(), count,
-                       e->len_hist.as<uint32_t>(), e->u_order.as<uint32_t>());
-    e->plan_sorted = true;
-  }
+  if (seeds2 && e->emit_variant == 0 && (rc = sort_by_length(e, count, 0))) return rc;
   if ((rc = scan_offsets(e, count, &total))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;
@@ -708,17 +713,28 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       hipLaunchKernelGGL(k_emit_perfect_pe, dim3(grid), dim3(256), 0, e->stream, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, e->prof.read_length, pl, e->u_contig.as<uint32_t>(), out->seq,
                          out->qual, 60u + out->qual_offset);
-    } else if (paired && e->prof.kind == SIMMR_K_MINIMAL_SHORT && e->emit_variant == 0) {
+    } else if (e->emit_variant == 0) {
+      // lane-per-read kernel: template on (exception plane present, paired, perfect-long Phred)
+      bool exc = false;
+      if (paired) exc = e->genomes[e->plan_genome].has_exc;
+      else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
+      const bool pl_kind = e->prof.kind == SIMMR_K_PERFECT_LONG;
+      using KernT = void (*)(ProfileDev, const GenomeDev*, uint32_t, uint64_t, const uint32_t*, PlanArrays,
+                             const uint64_t*, const uint32_t*, const uint32_t*, const uint64_t*, uint8_t*, uint8_t*,
+                             uint32_t, const Tables*, unsigned long long*);
+      KernT kern;
+      if (paired) kern = exc ? k_emit_lanes<true, true, false> : k_emit_lanes<false, true, false>;
+      else if (pl_kind) kern = exc ? k_emit_lanes<true, false, true> : k_emit_lanes<false, false, true>;
+      else kern = exc ? k_emit_lanes<true, false, false> : k_emit_lanes<false, false, false>;
       int per_cu = 0;
-      const bool exc = e->genomes[e->plan_genome].has_exc;
-      auto kern = exc ? k_emit_lanes<true> : k_emit_lanes<false>;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, LANES_WG, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-      const uint64_t wgs = (2 * n_units + LANES_WG - 1) / LANES_WG;
+      const uint64_t n_tasks = paired ? 2 * n_units : n_units;
+      const uint64_t wgs = (n_tasks + LANES_WG - 1) / LANES_WG;
       const uint32_t grid = (uint32_t)std::min<uint64_t>(wgs, (uint64_t)e->n_cu * (uint64_t)per_cu);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(LANES_WG), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, e->plan_sorted ? e->u_order.as<uint32_t>() : (const uint32_t*)nullptr,
-                         pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(), out->seq,
-                         out->qual, out->qual_offset, e->d_tables.as<Tables>(), counters);
+                         pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(),
+                         out->seq, out->qual, out->qual_offset, e->d_tables.as<Tables>(), counters);
     } else {
       hipLaunchKernelGGL(k_emit_stream, dim3(stream_grid(e, n_units)), dim3(64), 0, e->stream, e->prof,
                          paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl,
@@ -851,6 +867,8 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
                          e->d_tables.as<Tables>(), e->d_err.as<uint32_t>());
     }
   }
+  e->plan_sorted = false;
+  if (e->emit_variant == 0 && (rc = sort_by_length(e, count, 6))) return rc;
   if ((rc = scan_offsets(e, count, &total))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;

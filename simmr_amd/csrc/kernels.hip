@@ -1029,12 +1029,12 @@ k_emit_stream(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #define LBINS 1024u
 
 extern "C" __global__ void __launch_bounds__(256)
-k_len_hist(const uint32_t* __restrict__ len, uint64_t n, uint32_t* __restrict__ hist) {
+k_len_hist(const uint32_t* __restrict__ len, uint64_t n, uint32_t shift, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[LBINS];
   for (uint32_t i = threadIdx.x; i < LBINS; i += 256) h[i] = 0;
   __syncthreads();
   for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) {
-    uint32_t L = len[k];
+    uint32_t L = len[k] >> shift;
     atomicAdd(&h[L < LBINS ? L : LBINS - 1], 1u);
   }
   __syncthreads();
@@ -1056,7 +1056,7 @@ k_len_scan(uint32_t* __restrict__ hist_cursor) {
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-k_len_scatter(const uint32_t* __restrict__ len, uint64_t n, uint32_t* __restrict__ cursor,
+k_len_scatter(const uint32_t* __restrict__ len, uint64_t n, uint32_t shift, uint32_t* __restrict__ cursor,
               uint32_t* __restrict__ order) {
   __shared__ uint32_t h[LBINS];
   __shared__ uint32_t base[LBINS];
@@ -1070,7 +1070,7 @@ k_len_scatter(const uint32_t* __restrict__ len, uint64_t n, uint32_t* __restrict
       uint64_t k = start + (uint64_t)i * 256 + threadIdx.x;
       bin[i] = 0xffffffffu;
       if (k < n) {
-        uint32_t L = len[k];
+        uint32_t L = len[k] >> shift;
         bin[i] = L < LBINS ? L : LBINS - 1;
         rank[i] = atomicAdd(&h[bin[i]], 1u);
       }
@@ -1203,14 +1203,19 @@ __device__ __attribute__((noinline)) bool tail_try(double x_, double y_, double 
   return true;
 }
 
-SIMMR_DEV void q_emit(LaneQ& s, double x, const ProfileDev& prof, const OutRing& ring, uint32_t qoff) {
-  // minimal_short.rs:90-101: floor(Normal<f32>(mean, 10).sample()) as u8
-  const uint32_t q = sat_u8_f32(floorf(__fadd_rn(prof.mean_phred_f, __fmul_rn(10.0f, (float)x))));
+template <bool PL>
+SIMMR_DEV void q_emit(LaneQ& s, double x, const ProfileDev& prof, const Tables* __restrict__ T,
+                      const OutRing& ring, uint32_t qoff) {
+  // minimal_short.rs:90-101 / minimal_long.rs:88-98: floor(Normal<f32>(mean, 10).sample()) as u8;
+  // perfect_long.rs:68-77 through the threshold table (phred_of_z)
+  const uint32_t q = PL ? phred_of_z(prof, T, x)
+                        : sat_u8_f32(floorf(__fadd_rn(prof.mean_phred_f, __fmul_rn(10.0f, (float)x))));
   s.qsum += q;
   ring_put(ring, s.i, q + qoff);
   s.i++;
 }
 
+template <bool PL>
 SIMMR_DEV void q_step(LaneQ& s, uint64_t bits, const double2* __restrict__ zx2,
                       const float2* __restrict__ zf2f, const Tables* __restrict__ T,
                       const ProfileDev& prof, const OutRing& ring, uint32_t qoff) {
@@ -1220,7 +1225,7 @@ SIMMR_DEV void q_step(LaneQ& s, uint64_t bits, const double2* __restrict__ zx2,
     const double2 X = zx2[zi];
     const double x = __dmul_rn(u, X.x);
     if (fabs(x) < X.y) {
-      q_emit(s, x, prof, ring, qoff);
+      q_emit<PL>(s, x, prof, T, ring, qoff);
     } else if (zi == 0) {
       s.st = 2; s.px = u;
     } else {
@@ -1240,14 +1245,14 @@ SIMMR_DEV void q_step(LaneQ& s, uint64_t bits, const double2* __restrict__ zx2,
     else if (tf > pf * (1.0f + 1e-4f)) accept = false;
     else accept = wedge_f64(T, s.pidx, s.px, bits);
     s.st = 0;
-    if (accept) q_emit(s, s.px, prof, ring, qoff);
+    if (accept) q_emit<PL>(s, s.px, prof, T, ring, qoff);
   } else if (s.st == 2) {
     s.tx = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ULL)) - (1.0 - 2.220446049250313e-16 / 2.0);
     s.st = 3;
   } else {
     const double y_ = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ULL)) - (1.0 - 2.220446049250313e-16 / 2.0);
     double x;
-    if (tail_try(s.tx, y_, s.px, &x)) { s.st = 0; q_emit(s, x, prof, ring, qoff); }
+    if (tail_try(s.tx, y_, s.px, &x)) { s.st = 0; q_emit<PL>(s, x, prof, T, ring, qoff); }
     else s.st = 2;
   }
 }
@@ -1286,7 +1291,8 @@ SIMMR_DEV uint64_t load_q8(const uint8_t* __restrict__ qsrc, uint32_t i, uint32_
 }
 
 template <bool HAS_EXC>
-SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const GenomeDev& G, uint64_t src,
+SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const uint32_t* __restrict__ packed,
+                      const uint32_t* __restrict__ mask, uint64_t src,
                       const uint32_t* __restrict__ thr, const uint8_t* __restrict__ qsrc, uint32_t qoff,
                       const OutRing& ring) {
   if (s.st == 0) {
@@ -1295,8 +1301,8 @@ SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const Geno
     if ((i & 7u) == 0) { s.qreg = s.qnext; s.qnext = load_q8(qsrc, i + 8, L); }
     if ((i & 15u) == 0) {
       s.creg = s.cnext;
-      s.cnext = fetch_codes16(G.packed, (int64_t)(src + i + 16));
-      if (HAS_EXC) { s.ereg = s.enext; s.enext = fetch_mask16(G.mask, (int64_t)(src + i + 16)); }
+      s.cnext = fetch_codes16(packed, (int64_t)(src + i + 16));
+      if (HAS_EXC) { s.ereg = s.enext; s.enext = mask ? fetch_mask16(mask, (int64_t)(src + i + 16)) : 0u; }
     }
     const uint32_t q = ((uint32_t)(s.qreg >> (8 * (i & 7u))) - qoff) & 0xffu;
     uint32_t code = (s.creg >> (2 * (i & 15u))) & 3u;
@@ -1326,11 +1332,12 @@ SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const Geno
 }
 
 #define LANES_WG 512
-template <bool HAS_EXC>
+template <bool HAS_EXC, bool PAIRED, bool PL>
 __global__ void __launch_bounds__(LANES_WG)
 k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
              const uint32_t* __restrict__ order, PlanArrays pl, const uint64_t* __restrict__ u_off,
-             const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
+             const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
+             const uint64_t* __restrict__ u_seed,
              uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_offset,
              const Tables* __restrict__ T, unsigned long long* __restrict__ counters) {
   __shared__ double2 zx2[256];
@@ -1345,8 +1352,7 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
   }
   __syncthreads();
   uint8_t* my_ring = rings + threadIdx.x * RING_PITCH;
-  const GenomeDev G = genomes[genome];
-  const uint64_t n_tasks = 2 * n_units;
+  const uint64_t n_tasks = PAIRED ? 2 * n_units : n_units;
   uint64_t qsum_tot = 0;
   uint32_t subst_tot = 0, acgt_tot = 0;
   const uint64_t stride = (uint64_t)gridDim.x * LANES_WG;
@@ -1355,13 +1361,20 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
     const bool live = task < n_tasks;
     uint32_t L = 0, rev = 0;
     uint64_t seed_q = 0, seed_m = 0, src = 0, off = 0;
+    const uint32_t* packed = nullptr;
+    const uint32_t* mask = nullptr;
     if (live) {
-      const uint64_t u = order ? (uint64_t)order[task >> 1] : (task >> 1);
-      rev = (uint32_t)(task & 1u);
+      const uint64_t ti = PAIRED ? (task >> 1) : task;
+      // longest first: the tail of the grid-stride loop then holds the shortest reads
+      const uint64_t u = order ? (uint64_t)order[n_units - 1 - ti] : ti;
+      rev = PAIRED ? (uint32_t)(task & 1u) : 0u;
       L = pl.len[u];
       off = u_off[u] + (rev ? L : 0u);
+      const GenomeDev G = genomes[PAIRED ? genome : u_genome[u]];
+      packed = G.packed;
+      mask = G.mask;
       src = G.contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]);
-      seed_q = rev ? pl.qs2[u] : u_seed[u];
+      seed_q = rev ? pl.qs2[u] : u_seed[u];  // long reads re-seed everything with read_seed (simulate.rs:497-503)
       seed_m = rev ? pl.ms2[u] : u_seed[u];
     }
     // ---- phase Q: simulate_phred_scores (minimal_short.rs:83-102)
@@ -1376,7 +1389,7 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
         chacha12_block(key, blk, w);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          if (s.i < L) q_step(s, ((uint64_t)w[2 * j + 1] << 32) | w[2 * j], zx2, zf2f, T, prof, ring, qual_offset);
+          if (s.i < L) q_step<PL>(s, ((uint64_t)w[2 * j + 1] << 32) | w[2 * j], zx2, zf2f, T, prof, ring, qual_offset);
         }
         ring_flush_fwd(ring, s.i);
       }
@@ -1391,14 +1404,14 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
       OutRing ring;
       ring_init(ring, my_ring, seq + off, L, rev != 0);
       s.qnext = load_q8(qsrc, 0, L);
-      s.cnext = fetch_codes16(G.packed, (int64_t)src);
-      s.enext = HAS_EXC ? fetch_mask16(G.mask, (int64_t)src) : 0u;
+      s.cnext = live ? fetch_codes16(packed, (int64_t)src) : 0u;
+      s.enext = (HAS_EXC && mask) ? fetch_mask16(mask, (int64_t)src) : 0u;
       for (uint32_t blk = 0; __any(s.i < L); blk++) {
         uint32_t w[16];
         chacha12_block(key, blk, w);
 #pragma unroll
         for (int j = 0; j < 16; j++)
-          if (s.i < L) m_step<HAS_EXC>(s, w[j], L, rev, G, src, thr, qsrc, qual_offset, ring);
+          if (s.i < L) m_step<HAS_EXC>(s, w[j], L, rev, packed, mask, src, thr, qsrc, qual_offset, ring);
         if (rev) ring_flush_rev(ring, L - s.i); else ring_flush_fwd(ring, s.i);
       }
       subst_tot += s.n_subst;

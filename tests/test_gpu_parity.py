@@ -145,6 +145,22 @@ def test_minimal_short_wave_per_pair_variant(oracle, genome_1m, monkeypatch):
         e2.close()
 
 
+def test_long_wave_per_read_variant(oracle, genome_multi, monkeypatch):
+    """k_emit_stream (wave per read, LDS windows) stays covered for long reads."""
+    from simmr_amd.engine import Engine
+    monkeypatch.setenv("SIMMR_EMIT_VARIANT", "1")
+    e2 = Engine(0)
+    try:
+        e2.stage_genome(0, genome_multi.contigs)
+        for prof in (MinimalLongErrorProfile().pod(),
+                     PerfectLongErrorProfile(gamma_mean=3000.0, gamma_std=2500.0, length_mode=_abi.LEN_PER_READ).pod()):
+            dev = e2.simulate_long_reads([0], [40], prof, 21)
+            ora = _oracle.simulate_long(oracle, [genome_multi], [40], prof, 21)
+            assert_same(dev.to_host(), ora.trimmed())
+    finally:
+        e2.close()
+
+
 def test_minimal_short_exceptions(engine, oracle):
     rng = np.random.default_rng(12)
     seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 20000)].copy()
