@@ -149,6 +149,55 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
                             uint32_t read_id_base, const simmr_reads_out* out,
                             uint64_t* total_bases, uint32_t* const_len, int threads);
 
+/* ---------------- custom (empirical) profile: custom_short.rs + its crates (custom.c) */
+typedef struct orc_uniform_u32 { uint32_t low, range, z; } orc_uniform_u32;
+typedef struct orc_uniform_f64 { double low, scale; } orc_uniform_f64;
+typedef struct orc_alias {
+  uint32_t n;
+  double* odds;       /* no_alias_odds */
+  uint32_t* aliases;
+  orc_uniform_u32 uniform_index;
+  orc_uniform_f64 uniform_weight;
+} orc_alias;
+typedef struct orc_bins {
+  uint64_t num_bins, bin_width, n_density, n_ranges;
+  double* density;
+  uint32_t *range_lo, *range_hi;
+} orc_bins;
+typedef struct orc_model { /* shared/src/encoding.rs:102-117 ErrorModelParams */
+  uint64_t bin_size, n_quality;
+  orc_bins* quality;
+  uint8_t bit_encoding;
+  uint64_t kmer_size, n_prob;
+  uint32_t* prob_kmer; uint64_t* prob_n; uint32_t** prob_alt; float** prob_w;
+  double insert_size_mean, insert_size_std;
+  uint8_t has_insert_bins;
+  orc_bins insert_bins;
+  double read_length_mean, read_length_std;
+  orc_bins read_length_bins;
+  uint8_t is_long;
+} orc_model;
+typedef struct orc_pdf { orc_alias alias; uint32_t n_bins; orc_uniform_u32* bins; } orc_pdf;
+
+void orc_uniform_u32_new_inclusive(uint32_t low, uint32_t high, orc_uniform_u32* u);
+uint32_t orc_uniform_u32_sample(const orc_uniform_u32* u, orc_rng* r);
+void orc_uniform_f64_new(double low, double high, orc_uniform_f64* u);
+double orc_uniform_f64_sample(const orc_uniform_f64* u, orc_rng* r);
+int orc_alias_new(const double* weights, uint32_t n, orc_alias* a);
+void orc_alias_free(orc_alias* a);
+uint32_t orc_alias_sample(const orc_alias* a, orc_rng* r);
+int orc_model_parse(const uint8_t* bytes, uint64_t n, orc_model* m);
+int orc_pdf_new(const orc_bins* b, orc_pdf* p);
+int orc_pdf_sample(const orc_pdf* p, uint64_t seed, uint32_t* out);
+typedef struct orc_custom orc_custom;
+orc_custom* orc_custom_new(const uint8_t* bytes, uint64_t n);
+const orc_model* orc_custom_model(const orc_custom* c);
+int orc_custom_get_read_length(const orc_custom* c, uint64_t seed, uint16_t* out);
+int orc_custom_get_insert_size(const orc_custom* c, uint64_t seed, uint16_t* out);
+uint16_t orc_custom_minimum_genome_size(const orc_custom* c);
+int orc_custom_simulate_phred_scores(const orc_custom* c, uint64_t len, uint64_t seed, uint8_t* out);
+int64_t orc_custom_simulate_errors(const orc_model* m, const uint8_t* seq, uint64_t len, uint64_t seed, uint8_t* out);
+
 /* counters over a finished SoA (same definitions as enum simmr_counter where
  * derivable from outputs + the packed reference) */
 const char* orc_last_error(void);

@@ -107,8 +107,30 @@ uint64_t orc_per_read_seed(uint64_t seed, uint64_t read_index) {
 
 /* ------------------------------------------------------- ErrorProfile impls */
 
+/* CustomShortErrorProfile objects are built once per model buffer (cli.rs:255-272) */
+static orc_custom* custom_of(const simmr_error_profile* p) {
+  /* keyed by the model CONTENT (FNV-1a), not by the caller's buffer address */
+  static uint64_t key_hash[8], key_n[8];
+  static orc_custom* val[8];
+  static int used = 0;
+  orc_custom* r = NULL;
+  uint64_t h = 1469598103934665603ULL;
+  const uint8_t* b = (const uint8_t*)p->custom_model;
+  for (uint64_t i = 0; i < p->custom_model_bytes; i++) { h ^= b[i]; h *= 1099511628211ULL; }
+#pragma omp critical(orc_custom_cache)
+  {
+    for (int i = 0; i < used; i++) if (key_hash[i] == h && key_n[i] == p->custom_model_bytes) r = val[i];
+    if (!r) {
+      r = orc_custom_new(b, p->custom_model_bytes);
+      if (r) { int slot = used < 8 ? used++ : 7; key_hash[slot] = h; key_n[slot] = p->custom_model_bytes; val[slot] = r; }
+    }
+  }
+  return r;
+}
+
 int orc_profile_is_long_read(const simmr_error_profile* p) {
-  /* perfect_short.rs:61, minimal_short.rs:147, perfect_long.rs:133, minimal_long.rs:156 */
+  /* perfect_short.rs:61, minimal_short.rs:147, perfect_long.rs:133, minimal_long.rs:156, custom_short.rs:540-542 */
+  if (p->kind == SIMMR_CUSTOM) { orc_custom* c = custom_of(p); return c ? orc_custom_model(c)->is_long : 0; }
   return p->kind == SIMMR_PERFECT_LONG || p->kind == SIMMR_MINIMAL_LONG;
 }
 
@@ -124,6 +146,12 @@ int orc_profile_minimum_genome_size(const simmr_error_profile* p, uint16_t* out)
     case SIMMR_MINIMAL_LONG:
       *out = 20000;
       return 0;
+    case SIMMR_CUSTOM: {
+      orc_custom* c = custom_of(p);
+      if (!c) FAIL(SIMMR_EINVAL, "cannot parse the custom model");
+      *out = orc_custom_minimum_genome_size(c);
+      return 0;
+    }
     default: FAIL(SIMMR_EINVAL, "profile kind %u not restated", p->kind);
   }
 }
@@ -147,6 +175,11 @@ int orc_profile_get_read_length(const simmr_error_profile* p, uint64_t seed, uin
     }
     case SIMMR_PERFECT_LONG: *out = 20000; return 0;            /* perfect_long.rs:32-34 */
     case SIMMR_MINIMAL_LONG: return gamma_length(p, seed, out); /* minimal_long.rs:37-53 */
+    case SIMMR_CUSTOM: {                                         /* custom_short.rs:237-244 */
+      orc_custom* c = custom_of(p);
+      if (!c || orc_custom_get_read_length(c, seed, out)) FAIL(SIMMR_EINVAL, "custom read-length PDF failed");
+      return 0;
+    }
     default: FAIL(SIMMR_EINVAL, "profile kind %u not restated", p->kind);
   }
 }
@@ -167,6 +200,11 @@ int orc_profile_get_insert_size(const simmr_error_profile* p, uint64_t seed, uin
     case SIMMR_MINIMAL_SHORT: {                                 /* minimal_short.rs:58-67 */
       orc_rng r; orc_rng_seed_from_u64(&r, seed);
       *out = sat_u16_f64(floor(orc_normal_f64(&r, (double)p->insert_size, p->insert_size_std)));
+      return 0;
+    }
+    case SIMMR_CUSTOM: {                                         /* custom_short.rs:263-270 */
+      orc_custom* c = custom_of(p);
+      if (!c || orc_custom_get_insert_size(c, seed, out)) FAIL(SIMMR_EINVAL, "custom insert-size PDF failed");
       return 0;
     }
     default: FAIL(SIMMR_EINVAL, "get_insert_size() panics for long-read profiles"); /* minimal_long.rs:29-31 */
@@ -196,6 +234,11 @@ int orc_profile_simulate_phred_scores(const simmr_error_profile* p, uint64_t len
       }
       return 0;
     }
+    case SIMMR_CUSTOM: {                                         /* custom_short.rs:332-353 */
+      orc_custom* c = custom_of(p);
+      if (!c || orc_custom_simulate_phred_scores(c, len, seed, out)) FAIL(SIMMR_EINVAL, "custom quality PDF failed");
+      return 0;
+    }
     default: FAIL(SIMMR_EINVAL, "profile kind %u not restated", p->kind);
   }
 }
@@ -203,7 +246,7 @@ int orc_profile_simulate_phred_scores(const simmr_error_profile* p, uint64_t len
 int orc_profile_simulate_point_mutations(const simmr_error_profile* p, const uint8_t* seq,
                                          const uint8_t* qual, uint64_t len, uint64_t seed,
                                          uint8_t* out) {
-  if (p->kind == SIMMR_PERFECT_SHORT) { /* perfect_short.rs:46-54 */
+  if (p->kind == SIMMR_PERFECT_SHORT || p->kind == SIMMR_CUSTOM) { /* perfect_short.rs:46-54, custom_short.rs:522-529 */
     memmove(out, seq, len);
     return 0;
   }
@@ -361,6 +404,7 @@ static int pe_emit_pair(const orc_genome* g, const simmr_error_profile* p, uint3
     for (uint64_t i = 0; i < 2 * L; i++) o->qual[o1 + i] = (uint8_t)(o->qual[o1 + i] + o->qual_offset);
   uint8_t f2 = pl->flags2;
   if (p->kind == SIMMR_PERFECT_SHORT) f2 &= (uint8_t)~(SIMMR_FLAG_QSEED_SUBST | SIMMR_FLAG_MSEED_SUBST);
+  if (p->kind == SIMMR_CUSTOM) f2 &= (uint8_t)~SIMMR_FLAG_MSEED_SUBST; /* the mutation seed is drawn but unused */
   put_meta(o, 2 * k, pl->fwd_start, pl->fwd_end, contig, 0, id, 0);              /* :287-292 */
   put_meta(o, 2 * k + 1, pl->rev_start, pl->rev_end, contig, 0, id, f2);          /* :293-298 */
   return 0;

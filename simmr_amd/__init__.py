@@ -6,13 +6,13 @@ mirror of the reference's plug-in surface plus ctypes plumbing.
 """
 from . import _abi
 from ._abi import SimmrError
-from .profiles import (AbundanceProfile, CustomAbundanceProfile, ErrorProfile, ExactAbundanceProfile,
+from .profiles import (AbundanceProfile, CustomAbundanceProfile, CustomShortErrorProfile, ErrorProfile, ExactAbundanceProfile,
                        MinimalLongErrorProfile, MinimalShortErrorProfile, PerfectLongErrorProfile,
                        PerfectShortErrorProfile, UniformAbundanceProfile)
 
 __all__ = ["_abi", "SimmrError", "Engine", "Reads", "ErrorProfile", "AbundanceProfile",
            "PerfectShortErrorProfile", "MinimalShortErrorProfile", "PerfectLongErrorProfile",
-           "MinimalLongErrorProfile", "UniformAbundanceProfile", "ExactAbundanceProfile",
+           "MinimalLongErrorProfile", "CustomShortErrorProfile", "UniformAbundanceProfile", "ExactAbundanceProfile",
            "CustomAbundanceProfile"]
 
 

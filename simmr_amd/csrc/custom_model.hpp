@@ -1,0 +1,169 @@
+// custom_model.hpp — host side of the custom (empirical) error profile:
+// reads the bincode `ErrorModelParams` a simmrd run writes
+// (shared/src/encoding.rs:82-117,244-281) and builds, exactly as the reference
+// does at start-up (CustomPDF::new, custom_short.rs:60-86), the alias tables
+// (rand_distr 0.4.3 WeightedAliasIndex<f64>::new) and per-bin uniform samplers
+// (rand 0.8.5 Uniform<u32>::new_inclusive) in the flat form the kernels read.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "device_types.hpp"
+
+namespace simmr {
+
+struct BinsHost {
+  uint64_t num_bins = 0, bin_width = 0;
+  std::vector<double> density;
+  std::vector<std::pair<uint32_t, uint32_t>> ranges;
+};
+
+struct ModelHost {
+  uint64_t bin_size = 0;
+  std::vector<BinsHost> quality;
+  uint8_t bit_encoding = 0;
+  uint64_t kmer_size = 0;
+  std::vector<std::pair<uint32_t, std::vector<std::pair<uint32_t, float>>>> probabilities;
+  double insert_size_mean = 0, insert_size_std = 0;
+  bool has_insert_bins = false;
+  BinsHost insert_bins;
+  double read_length_mean = 0, read_length_std = 0;
+  BinsHost read_length_bins;
+  bool is_long = false;
+};
+
+class BincodeReader {
+ public:
+  BincodeReader(const uint8_t* p, uint64_t n) : p_(p), n_(n) {}
+  bool ok() const { return !bad_; }
+  bool at_end() const { return pos_ == n_; }
+  uint64_t u64() { uint64_t v = 0; take(&v, 8); return v; }
+  uint32_t u32() { uint32_t v = 0; take(&v, 4); return v; }
+  uint8_t u8() { uint8_t v = 0; take(&v, 1); return v; }
+  double f64() { double v = 0; take(&v, 8); return v; }
+  float f32() { float v = 0; take(&v, 4); return v; }
+  uint64_t len(uint64_t elem_bytes) {  // Vec length, checked against what is left
+    uint64_t v = u64();
+    if (bad_ || v > (n_ - pos_) / (elem_bytes ? elem_bytes : 1)) { bad_ = true; return 0; }
+    return v;
+  }
+ private:
+  void take(void* dst, uint64_t k) {
+    if (bad_ || pos_ + k > n_) { bad_ = true; return; }
+    memcpy(dst, p_ + pos_, k);
+    pos_ += k;
+  }
+  const uint8_t* p_;
+  uint64_t n_, pos_ = 0;
+  bool bad_ = false;
+};
+
+inline bool read_bins(BincodeReader& r, BinsHost* b) {
+  b->num_bins = r.u64();
+  b->bin_width = r.u64();
+  uint64_t nd = r.len(8);
+  b->density.resize(nd);
+  for (uint64_t i = 0; i < nd; i++) b->density[i] = r.f64();
+  uint64_t nr = r.len(8);
+  b->ranges.resize(nr);
+  for (uint64_t i = 0; i < nr; i++) { b->ranges[i].first = r.u32(); b->ranges[i].second = r.u32(); }
+  return r.ok();
+}
+
+// bincode::deserialize::<ErrorModelParams>: fields in declaration order
+inline bool parse_model(const uint8_t* bytes, uint64_t n, ModelHost* m, std::string* err) {
+  BincodeReader r(bytes, n);
+  m->bin_size = r.u64();
+  uint64_t nq = r.len(32);
+  m->quality.resize(nq);
+  for (uint64_t i = 0; i < nq && r.ok(); i++) read_bins(r, &m->quality[i]);
+  m->bit_encoding = r.u8();
+  m->kmer_size = r.u64();
+  uint64_t np = r.len(12);
+  m->probabilities.resize(np);
+  for (uint64_t i = 0; i < np && r.ok(); i++) {
+    m->probabilities[i].first = r.u32();
+    uint64_t k = r.len(8);
+    m->probabilities[i].second.resize(k);
+    for (uint64_t j = 0; j < k; j++) { m->probabilities[i].second[j].first = r.u32(); m->probabilities[i].second[j].second = r.f32(); }
+  }
+  m->insert_size_mean = r.f64();
+  m->insert_size_std = r.f64();
+  m->has_insert_bins = r.u8() != 0;
+  if (m->has_insert_bins) read_bins(r, &m->insert_bins);
+  m->read_length_mean = r.f64();
+  m->read_length_std = r.f64();
+  read_bins(r, &m->read_length_bins);
+  m->is_long = r.u8() != 0;
+  if (!r.ok() || !r.at_end()) { *err = "Error parsing custom error profile: unexpected end of file or trailing bytes"; return false; }
+  return true;
+}
+
+// Flat tables for the device
+struct PdfTables {
+  std::vector<PdfDev> pdfs;
+  std::vector<double> odds;
+  std::vector<uint32_t> alias, bin_low, bin_range, bin_zone;
+};
+
+inline double pairwise_sum(const double* v, size_t n) {  // rand_distr AliasableWeight::sum for floats
+  if (n <= 32) { double s = 0.0; for (size_t i = 0; i < n; i++) s += v[i]; return s; }
+  size_t mid = n / 2;
+  return pairwise_sum(v, mid) + pairwise_sum(v + mid, n - mid);
+}
+
+// Appends one CustomPDF entry (alias table + bins); an empty Bins gives n == 0.
+inline bool append_pdf(const BinsHost& b, PdfTables* t, std::string* err) {
+  PdfDev d{};
+  const uint32_t n = (uint32_t)b.density.size();
+  d.n = n;
+  d.off = (uint32_t)t->odds.size();
+  d.off_bins = (uint32_t)t->bin_low.size();
+  d.n_bins = (uint32_t)b.ranges.size();
+  if (n > 0) {
+    double wsum = pairwise_sum(b.density.data(), n);
+    if (wsum > 1.7976931348623157e308) wsum = 1.7976931348623157e308;
+    for (double w : b.density) if (!(w >= 0.0)) { *err = "custom model: negative or NaN density (WeightedError::InvalidWeight)"; return false; }
+    if (wsum == 0.0) { *err = "custom model: all densities are zero (WeightedError::AllWeightsZero)"; return false; }
+    std::vector<double> odds(n);
+    std::vector<uint32_t> al(n, 0);
+    for (uint32_t i = 0; i < n; i++) odds[i] = b.density[i] * (double)n;
+    uint32_t smalls = 0xFFFFFFFFu, bigs = 0xFFFFFFFFu;  // the intrusive stacks of `Aliases`
+    for (uint32_t i = 0; i < n; i++) {
+      if (odds[i] < wsum) { al[i] = smalls; smalls = i; } else { al[i] = bigs; bigs = i; }
+    }
+    while (smalls != 0xFFFFFFFFu && bigs != 0xFFFFFFFFu) {
+      const uint32_t s = smalls; smalls = al[s];
+      const uint32_t g = bigs; bigs = al[g];
+      al[s] = g;
+      odds[g] = odds[g] - wsum + odds[s];
+      if (odds[g] < wsum) { al[g] = smalls; smalls = g; } else { al[g] = bigs; bigs = g; }
+    }
+    while (smalls != 0xFFFFFFFFu) { const uint32_t s = smalls; smalls = al[s]; odds[s] = wsum; }
+    while (bigs != 0xFFFFFFFFu) { const uint32_t g = bigs; bigs = al[g]; odds[g] = wsum; }
+    // Uniform::new(0u32, n) and Uniform::new(0.0, weight_sum)
+    d.idx_zone = 0xFFFFFFFFu - (uint32_t)((0x100000000ULL - n) % n);
+    uint64_t mb = (0xFFFFFFFFFFFFFFFFULL >> 12) | 0x3FF0000000000000ULL;
+    double max_rand; memcpy(&max_rand, &mb, 8); max_rand -= 1.0;
+    double scale = wsum - 0.0;
+    while (scale * max_rand + 0.0 >= wsum) { uint64_t sb; memcpy(&sb, &scale, 8); sb -= 1; memcpy(&scale, &sb, 8); }
+    d.w_scale = scale;
+    t->odds.insert(t->odds.end(), odds.begin(), odds.end());
+    t->alias.insert(t->alias.end(), al.begin(), al.end());
+  }
+  for (const auto& r : b.ranges) {  // Uniform::new_inclusive(start, end)
+    if (r.first > r.second) { *err = "custom model: bin range with start > end (Uniform::new_inclusive panics)"; return false; }
+    const uint32_t range = r.second - r.first + 1u;
+    t->bin_low.push_back(r.first);
+    t->bin_range.push_back(range);
+    t->bin_zone.push_back(range ? 0xFFFFFFFFu - (uint32_t)((0x100000000ULL - range) % range) : 0xFFFFFFFFu);
+  }
+  t->pdfs.push_back(d);
+  return true;
+}
+
+}  // namespace simmr

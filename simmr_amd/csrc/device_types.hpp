@@ -33,6 +33,31 @@ struct GenomeDev {
   uint32_t has_exc;
 };
 
+#define SIMMR_K_CUSTOM 4u
+#define SIMMR_ERRBIT_PDF 4u /* custom PDF picked a bin without a range (a reference panic) or ran out of words */
+
+// One CustomPDF entry (custom_short.rs:28-35): WeightedAliasIndex<f64> + per-bin Uniform<u32>,
+// flattened.  Built on the host exactly as rand_distr 0.4.3 / rand 0.8.5 build them.
+struct PdfDev {
+  uint32_t n;          // number of densities (alias table size)
+  uint32_t idx_zone;   // Uniform<u32>::new(0, n): zone = u32::MAX - ((2^32 - n) % n)
+  uint32_t n_bins;     // number of bin ranges
+  uint32_t off;        // offset of this PDF in odds[] / alias[]
+  uint32_t off_bins;   // offset in bin_low[] / bin_range[] / bin_zone[]
+  uint32_t pad;
+  double w_scale;      // Uniform<f64>::new(0, weight_sum).scale
+};
+struct CustomDev {
+  const PdfDev* pdfs;  // [0] read length, [1] insert size (n == 0 if absent), [2 + p] quality of position p
+  const double* odds;
+  const uint32_t* alias;
+  const uint32_t* bin_low;
+  const uint32_t* bin_range;  // 0 = full u32 range
+  const uint32_t* bin_zone;
+  uint32_t n_quality;
+  uint32_t pad;
+};
+
 // Device form of simmr_error_profile, with host-derived constants.
 struct ProfileDev {
   uint32_t kind;
@@ -44,6 +69,7 @@ struct ProfileDev {
   float pl_mean;      // perfect-long: convert_phred_to_accuracy(20)
   float gamma_shape, gamma_scale;
   double read_length_std, insert_size_std;
+  CustomDev custom;
 };
 
 struct Key8 {

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "kernels.hip"
+#include "custom_model.hpp"
 
 using namespace simmr;
 
@@ -83,6 +84,8 @@ struct simmr_engine {
   DevBuf o_last_idx, o_wg_sums, o_wg_prefix, o_result;
   // long-read runs
   DevBuf d_runs, d_usable;
+  // custom profile tables
+  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone;
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -227,11 +230,57 @@ int check_genome(simmr_engine* e, uint32_t idx) {
   return SIMMR_OK;
 }
 
+// ---- custom (empirical) profile: parse the model, build + upload the PDF tables --------
+template <class T> int upload_vec(simmr_engine* e, DevBuf& b, const std::vector<T>& v) {
+  if (!b.ensure(std::max<size_t>(v.size(), 1) * sizeof(T))) return e->fail(SIMMR_ENOMEM, "custom table allocation failed");
+  if (!v.empty()) HIP_TRY(e, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, e->stream));
+  return SIMMR_OK;
+}
+
+int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, ProfileDev* out) {
+  if (!p->custom_model || p->custom_model_bytes == 0) return e->fail(SIMMR_EINVAL, "custom profile without a model");
+  ModelHost m;
+  std::string err;
+  if (!parse_model((const uint8_t*)p->custom_model, p->custom_model_bytes, &m, &err)) return e->fail(SIMMR_EINVAL, "%s", err.c_str());
+  // main.rs:30-33: a custom-short profile must not be a long-read model; simulate_errors (the k-mer
+  // splice of long reads, custom_short.rs:455-516) is not on the paired-end path and not built here
+  if (m.is_long || want_long)
+    return e->fail(SIMMR_EINVAL, "You specified a custom short-read error profile but the provided error profile is for long reads");
+  if (m.quality.empty()) return e->fail(SIMMR_EINVAL, "custom model has no quality distributions");
+  PdfTables t;
+  if (!append_pdf(m.read_length_bins, &t, &err)) return e->fail(SIMMR_EINVAL, "%s", err.c_str());
+  if (!append_pdf(m.has_insert_bins ? m.insert_bins : BinsHost(), &t, &err)) return e->fail(SIMMR_EINVAL, "%s", err.c_str());
+  for (const BinsHost& b : m.quality) if (!append_pdf(b, &t, &err)) return e->fail(SIMMR_EINVAL, "%s", err.c_str());
+  if (t.pdfs[0].n == 0) return e->fail(SIMMR_EINVAL, "custom model has an empty read-length distribution");
+  for (size_t i = 2; i < t.pdfs.size(); i++) if (t.pdfs[i].n == 0) return e->fail(SIMMR_EINVAL, "custom model has an empty quality distribution");
+  int rc;
+  if ((rc = upload_vec(e, e->c_pdfs, t.pdfs)) || (rc = upload_vec(e, e->c_odds, t.odds)) ||
+      (rc = upload_vec(e, e->c_alias, t.alias)) || (rc = upload_vec(e, e->c_low, t.bin_low)) ||
+      (rc = upload_vec(e, e->c_range, t.bin_range)) || (rc = upload_vec(e, e->c_zone, t.bin_zone)))
+    return rc;
+  if ((rc = sync_check(e, "custom table upload"))) return rc;  // the host vectors go out of scope
+  ProfileDev d{};
+  d.kind = SIMMR_K_CUSTOM;
+  d.rng_mode = p->rng_mode;
+  // custom_short.rs:535-538: (2.0 * read_length_mean + insert_size_mean) as u16 (saturating)
+  const double req = 2.0 * m.read_length_mean + m.insert_size_mean;
+  d.required = !(req == req) || req <= 0.0 ? 0u : (req >= 65535.0 ? 65535u : (uint32_t)req);
+  d.custom.pdfs = e->c_pdfs.as<PdfDev>();
+  d.custom.odds = e->c_odds.as<double>();
+  d.custom.alias = e->c_alias.as<uint32_t>();
+  d.custom.bin_low = e->c_low.as<uint32_t>();
+  d.custom.bin_range = e->c_range.as<uint32_t>();
+  d.custom.bin_zone = e->c_zone.as<uint32_t>();
+  d.custom.n_quality = (uint32_t)m.quality.size();
+  *out = d;
+  return SIMMR_OK;
+}
+
 // ---- profile validation (cli.rs:229-301 semantics) -------------------------
 int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, ProfileDev* out) {
   if (!p) return e->fail(SIMMR_EINVAL, "profile is NULL");
-  if (p->kind > SIMMR_MINIMAL_LONG)
-    return e->fail(SIMMR_EINVAL, "profile kind %u is not implemented on the device", p->kind);
+  if (p->kind > SIMMR_CUSTOM) return e->fail(SIMMR_EINVAL, "unknown profile kind %u", p->kind);
+  if (p->kind == SIMMR_CUSTOM) return make_custom_profile(e, p, want_long, out);
   if (p->rng_mode != SIMMR_RNG_REFERENCE)
     return e->fail(SIMMR_EINVAL, "rng_mode %u is not implemented", p->rng_mode);
   const bool is_long = p->kind == SIMMR_PERFECT_LONG || p->kind == SIMMR_MINIMAL_LONG;
@@ -522,7 +571,7 @@ void simmr_engine_destroy(simmr_engine* e) {
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_bytes, &e->u_qs2,
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
-                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist};
+                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone};
   for (DevBuf* b : bufs) b->release();
   if (e->ev_a) (void)hipEventDestroy(e->ev_a);
   if (e->ev_b) (void)hipEventDestroy(e->ev_b);
@@ -665,7 +714,7 @@ int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profil
                        e->d_err.as<uint32_t>());
   }
   e->plan_sorted = false;
-  if (seeds2 && e->emit_variant == 0 && (rc = sort_by_length(e, count, 0))) return rc;
+  if (prof.kind == SIMMR_K_MINIMAL_SHORT && e->emit_variant == 0 && (rc = sort_by_length(e, count, 0))) return rc;
   if ((rc = scan_offsets(e, count, &total))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;
@@ -673,6 +722,8 @@ int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profil
   if (errw & SIMMR_ERRBIT_GENOME) return e->fail(SIMMR_EGENOME, "a sequence is smaller than the required length");
   if (errw & SIMMR_ERRBIT_SLICE)
     return e->fail(SIMMR_ERANGE, "a read would extend past its sequence (the reference panics on this slice)");
+  if (errw & SIMMR_ERRBIT_PDF)
+    return e->fail(SIMMR_ERANGE, "a custom PDF selected a density without a bin range (the reference panics: index out of bounds)");
   (void)hipEventElapsedTime(&e->last_plan_ms, e->ev_a, e->ev_b);
   e->plan_kind = PLAN_PE;
   e->prof = prof;
@@ -713,6 +764,13 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       hipLaunchKernelGGL(k_emit_perfect_pe, dim3(grid), dim3(256), 0, e->stream, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, e->prof.read_length, pl, e->u_contig.as<uint32_t>(), out->seq,
                          out->qual, 60u + out->qual_offset);
+    } else if (e->prof.kind == SIMMR_K_CUSTOM) {
+      HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 16);
+      hipLaunchKernelGGL(k_emit_custom_pe, dim3(grid), dim3(64), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
+                         e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
+                         e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset, counters,
+                         e->d_err.as<uint32_t>());
     } else if (e->emit_variant == 0) {
       // lane-per-read kernel: template on (exception plane present, paired, perfect-long Phred)
       bool exc = false;
@@ -752,6 +810,12 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
   }
   hipError_t s = hipGetLastError();
   if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "emit launch failed: %s", hipGetErrorString(s));
+  if (n_units > 0 && e->prof.kind == SIMMR_K_CUSTOM) {
+    uint32_t errw = 0;
+    if ((rc = read_err_word(e, &errw))) return rc;
+    if (errw & SIMMR_ERRBIT_PDF)
+      return e->fail(SIMMR_ERANGE, "a custom quality PDF selected a density without a bin range (the reference panics: index out of bounds)");
+  }
   return SIMMR_OK;
 }
 

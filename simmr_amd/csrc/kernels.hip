@@ -271,6 +271,56 @@ k_outer_emit(OuterParams P, uint64_t first_block, uint64_t n_blocks, uint32_t fi
 }
 
 // ===========================================================================
+// 2b. Custom (empirical) PDFs: CustomPDF::sample (custom_short.rs:108-151) =
+//     WeightedAliasIndex<f64>::sample, then Uniform<u32>::sample of the chosen bin.
+// ===========================================================================
+SIMMR_DEV uint32_t pdf_sample_lane(LaneRng& rng, const CustomDev& C, const PdfDev pdf, bool* bad) {
+  uint32_t c;
+  for (;;) {  // uniform_index.sample
+    const uint64_t m = (uint64_t)rng.next_u32() * pdf.n;
+    if ((uint32_t)m <= pdf.idx_zone) { c = (uint32_t)(m >> 32); break; }
+  }
+  const double v01 = __longlong_as_double((long long)((rng.next_u64() >> 12) | 0x3FF0000000000000ULL)) - 1.0;
+  const double x = __dmul_rn(v01, pdf.w_scale);
+  const uint32_t bin = (x < C.odds[pdf.off + c]) ? c : C.alias[pdf.off + c];
+  if (bin >= pdf.n_bins) { *bad = true; return 0; }
+  const uint32_t range = C.bin_range[pdf.off_bins + bin], low = C.bin_low[pdf.off_bins + bin];
+  if (range == 0) return rng.next_u32();
+  const uint32_t zone = C.bin_zone[pdf.off_bins + bin];
+  for (;;) {
+    const uint64_t m = (uint64_t)rng.next_u32() * range;
+    if ((uint32_t)m <= zone) return low + (uint32_t)(m >> 32);
+  }
+}
+
+// Same draw sequence, reading the words of one StdRng stream staged in LDS
+// (W[0 .. nw)); *ovf is set when the window is too short.
+SIMMR_DEV uint32_t pdf_sample_words(const uint32_t* __restrict__ W, uint32_t nw, const CustomDev& C,
+                                    const PdfDev pdf, bool* bad, bool* ovf) {
+  uint32_t k = 0, c = 0;
+  for (;;) {
+    if (k >= nw) { *ovf = true; return 0; }
+    const uint64_t m = (uint64_t)W[k++] * pdf.n;
+    if ((uint32_t)m <= pdf.idx_zone) { c = (uint32_t)(m >> 32); break; }
+  }
+  if (k + 2 > nw) { *ovf = true; return 0; }
+  const uint64_t bits = ((uint64_t)W[k + 1] << 32) | W[k];
+  k += 2;
+  const double v01 = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ULL)) - 1.0;
+  const double x = __dmul_rn(v01, pdf.w_scale);
+  const uint32_t bin = (x < C.odds[pdf.off + c]) ? c : C.alias[pdf.off + c];
+  if (bin >= pdf.n_bins) { *bad = true; return 0; }
+  const uint32_t range = C.bin_range[pdf.off_bins + bin], low = C.bin_low[pdf.off_bins + bin];
+  if (range == 0) { if (k >= nw) { *ovf = true; return 0; } return W[k]; }
+  const uint32_t zone = C.bin_zone[pdf.off_bins + bin];
+  for (;;) {
+    if (k >= nw) { *ovf = true; return 0; }
+    const uint64_t m = (uint64_t)W[k++] * range;
+    if ((uint32_t)m <= zone) return low + (uint32_t)(m >> 32);
+  }
+}
+
+// ===========================================================================
 // 3. Per-unit planning (simulate.rs:211-258 for pairs, :478-491 for long reads)
 //    One lane per unit; each lane owns a LaneRng (one ChaCha block in LDS).
 // ===========================================================================
@@ -297,6 +347,17 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
     L = sat_u16_f64(floor(__dadd_rn((double)prof.read_length, __dmul_rn(prof.read_length_std, z))));
     I = sat_u16_f64(floor(__dadd_rn((double)prof.insert_size, __dmul_rn(prof.insert_size_std, z))));
     rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);  // simulate.rs:227: fresh StdRng
+  } else if (prof.kind == SIMMR_K_CUSTOM) {
+    // custom_short.rs:237-270: each getter samples its PDF with a fresh StdRng(pe_seed), `as u16`
+    bool bad = false;
+    L = pdf_sample_lane(rng, prof.custom, prof.custom.pdfs[0], &bad) & 0xffffu;
+    I = 0;
+    if (prof.custom.pdfs[1].n) {
+      rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);
+      I = pdf_sample_lane(rng, prof.custom, prof.custom.pdfs[1], &bad) & 0xffffu;
+    }
+    if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
+    rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);
   }
   const uint64_t required = prof.required;
   if (size <= required) { atomicOr(err, SIMMR_ERRBIT_GENOME); return; }
@@ -316,6 +377,7 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
   if (rng.gen_bool()) qs = rng.next_u64(); else { qs = entropy_substitute(pe_seed, 1); flags |= SIMMR_FLAG_QSEED_SUBST; }
   if (rng.gen_bool()) ms = rng.next_u64(); else { ms = entropy_substitute(pe_seed, 2); flags |= SIMMR_FLAG_MSEED_SUBST; }
   if (prof.kind == SIMMR_K_PERFECT_SHORT) flags &= (uint8_t)~(SIMMR_FLAG_QSEED_SUBST | SIMMR_FLAG_MSEED_SUBST);
+  if (prof.kind == SIMMR_K_CUSTOM) flags &= (uint8_t)~SIMMR_FLAG_MSEED_SUBST;  // drawn but never used
   // Rust would panic on an out-of-range slice; never silently read out of bounds.
   const uint64_t len = G.contigs[u_contig[k]].len;
   if (fs + L > len || re + L > len) { atomicOr(err, SIMMR_ERRBIT_SLICE); L = 0; }
@@ -1002,6 +1064,80 @@ k_emit_stream(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   }
   if (lane == 0 && counters) {
     atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
+    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
+    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
+  }
+}
+
+// ===========================================================================
+// 7b. Emit: custom-short pairs (custom_short.rs:332-353, :522-529).
+// simulate_phred_scores re-seeds the SAME StdRng at every position, so a read's
+// qualities are functions of the first few words of one stream and of the
+// position's PDF: one wave per pair stages those words once in LDS, then every
+// lane samples its positions independently.  Bases are a plain copy (mate 2
+// reverse-complemented); simulate_errors is not on the paired-end path.
+// ===========================================================================
+#define CUSTOM_MAX_WORDS 1024u
+extern "C" __global__ void __launch_bounds__(64)
+k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
+                 PlanArrays pl, const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
+                 const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
+                 uint32_t qual_offset, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
+  __shared__ uint32_t W[2][CUSTOM_MAX_WORDS];
+  const uint32_t lane = threadIdx.x & 63u;
+  const GenomeDev G = genomes[genome];
+  const CustomDev C = prof.custom;
+  uint64_t qsum = 0;
+  uint32_t n_acgt = 0;
+  for (uint64_t k = blockIdx.x; k < n_units; k += gridDim.x) {
+    const uint32_t L = pl.len[k];
+    if (L == 0) continue;
+    const uint64_t cbase = G.contigs[u_contig[k]].base;
+    const uint64_t o1 = u_off[k], o2 = o1 + L;
+    const uint64_t seedA = u_seed[k], seedB = pl.qs2[k];
+    for (uint32_t nw = 64;; nw *= 4) {
+      __syncthreads();
+      const uint32_t nb = nw / 16;
+      for (uint32_t j = lane; j < 2 * nb; j += 64) {
+        const uint32_t st = j / nb, blk = j - st * nb;
+        const Key key = pcg32_expand(st ? seedB : seedA);
+        uint32_t o[16];
+        chacha12_block(key, blk, o);
+#pragma unroll
+        for (int i = 0; i < 16; i++) W[st][blk * 16 + i] = o[i];
+      }
+      __syncthreads();
+      bool ovf = false, bad = false;
+      for (uint32_t p = lane; p < L; p += 64) {
+        const PdfDev pdf = C.pdfs[2 + (p < C.n_quality ? p : C.n_quality - 1)];
+        const uint32_t q1 = pdf_sample_words(W[0], nw, C, pdf, &bad, &ovf) & 0xffu;  // `as u8`
+        const uint32_t q2 = pdf_sample_words(W[1], nw, C, pdf, &bad, &ovf) & 0xffu;
+        qual[o1 + p] = (uint8_t)(q1 + qual_offset);
+        qual[o2 + p] = (uint8_t)(q2 + qual_offset);
+      }
+      if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
+      if (!__any(ovf)) break;
+      if (nw * 4 > CUSTOM_MAX_WORDS) { if (lane == 0) atomicOr(err, SIMMR_ERRBIT_PDF); break; }
+    }
+    for (uint32_t p = lane; p < L; p += 64) {
+      qsum += (uint32_t)((qual[o1 + p] - qual_offset) & 0xffu) + (uint32_t)((qual[o2 + p] - qual_offset) & 0xffu);
+      const uint64_t p1 = cbase + pl.a[k] + p;           // forward mate, byte p
+      const uint64_t p2 = cbase + pl.b[k] + (L - 1 - p);  // mate 2, byte p <- slice base L-1-p (simulate.rs:283)
+      uint32_t c1 = (G.packed[p1 >> 4] >> ((p1 & 15u) * 2u)) & 3u, c2 = (G.packed[p2 >> 4] >> ((p2 & 15u) * 2u)) & 3u;
+      if (G.has_exc) {
+        c1 |= ((G.mask[p1 >> 5] >> (p1 & 31u)) & 1u) << 2;
+        c2 |= ((G.mask[p2 >> 5] >> (p2 & 31u)) & 1u) << 2;
+      }
+      n_acgt += (c1 < 4u ? 1u : 0u) + (c2 < 4u ? 1u : 0u);
+      seq[o1 + p] = (uint8_t)"ACGTN-N-"[c1];
+      seq[o2 + p] = (uint8_t)"TGCAN-N-"[c2];
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    n_acgt += __shfl_down(n_acgt, d, 64);
+    qsum += __shfl_down(qsum, d, 64);
+  }
+  if (lane == 0 && counters) {
     atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
     atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
   }

@@ -2,6 +2,8 @@
 // arithmetic).  Each function cites the reference lines it mirrors.
 #include "simmr_host.hpp"
 
+#include "../csrc/custom_model.hpp"
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -293,6 +295,31 @@ simmr_error_profile PerfectLongErrorProfile::pod() const {
   return p;
 }
 
+std::unique_ptr<CustomShortErrorProfile> CustomShortErrorProfile::from_path(const std::string& path, std::string* err) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { *err = "No such file or directory (os error 2)"; return nullptr; }
+  auto p = std::make_unique<CustomShortErrorProfile>();
+  p->model.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  simmr::ModelHost m;
+  if (!simmr::parse_model(p->model.data(), p->model.size(), &m, err)) return nullptr;
+  p->read_length_mean = m.read_length_mean;
+  p->insert_size_mean = m.insert_size_mean;
+  p->is_long = m.is_long;
+  return p;
+}
+simmr_error_profile CustomShortErrorProfile::pod() const {
+  simmr_error_profile p = zero_pod();
+  p.kind = SIMMR_CUSTOM;
+  p.custom_model = model.data();
+  p.custom_model_bytes = model.size();
+  return p;
+}
+uint16_t CustomShortErrorProfile::minimum_genome_size() const {
+  const double v = 2.0 * read_length_mean + insert_size_mean;  // `as u16` saturates
+  if (!(v == v) || v <= 0.0) return 0;
+  return v >= 65535.0 ? 65535 : (uint16_t)v;
+}
+
 // ----------------------------------------------------------- abundance profiles
 
 Abundances AbundanceProfile::adjust_for_size(const std::vector<Genome>& genomes, const Abundances& ra,
@@ -338,7 +365,7 @@ std::string usage() {
          "  --mean-phred-score <N>        Average Phred quality score [default: 30]\n"
          "  --error-profile <P>           minimal-short | minimal-long | perfect-short | perfect-long | custom-short [default: perfect-short]\n"
          "  --abundance-profile <P>       exact | uniform | custom [default: uniform]\n"
-         "  --custom-profile <FILE>       custom error profile (not implemented on the device yet)\n"
+         "  --custom-profile <FILE>       Filepath to a custom error profile (simmrd model) for custom-short\n"
          "  --with-ani <N>                [not implemented, as in the reference]\n"
          "  --read-header-format <FMT>    header template ({:genome_id:} {:read_id:} {:pair:} {:sequence_id:} ...)\n"
          "  --seed <N>                    Random seed\n"
@@ -446,9 +473,13 @@ std::unique_ptr<ErrorProfile> determine_error_profile(const CliArgs& args, std::
       if (args.per_read_lengths) p->length_mode = SIMMR_LEN_PER_READ;
       return p;
     }
-    case ErrorProfileKind::CustomShort:
-      *err = "custom-short profiles are not implemented on the device yet (DESIGN.md §6)";
-      return nullptr;
+    case ErrorProfileKind::CustomShort: {  // cli.rs:255-272
+      if (!args.custom_profile) { *err = "--custom-profile is required with --error-profile custom-short"; return nullptr; }
+      std::string e2;
+      auto p = CustomShortErrorProfile::from_path(*args.custom_profile, &e2);
+      if (!p) { *err = "Error parsing custom error profile: " + e2; return nullptr; }
+      return p;
+    }
   }
   *err = "unknown error profile";
   return nullptr;

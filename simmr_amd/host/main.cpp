@@ -60,6 +60,9 @@ static int run_main(int argc, char** argv) {
 
   std::unique_ptr<ErrorProfile> eprofile = determine_error_profile(args, &err);  // main.rs:27
   if (!eprofile) return die(err);
+  // main.rs:30-33
+  if (args.error_profile == ErrorProfileKind::CustomShort && eprofile->is_long_read())
+    return die("You specified a custom short-read error profile but the provided error profile is for long reads");
 
   info("Loading genomes");
   std::vector<Genome> genomes;

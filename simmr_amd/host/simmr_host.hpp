@@ -116,6 +116,17 @@ struct PerfectLongErrorProfile : MinimalLongErrorProfile {  // perfect_long.rs
   simmr_error_profile pod() const override;
 };
 
+struct CustomShortErrorProfile : ErrorProfile {  // custom_short.rs (model read by cli.rs:255-272)
+  std::vector<uint8_t> model;  // bincode ErrorModelParams, handed to the library as is
+  double read_length_mean = 0, insert_size_mean = 0;
+  bool is_long = false;
+  // shared/src/encoding.rs:268-281 deserialize_model_from_path
+  static std::unique_ptr<CustomShortErrorProfile> from_path(const std::string& path, std::string* err);
+  simmr_error_profile pod() const override;
+  uint16_t minimum_genome_size() const override;  // custom_short.rs:535-538
+  bool is_long_read() const override { return is_long; }
+};
+
 // --------------------------------------------------- abundance_profiles/*.rs
 using Abundances = std::vector<std::pair<uint64_t, double>>;
 class AbundanceProfile {  // abundance_profiles/base.rs:10-69

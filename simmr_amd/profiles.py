@@ -130,6 +130,29 @@ class PerfectLongErrorProfile(MinimalLongErrorProfile):
     kind = _abi.PERFECT_LONG
 
 
+class CustomShortErrorProfile(ErrorProfile):
+    """error_profiles/custom_short.rs: empirical read-length / insert-size / per-position
+    quality distributions from a simmrd model (bincode ErrorModelParams).  `model` is the
+    file's bytes; they are handed to the library, which builds the alias tables."""
+    kind = _abi.CUSTOM
+
+    def __init__(self, model: bytes):
+        import ctypes
+        self.model = bytes(model)
+        self._buf = ctypes.create_string_buffer(self.model, len(self.model))
+
+    def pod(self):
+        import ctypes
+        p = ErrorProfilePOD()
+        p.kind = self.kind
+        p.custom_model = ctypes.cast(self._buf, ctypes.c_void_p).value
+        p.custom_model_bytes = len(self.model)
+        return p
+
+    def is_long_read(self):
+        return False  # main.rs:30-33 refuses long-read models for custom-short
+
+
 # ---------------------------------------------------------------------------
 class AbundanceProfile:
     def is_size_aware(self) -> bool:

@@ -70,6 +70,23 @@ def test_cli_pe_fastq_bytes(workdir, oracle, profile, cls):
     assert meta[1] == f"genome0\t{d}/g0.fna\t1501\t50" and meta[2] == f"genome1\t{d}/g1.fna\t1501\t50"
 
 
+def test_cli_custom_short(workdir, oracle):
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    d, genomes = workdir
+    blob = _model.synthetic_short_model()
+    (d / "model.bin").write_bytes(blob)
+    out = d / "custom.fq"
+    subprocess.check_call([str(EXE), "--genome", str(d / "g1.fna"), "--output", str(out), "--num-reads", "1200",
+                           "--seed", "5", "--error-profile", "custom-short", "--custom-profile", str(d / "model.bin"),
+                           "--read-header-format", "@{:read_id:}/{:pair:} sp={:start_position:} ep={:end_position:}"])
+    contigs, names = genomes[1]
+    prof = CustomShortErrorProfile(blob)
+    o = _oracle.simulate_pe(oracle, _oracle.HostGenome(contigs), prof.pod(), 1200, 5, qual_offset=33)
+    exp = fastq_of(o.trimmed(), o.n_reads, names, "x", True, fmt="@{:read_id:}/{:pair:} sp={:start_position:} ep={:end_position:}")
+    assert out.read_bytes() == exp
+
+
 def test_cli_long_fastq_bytes(workdir, oracle):
     d, genomes = workdir
     out = d / "long.fq"

@@ -237,6 +237,44 @@ def test_long_sharding(engine, oracle, genome_multi, genome_1m):
         assert np.array_equal(d["read_id"], whole["read_id"][first:first + n])
 
 
+# custom-short (empirical PDFs): bincode model -> alias tables on both sides
+@pytest.mark.parametrize("n_positions,seed", [(120, 42), (60, 7)])
+def test_custom_short_bit_exact(engine, oracle, genome_multi, n_positions, seed):
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    prof = CustomShortErrorProfile(_model.synthetic_short_model(n_positions=n_positions, seed=seed))
+    pod = prof.pod()
+    engine.counters_reset()
+    dev = engine.simulate_pe_reads_from_genome(1, pod, 4000, seed, qual_offset=33)
+    ora = _oracle.simulate_pe(oracle, genome_multi, pod, 4000, seed, qual_offset=33)
+    assert_same(dev.to_host(), ora.trimmed())
+    d = dev.to_host()
+    lens = np.diff(d["seq_off"].astype(np.int64))
+    assert 80 <= lens.min() and lens.max() < 200 and abs(lens.mean() - 140) < 3
+    c = engine.counters()
+    assert c[_abi.CNT_SUBSTITUTIONS] == 0 and c[_abi.CNT_BASES] == dev.total_bases
+
+
+def test_custom_short_rejects_bad_models(engine, genome_multi):
+    from simmr_amd import CustomShortErrorProfile, SimmrError
+    from tests import _model
+    blob = _model.synthetic_short_model()
+    with pytest.raises(SimmrError) as ei:
+        engine.pe_plan(1, CustomShortErrorProfile(blob[:-5]).pod(), 100, 1)
+    assert ei.value.code == _abi.EINVAL
+    long_blob = _model.serialize_model([([1.0], [(30, 30)])], ([1.0], [(100, 100)]), is_long=True)
+    with pytest.raises(SimmrError) as ei:
+        engine.pe_plan(1, CustomShortErrorProfile(long_blob).pod(), 100, 1)
+    assert ei.value.code == _abi.EINVAL and "long reads" in ei.value.msg
+    # simmrd writes one density more than bin ranges (probability.rs:162-166): picking it panics
+    # in the reference (index out of bounds); here it is an error, not a silent value
+    q = [([0.0, 1.0], [(30, 30)])] * 50
+    bad = _model.serialize_model(q, ([1.0], [(100, 100)]), read_length_mean=100.0, insert_size_mean=0.0)
+    with pytest.raises(SimmrError) as ei:
+        engine.simulate_pe_reads_from_genome(1, CustomShortErrorProfile(bad).pod(), 100, 1)
+    assert ei.value.code == _abi.ERANGE
+
+
 def test_error_paths(engine, genome_multi):
     from simmr_amd import SimmrError
     with pytest.raises(SimmrError) as ei:  # contig 2 (30 017) <= 2*20000+... required

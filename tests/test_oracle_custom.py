@@ -1,0 +1,88 @@
+"""Oracle restatement of the custom (empirical) profile: bincode model reader,
+alias-table PDFs (rand_distr WeightedAliasIndex), rand Uniform samplers, and the
+reference's one unit test for the k-mer splice (custom_long.rs:300-343)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import _model, _oracle
+
+
+@pytest.fixture(scope="module")
+def lib(oracle):
+    oracle.orc_custom_new.restype = C.c_void_p
+    oracle.orc_custom_new.argtypes = [C.c_char_p, C.c_uint64]
+    oracle.orc_custom_simulate_errors.restype = C.c_int64
+    oracle.orc_custom_simulate_errors.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p]
+    oracle.orc_custom_model.restype = C.c_void_p
+    oracle.orc_custom_model.argtypes = [C.c_void_p]
+    oracle.orc_custom_get_read_length.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint16)]
+    oracle.orc_custom_get_insert_size.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint16)]
+    oracle.orc_custom_minimum_genome_size.restype = C.c_uint16
+    oracle.orc_custom_minimum_genome_size.argtypes = [C.c_void_p]
+    oracle.orc_custom_simulate_phred_scores.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    return oracle
+
+
+def test_reference_simulate_errors_unit_test(lib):
+    # custom_long.rs:300-343: 3-mer map {ACC -> CAT (1.0), ATC -> ATC, TCG -> TGT}; "ACCCG" -> "CATGT"
+    e = _model.three_bit_encode
+    probs = [(e("ACC"), [(e("ACC"), 0.0), (e("CAT"), 1.0)]), (e("ATC"), [(e("ATC"), 1.0)]), (e("TCG"), [(e("TGT"), 1.0)])]
+    blob = _model.serialize_model([([1.0], [(30, 30)])], ([1.0], [(100, 100)]), probabilities=probs, kmer_size=3)
+    c = lib.orc_custom_new(blob, len(blob))
+    assert c
+    for seed in (0, 1, 42, 2 ** 63):
+        out = C.create_string_buffer(8)
+        n = lib.orc_custom_simulate_errors(lib.orc_custom_model(c), b"ACCCG", 5, seed, out)
+        assert n == 5 and out.raw[:5] == b"CATGT"
+    # an N in the alternate k-mer is a deletion (three_bit_decode_kmer(.., skip_n = true)); the loop
+    # bound keeps using the ORIGINAL length (custom_short.rs:475), so the reference then slices out of
+    # range and panics -- the oracle reports that as -1 instead of inventing a behaviour
+    probs = [(e("ACC"), [(e("ANC"), 1.0)])]
+    blob = _model.serialize_model([([1.0], [(30, 30)])], ([1.0], [(100, 100)]), probabilities=probs, kmer_size=3)
+    c = lib.orc_custom_new(blob, len(blob))
+    out = C.create_string_buffer(8)
+    assert lib.orc_custom_simulate_errors(lib.orc_custom_model(c), b"ACCGT", 5, 9, out) == -1
+
+
+def test_model_roundtrip_and_pdfs(lib):
+    blob = _model.synthetic_short_model()
+    c = lib.orc_custom_new(blob, len(blob))
+    assert c
+    assert lib.orc_custom_new(blob[:-3], len(blob) - 3) is None  # truncated model is rejected
+    assert lib.orc_custom_minimum_genome_size(c) == 2 * 140 + 200
+    v = C.c_uint16()
+    lens, ins = [], []
+    for seed in range(4000):
+        assert lib.orc_custom_get_read_length(c, seed, C.byref(v)) == 0
+        lens.append(v.value)
+        assert lib.orc_custom_get_insert_size(c, seed, C.byref(v)) == 0
+        ins.append(v.value)
+    lens, ins = np.array(lens), np.array(ins)
+    assert 80 <= lens.min() and lens.max() < 200 and abs(lens.mean() - 140) < 2 and abs(lens.std() - 12) < 2
+    assert 40 <= ins.min() and ins.max() < 400 and abs(ins.mean() - 200) < 5
+    # per-position Phred: same seed at every position (custom_short.rs:349), position-specific PDFs,
+    # positions past the model reuse the last PDF
+    q = np.zeros(200, dtype=np.uint8)
+    means = np.zeros(200)
+    for seed in range(300):
+        assert lib.orc_custom_simulate_phred_scores(c, 200, seed, C.c_void_p(q.ctypes.data)) == 0
+        assert q.max() < 70
+        means += q
+    means /= 300
+    assert means[:10].mean() > means[100:120].mean() + 5
+    assert abs(means[125:200].mean() - means[119]) < 1.5
+
+
+def test_alias_sampler_distribution(lib):
+    w = np.array([0.05, 0.0, 0.5, 0.25, 0.2])
+    a = (C.c_uint8 * 256)()  # opaque orc_alias storage
+    assert lib.orc_alias_new(C.c_void_p(w.ctypes.data), 5, a) == 0
+    r = _oracle.Rng()
+    lib.orc_rng_seed_from_u64(C.byref(r), 11)
+    lib.orc_alias_sample.restype = C.c_uint32
+    n = 200000
+    counts = np.bincount([lib.orc_alias_sample(a, C.byref(r)) for _ in range(n)], minlength=5)
+    assert counts[1] == 0
+    assert np.abs(counts / n - w).max() < 0.005
