@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--profile", default="minimal-short", choices=["minimal-short", "perfect-short", "minimal-long"])
     ap.add_argument("--gamma", default="8000,6000", help="minimal-long: gamma mean,std of the read length (BASELINE config 3)")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--rng", default="reference", choices=["reference", "philox"],
+                    help="reference: the reference's own ChaCha12 streams (bit-exact); philox: counter mode (tolerance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -78,6 +80,8 @@ def main():
         prof = MinimalLongErrorProfile(gamma_mean=gm, gamma_std=gs, length_mode=_abi.LEN_PER_READ).pod()
     else:
         prof = (MinimalShortErrorProfile() if args.profile == "minimal-short" else PerfectShortErrorProfile()).pod()
+    if args.rng == "philox" and args.profile != "perfect-short":
+        prof.rng_mode = _abi.RNG_PHILOX
 
     pairs_per_gpu = args.reads // 2
     total_reads = 2 * pairs_per_gpu * world  # the whole job
@@ -166,7 +170,8 @@ def main():
                 "workload": (f"{args.profile} gamma({args.gamma}) long reads" if long_mode else f"{args.profile} 150 bp PE")
                             + f", 1 genome ({args.genome_bases} bp synthetic SplitMix64 seed 2), "
                             f"{2 * pairs_per_gpu} reads per GPU per step, seed {args.seed}",
-                "rng": "reference StdRng streams (ChaCha12), bit-exact mode",
+                "rng": ("reference StdRng streams (ChaCha12), bit-exact mode" if args.rng == "reference" else
+                        "Philox4x32-10 counter mode for per-base draws (tolerance parity)"),
                 "reads_per_gpu": 2 * pairs_per_gpu,
                 "sharding": "pair-index range per GPU",
             },
@@ -176,7 +181,8 @@ def main():
             "plan_ms_per_step": sum(plan_ms) / max(len(plan_ms), 1),
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_emit_perfect_pe" if args.profile == "perfect-short" else "k_emit_lanes",
+                "kernel": ("k_emit_perfect_pe" if args.profile == "perfect-short" else
+                           "k_emit_lanes" if args.rng == "reference" else "k_emit_philox"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

@@ -391,6 +391,18 @@ static int pe_emit_pair(const orc_genome* g, const simmr_error_profile* p, uint3
   uint8_t* tmp = (uint8_t*)malloc(L ? L : 1);
   if (!tmp) FAIL(SIMMR_ENOMEM, "oom");
   int rc;
+  if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_MINIMAL_SHORT) {
+    /* counter mode (philox.c): one key per read = its Phred seed */
+    orc_philox_read(p, seq + pl->fwd_start, L, pe_seed, o->qual + o1, o->seq + o1);
+    orc_philox_read(p, seq + pl->rev_end, L, pl->qseed2, o->qual + o2, tmp);
+    orc_reverse_complement(tmp, L, o->seq + o2);
+    free(tmp);
+    if (o->qual_offset)
+      for (uint64_t i = 0; i < 2 * L; i++) o->qual[o1 + i] = (uint8_t)(o->qual[o1 + i] + o->qual_offset);
+    put_meta(o, 2 * k, pl->fwd_start, pl->fwd_end, contig, 0, id, 0);
+    put_meta(o, 2 * k + 1, pl->rev_start, pl->rev_end, contig, 0, id, (uint8_t)(pl->flags2 & ~SIMMR_FLAG_MSEED_SUBST));
+    return 0;
+  }
   /* forward mate: quality :265, mutations :269 — both re-seeded with pe_seed */
   rc = orc_profile_simulate_phred_scores(p, L, pe_seed, o->qual + o1);
   if (!rc) rc = orc_profile_simulate_point_mutations(p, seq + pl->fwd_start, o->qual + o1, L, pe_seed, o->seq + o1);
@@ -599,8 +611,12 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
       int r2 = 0;
       if (u->end > G->len[u->contig]) { r2 = SIMMR_ERANGE; }
       /* :497 quality over end-start; :500 simulate_errors = copy; :503 mutations */
+      if (!r2 && p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_MINIMAL_LONG) {
+        orc_philox_read(p, G->seq[u->contig] + u->start, n, u->read_seed, out->qual + o1, out->seq + o1);
+      } else {
       if (!r2) r2 = orc_profile_simulate_phred_scores(p, n, u->read_seed, out->qual + o1);
       if (!r2) r2 = orc_profile_simulate_point_mutations(p, G->seq[u->contig] + u->start, out->qual + o1, n, u->read_seed, out->seq + o1);
+      }
       if (!r2 && out->qual_offset)
         for (uint64_t i = 0; i < n; i++) out->qual[o1 + i] = (uint8_t)(out->qual[o1 + i] + out->qual_offset);
       if (!r2) put_meta(out, (uint64_t)k, u->start, u->end, u->contig, u->genome,

@@ -85,7 +85,7 @@ struct simmr_engine {
   // long-read runs
   DevBuf d_runs, d_usable;
   // custom profile tables
-  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone;
+  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, ph_table;
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -281,8 +281,9 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
   if (!p) return e->fail(SIMMR_EINVAL, "profile is NULL");
   if (p->kind > SIMMR_CUSTOM) return e->fail(SIMMR_EINVAL, "unknown profile kind %u", p->kind);
   if (p->kind == SIMMR_CUSTOM) return make_custom_profile(e, p, want_long, out);
-  if (p->rng_mode != SIMMR_RNG_REFERENCE)
-    return e->fail(SIMMR_EINVAL, "rng_mode %u is not implemented", p->rng_mode);
+  if (p->rng_mode > SIMMR_RNG_PHILOX) return e->fail(SIMMR_EINVAL, "unknown rng_mode %u", p->rng_mode);
+  if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_PERFECT_LONG)
+    return e->fail(SIMMR_EINVAL, "SIMMR_RNG_PHILOX covers the Normal(mean, 10) Phred profiles (minimal-short, minimal-long)");
   const bool is_long = p->kind == SIMMR_PERFECT_LONG || p->kind == SIMMR_MINIMAL_LONG;
   if (is_long != want_long)
     return e->fail(SIMMR_EINVAL, want_long ? "a short-read profile was passed to the long-read path"
@@ -314,6 +315,37 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
     if (p->kind == SIMMR_MINIMAL_SHORT &&
         (!(p->read_length_std >= 0.0) || !(p->insert_size_std >= 0.0)))
       return e->fail(SIMMR_EINVAL, "negative standard deviation");
+  }
+  if (p->rng_mode == SIMMR_RNG_PHILOX && (p->kind == SIMMR_MINIMAL_SHORT || p->kind == SIMMR_MINIMAL_LONG)) {
+    // Phred alias table: P(floor(N(mean, 10)) saturated to u8 == q), Vose's method with LIFO
+    // worklists filled in increasing index order; entry = thr17 | alias << 24
+    double P[256], prev = 0.0, odds[256];
+    int alias[256], smalls[256], bigs[256], ns = 0, nb = 0;
+    for (int q = 0; q < 256; q++) {
+      const double upper = q == 255 ? 1.0 : 0.5 * erfc(-(((double)(q + 1) - (double)p->mean_phred) / 10.0) / 1.4142135623730951);
+      P[q] = upper - prev;
+      if (P[q] < 0.0) P[q] = 0.0;
+      prev = upper;
+    }
+    for (int i = 0; i < 256; i++) { odds[i] = P[i] * 256.0; alias[i] = i; }
+    for (int i = 0; i < 256; i++) { if (odds[i] < 1.0) smalls[ns++] = i; else bigs[nb++] = i; }
+    while (ns > 0 && nb > 0) {
+      const int sm = smalls[--ns], bg = bigs[--nb];
+      alias[sm] = bg;
+      odds[bg] = odds[bg] - 1.0 + odds[sm];
+      if (odds[bg] < 1.0) smalls[ns++] = bg; else bigs[nb++] = bg;
+    }
+    while (ns > 0) odds[smalls[--ns]] = 1.0;
+    while (nb > 0) odds[bigs[--nb]] = 1.0;
+    std::vector<uint32_t> table(256);
+    for (int i = 0; i < 256; i++) {
+      const double t = floor(odds[i] * 65536.0);
+      const uint32_t thr = t >= 65536.0 ? 65536u : (t <= 0.0 ? 0u : (uint32_t)t);
+      table[i] = thr | ((uint32_t)alias[i] << 24);
+    }
+    int rc = upload_vec(e, e->ph_table, table);
+    if (rc || (rc = sync_check(e, "philox table upload"))) return rc;
+    d.philox_phred = e->ph_table.as<uint32_t>();
   }
   *out = d;
   return SIMMR_OK;
@@ -571,7 +603,7 @@ void simmr_engine_destroy(simmr_engine* e) {
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_bytes, &e->u_qs2,
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
-                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone};
+                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->ph_table};
   for (DevBuf* b : bufs) b->release();
   if (e->ev_a) (void)hipEventDestroy(e->ev_a);
   if (e->ev_b) (void)hipEventDestroy(e->ev_b);
@@ -714,7 +746,9 @@ int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profil
                        e->d_err.as<uint32_t>());
   }
   e->plan_sorted = false;
-  if (prof.kind == SIMMR_K_MINIMAL_SHORT && e->emit_variant == 0 && (rc = sort_by_length(e, count, 0))) return rc;
+  if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0 &&
+      (rc = sort_by_length(e, count, 0)))
+    return rc;
   if ((rc = scan_offsets(e, count, &total))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;
@@ -764,6 +798,13 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       hipLaunchKernelGGL(k_emit_perfect_pe, dim3(grid), dim3(256), 0, e->stream, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, e->prof.read_length, pl, e->u_contig.as<uint32_t>(), out->seq,
                          out->qual, 60u + out->qual_offset);
+    } else if (e->prof.rng_mode == SIMMR_RNG_PHILOX) {
+      const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
+      hipLaunchKernelGGL(k_emit_philox, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
+                         e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
+                         e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
+                         out->qual_offset, e->d_tables.as<Tables>(), counters);
     } else if (e->prof.kind == SIMMR_K_CUSTOM) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
       const uint32_t grid = (uint32_t)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 16);
@@ -932,7 +973,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
     }
   }
   e->plan_sorted = false;
-  if (e->emit_variant == 0 && (rc = sort_by_length(e, count, 6))) return rc;
+  if (e->emit_variant == 0 && prof.rng_mode == SIMMR_RNG_REFERENCE && (rc = sort_by_length(e, count, 6))) return rc;
   if ((rc = scan_offsets(e, count, &total))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;

@@ -377,7 +377,7 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
   if (rng.gen_bool()) qs = rng.next_u64(); else { qs = entropy_substitute(pe_seed, 1); flags |= SIMMR_FLAG_QSEED_SUBST; }
   if (rng.gen_bool()) ms = rng.next_u64(); else { ms = entropy_substitute(pe_seed, 2); flags |= SIMMR_FLAG_MSEED_SUBST; }
   if (prof.kind == SIMMR_K_PERFECT_SHORT) flags &= (uint8_t)~(SIMMR_FLAG_QSEED_SUBST | SIMMR_FLAG_MSEED_SUBST);
-  if (prof.kind == SIMMR_K_CUSTOM) flags &= (uint8_t)~SIMMR_FLAG_MSEED_SUBST;  // drawn but never used
+  if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode == SIMMR_RNG_PHILOX) flags &= (uint8_t)~SIMMR_FLAG_MSEED_SUBST;  // drawn but never used
   // Rust would panic on an out-of-range slice; never silently read out of bounds.
   const uint64_t len = G.contigs[u_contig[k]].len;
   if (fs + L > len || re + L > len) { atomicOr(err, SIMMR_ERRBIT_SLICE); L = 0; }
@@ -1563,6 +1563,131 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
     atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)subst_tot);
     atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)acgt_tot);
     atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum_tot);
+  }
+}
+
+// ===========================================================================
+// 9. Emit, counter mode (SIMMR_RNG_PHILOX — the design BASELINE.json's north_star
+//    prescribes for the per-base draws; statistical parity).
+//
+// Philox4x32-10 keyed by the read's Phred seed, counter = base index / 2: no
+// draw depends on another, so the work item is simply "8 consecutive bases of
+// one read".  A workgroup takes 32 units (pairs or long reads), builds the
+// prefix of their group counts in LDS and deals the groups to its 256 lanes:
+// consecutive lanes hold consecutive groups, so the 8-byte quality and base
+// stores of a wave coalesce into 512 contiguous bytes.
+// ===========================================================================
+SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  uint32_t c1 = 0u, c2 = 0x73696D6Du, c3 = 0x72000001u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint32_t h0 = __umulhi(M0, c0), l0 = M0 * c0, h1 = __umulhi(M1, c2), l1 = M1 * c2;
+    c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+#define PHILOX_UNITS 32u
+extern "C" __global__ void __launch_bounds__(256)
+k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
+              uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
+              const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
+              const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
+              uint32_t qual_offset, const Tables* __restrict__ T, unsigned long long* __restrict__ counters) {
+  __shared__ uint32_t ptab[256];  // Phred alias table
+  __shared__ uint32_t thr[256];   // substitution thresholds
+  __shared__ uint32_t gpre[PHILOX_UNITS + 1];
+  __shared__ uint64_t lds4[4];
+  ptab[threadIdx.x] = prof.philox_phred[threadIdx.x];
+  thr[threadIdx.x] = (uint32_t)floorf(T->acc[threadIdx.x] * 16777216.0f);
+  uint64_t qsum = 0;
+  uint32_t n_subst = 0, n_acgt = 0;
+  const uint64_t n_blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t u0 = blk * PHILOX_UNITS;
+    const uint32_t nu = (n_units - u0) < PHILOX_UNITS ? (uint32_t)(n_units - u0) : PHILOX_UNITS;
+    __syncthreads();
+    {  // groups per unit -> exclusive prefix
+      uint64_t g = 0;
+      if (threadIdx.x < nu) {
+        const uint32_t L = pl.len[u0 + threadIdx.x];
+        g = (uint64_t)((L + 7u) >> 3) * (paired ? 2u : 1u);
+      }
+      uint64_t tot;
+      const uint64_t ex = wg_exclusive_scan_u64(g, lds4, &tot);
+      if (threadIdx.x < nu) gpre[threadIdx.x] = (uint32_t)ex;
+      if (threadIdx.x == 0) gpre[nu] = (uint32_t)tot;
+    }
+    __syncthreads();
+    const uint32_t n_items = gpre[nu];
+    for (uint32_t item = threadIdx.x; item < n_items; item += 256) {
+      // unit of this item: last u with gpre[u] <= item
+      uint32_t lo = 0, hi = nu;
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gpre[mid] <= item) lo = mid; else hi = mid; }
+      const uint64_t u = u0 + lo;
+      const uint32_t L = pl.len[u];
+      const uint32_t gpm = (L + 7u) >> 3;  // groups per mate
+      uint32_t g = item - gpre[lo];
+      const uint32_t rev = (paired && g >= gpm) ? 1u : 0u;
+      if (rev) g -= gpm;
+      const uint32_t b0 = g << 3;
+      const uint32_t n = (L - b0) < 8u ? (L - b0) : 8u;
+      const GenomeDev G = genomes[u_genome ? u_genome[u] : genome_const];
+      const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
+      const uint64_t off = u_off[u] + (rev ? L : 0u);
+      const uint64_t src = G.contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]) + b0;
+      const uint32_t codes = fetch_codes16(G.packed, (int64_t)src);
+      const uint32_t exc = G.has_exc ? fetch_mask16(G.mask, (int64_t)src) : 0u;
+      uint64_t qbytes = 0, sbytes = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        uint32_t w[4];
+        philox4x32_10((b0 >> 1) + (uint32_t)c, (uint32_t)key, (uint32_t)(key >> 32), w);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int j = 2 * c + h;  // base b0 + j
+          const uint32_t A = w[2 * h], B = w[2 * h + 1];
+          const uint32_t e = ptab[A >> 24];
+          const uint32_t q = (((A >> 8) & 0xffffu) < (e & 0x1ffffu)) ? (A >> 24) : (e >> 24);
+          uint32_t code = (codes >> (2 * j)) & 3u;
+          const uint32_t x = (exc >> j) & 1u;
+          const bool live = (uint32_t)j < n;
+          if (live) { qsum += q; n_acgt += x ? 0u : 1u; }
+          if ((B >> 8) > thr[q] && !x) {
+            const uint32_t k = (((((A & 0xffu) << 8) | (B & 0xffu)) * 3u) >> 16);
+            code = k + (k >= code ? 1u : 0u);
+            if (live) n_subst++;
+          }
+          const uint32_t lut = rev ? 0x41434754u : 0x54474341u;  // "TGCA" / "ACGT"
+          const uint32_t ch = x ? ((code & 1u) ? '-' : 'N') : ((lut >> (8 * code)) & 0xffu);
+          if (live) {
+            qbytes |= (uint64_t)((q + qual_offset) & 0xffu) << (8 * j);
+            // mate 2 is reverse-complemented after mutation: base b0+j -> byte L-1-(b0+j)
+            sbytes |= (uint64_t)ch << (8 * (rev ? (n - 1u - (uint32_t)j) : (uint32_t)j));
+          }
+        }
+      }
+      uint8_t* qd = qual + off + b0;
+      uint8_t* sd = seq + off + (rev ? (L - b0 - n) : b0);
+      if (n == 8u) {
+        *reinterpret_cast<u64_unaligned*>(qd) = qbytes;
+        *reinterpret_cast<u64_unaligned*>(sd) = sbytes;
+      } else {
+        for (uint32_t i = 0; i < n; i++) { qd[i] = (uint8_t)(qbytes >> (8 * i)); sd[i] = (uint8_t)(sbytes >> (8 * i)); }
+      }
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    n_subst += __shfl_down(n_subst, d, 64);
+    n_acgt += __shfl_down(n_acgt, d, 64);
+    qsum += __shfl_down(qsum, d, 64);
+  }
+  if ((threadIdx.x & 63u) == 0 && counters) {
+    atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
+    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
+    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
   }
 }
 

@@ -237,6 +237,66 @@ def test_long_sharding(engine, oracle, genome_multi, genome_1m):
         assert np.array_equal(d["read_id"], whole["read_id"][first:first + n])
 
 
+# ---- SIMMR_RNG_PHILOX: counter mode (north_star's design for the per-base draws) ----
+def test_philox_mode_matches_its_specification(engine, oracle, genome_multi, genome_1m):
+    """Same bytes as the CPU restatement of the mode (oracle/philox.c): positions and
+    lengths still come from the reference streams, per-base draws from Philox4x32-10."""
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()
+    for gidx, g, reads, seed in ((1, genome_multi, 3001, 5), (0, genome_1m, 8000, 42)):
+        dev = engine.simulate_pe_reads_from_genome(gidx, prof, reads, seed, qual_offset=33)
+        ora = _oracle.simulate_pe(oracle, g, prof, reads, seed, qual_offset=33)
+        assert_same(dev.to_host(), ora.trimmed())
+    lp = MinimalLongErrorProfile(gamma_mean=3000.0, gamma_std=2500.0, length_mode=_abi.LEN_PER_READ,
+                                 rng_mode=_abi.RNG_PHILOX, mean_phred_score=20).pod()
+    dev = engine.simulate_long_reads([1], [120], lp, 3)
+    ora = _oracle.simulate_long(oracle, [genome_multi], [120], lp, 3)
+    d, o = dev.to_host(), ora.trimmed()
+    o["genome"][:] = 1
+    assert_same(d, o, cols=COLS + ("genome",))
+
+
+def test_philox_mode_tolerances(engine, genome_1m):
+    """The tolerances BASELINE.json / SURVEY §8d state for the statistical profiles:
+    substitution rate within 2 % of the analytic 0.013404 (mean Phred 30), Phred mean
+    29.5 +- 0.05 and sd ~10, substitution target uniform over the 3 alternatives."""
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()
+    engine.counters_reset()
+    dev = engine.simulate_pe_reads_from_genome(0, prof, 1_000_000, 2024)
+    c = engine.counters()
+    rate = c[_abi.CNT_SUBSTITUTIONS] / c[_abi.CNT_ACGT_BASES]
+    assert abs(rate / 0.013404 - 1) < 0.02, rate
+    assert abs(c[_abi.CNT_QUAL_SUM] / c[_abi.CNT_BASES] - 29.5) < 0.05
+    d = dev.to_host()
+    q = d["qual"].astype(np.float64)
+    assert abs(q.std() - 10.0) < 0.1
+    # exact Phred histogram vs the Normal(30, 10) floor distribution (z-test per bin)
+    from math import erf, sqrt
+    cdf = lambda x: 0.5 * (1 + erf((x - 30.0) / 10.0 / sqrt(2)))
+    hist = np.bincount(d["qual"], minlength=256)
+    n = hist.sum()
+    for qv in range(5, 60, 5):
+        p = cdf(qv + 1) - cdf(qv)
+        assert abs(hist[qv] / n - p) < 5 * sqrt(p / n), qv
+    # forward mates: compare with the reference bases -> which alternatives were chosen
+    ref = genome_1m.contigs[0]
+    counts = np.zeros((4, 4), dtype=np.int64)
+    lut = np.full(256, 4, dtype=np.int64)
+    lut[[65, 67, 71, 84]] = [0, 1, 2, 3]
+    fwd = np.flatnonzero((d["flags"] & 1) == 0)[:100000]
+    for r in fwd:
+        s, e2, o = int(d["start"][r]), int(d["end"][r]), int(d["seq_off"][r])
+        a, b = lut[ref[s:e2]], lut[d["seq"][o:o + e2 - s]]
+        m = a != b
+        np.add.at(counts, (a[m], b[m]), 1)
+    subs = counts.sum()
+    assert subs > 100000
+    for a in range(4):
+        row = counts[a][[x for x in range(4) if x != a]]
+        exp = row.sum() / 3
+        chi2 = ((row - exp) ** 2 / exp).sum()
+        assert chi2 < 13.8, (a, row)  # chi-square, 2 dof, p > 0.001
+
+
 # custom-short (empirical PDFs): bincode model -> alias tables on both sides
 @pytest.mark.parametrize("n_positions,seed", [(120, 42), (60, 7)])
 def test_custom_short_bit_exact(engine, oracle, genome_multi, n_positions, seed):

@@ -101,6 +101,33 @@ def test_gamma_moments(oracle):
     assert abs(sat.mean() - 19833) < 250 and abs((sat == 65535).mean() - 0.0142) < 0.003
 
 
+def test_philox4x32_10_random123_vectors(oracle):
+    """Known-answer vectors of Random123's kat_vectors for philox4x32-10 (SIMMR_RNG_PHILOX)."""
+    def ph(ctr, key):
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        oracle.orc_philox4x32_10(c, k, o)
+        return " ".join("%08x" % x for x in o)
+    assert ph([0] * 4, [0] * 2) == "6627e8d5 e169c58d bc57ac4c 9b00dbd8"
+    assert ph([0xffffffff] * 4, [0xffffffff] * 2) == "408f276d 41c83b0e a20bc7c6 6d5451fd"
+    assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        "d16cfe09 94fdcceb 5001e420 24126ea1"
+    # Phred alias table: exact probabilities of floor(N(30, 10)) saturated to u8
+    t = (C.c_uint32 * 256)()
+    oracle.orc_philox_phred_table(30, t)
+    tab = np.array(list(t), dtype=np.uint64)
+    thr, al = (tab & 0x1ffff).astype(float), (tab >> 24).astype(int)
+    P = np.zeros(256)
+    for i in range(256):
+        P[i] += thr[i] / 65536 / 256
+        P[al[i]] += (1 - thr[i] / 65536) / 256
+    from math import erf, sqrt
+    cdf = lambda x: 0.5 * (1 + erf((x - 30.0) / 10.0 / sqrt(2)))
+    for q in (0, 1, 10, 29, 30, 45, 70):
+        want = cdf(1) if q == 0 else cdf(q + 1) - cdf(q)
+        assert abs(P[q] - want) < 2.0 / 65536 / 256 * 256, q
+    assert abs((P * np.arange(256)).sum() - 29.5) < 0.01
+
+
 # ---- reference unit tests restated ------------------------------------------
 def test_util_tests_rs(oracle):
     # util_tests.rs:7-50 complement, :69-109 conversions, :53-66 encoding
