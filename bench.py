@@ -41,8 +41,10 @@ def main():
     ap.add_argument("--profile", default="minimal-short", choices=["minimal-short", "perfect-short", "minimal-long"])
     ap.add_argument("--gamma", default="8000,6000", help="minimal-long: gamma mean,std of the read length (BASELINE config 3)")
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--rng", default="reference", choices=["reference", "philox"],
-                    help="reference: the reference's own ChaCha12 streams (bit-exact); philox: counter mode (tolerance)")
+    ap.add_argument("--rng", default="philox", choices=["reference", "philox"],
+                    help="philox: Philox4x32-10 counter mode for the per-base draws (north_star's design, tolerance "
+                         "parity); reference: the reference's own ChaCha12 streams (bit-exact, slower)")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the untimed side measurement of the other rng mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -137,6 +139,28 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    # untimed side measurement of the other rng mode on the same shard (N = 1 only)
+    other = None
+    if world == 1 and not args.no_other_mode and args.profile != "perfect-short":
+        keep_mode, keep_c = prof.rng_mode, counters_dev.clone()
+        prof.rng_mode = _abi.RNG_REFERENCE if args.rng == "philox" else _abi.RNG_PHILOX
+        step(False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        kms = eng.last_emit_kernel_ms()
+        other = {
+            "rng": "reference StdRng streams (ChaCha12), bit-exact vs the reference algorithm" if args.rng == "philox"
+                   else "Philox4x32-10 counter mode (tolerance parity)",
+            "value": info.n_reads / dt, "unit": "reads/s", "ms_per_step": dt * 1e3,
+            "kernel": "k_emit_lanes" if args.rng == "philox" else "k_emit_philox", "kernel_ms": kms,
+            "steps": 1, "note": "one step after one warm-up step, same shard, outside the timed region",
+        }
+        prof.rng_mode = keep_mode
+        counters_dev.copy_(keep_c)
+
     counters = counters_dev.cpu().numpy().astype(np.uint64)
     n_reads_job = int(counters[_abi.CNT_READS])
     n_bases_job = int(counters[_abi.CNT_BASES])
@@ -146,6 +170,9 @@ def main():
     # per read ceil(L/4) packed-reference bytes + L bases + L qualities + 16 metadata
     lens = out.seq_off[1:info.n_reads + 1] - out.seq_off[:info.n_reads]
     alg_bytes = int(((lens + 3) // 4).sum().item()) + 2 * int(info.total_bases) + 16 * int(info.n_reads)
+    if other is not None and other["kernel_ms"] > 0:
+        other["achieved_GBps"] = alg_bytes / (other["kernel_ms"] * 1e-3) / 1e9
+        other["roofline_frac"] = other["achieved_GBps"] / HBM_PEAK_GBPS
     emit_avg_ms = sum(emit_ms) / max(len(emit_ms), 1)
     achieved = alg_bytes / (emit_avg_ms * 1e-3) / 1e9 if emit_avg_ms > 0 else 0.0
 
@@ -190,9 +217,12 @@ def main():
                 "traffic": None,
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": emit_avg_ms,
-                "note": "integer-ALU bound (ChaCha12), see DESIGN.md",
+                "note": ("HBM-write bound data movement" if args.profile == "perfect-short" else
+                         "integer-VALU bound (RNG), not HBM bound: see DESIGN.md section 4 and profiles/"),
             },
         }
+        if other is not None:
+            result["other_rng_mode"] = other
         if world == 1 and not args.no_cpu_baseline and not long_mode:
             result["cpu_baseline"] = cpu_baseline(args, prof)
         print(json.dumps(result), flush=True)
@@ -201,29 +231,62 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """CPU share of this process: the cgroup quota when there is one (a GPU box gives one
+    GPU's job 16 CPUs although 256 hardware threads are visible), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, int(round(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(args, prof):
-    """The CPU oracle (port of the reference algorithm) on a bounded sample of
-    the same workload, on this host's cores."""
+    """The CPU oracle — a port of the reference algorithm with the reference's own
+    generator (the Rust reference cannot be built here) — on a bounded sample of the
+    same workload, on this host's cores.  Output buffers are allocated and touched
+    before the clock starts."""
     import numpy as np
+    from simmr_amd import _abi
     from tests import _oracle, _synth
     lib = _oracle.load()
+    import ctypes
+    ref = type(prof)()
+    ctypes.memmove(ctypes.byref(ref), ctypes.byref(prof), ctypes.sizeof(prof))
+    prof = ref
+    prof.rng_mode = _abi.RNG_REFERENCE
     contigs = _synth.synthetic_contigs([args.genome_bases], 2)
     genome = _oracle.HostGenome(contigs)
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
+
+    def timed(n, threads):
+        out = _oracle.HostReads(n, n * 176, 0)
+        for a in (out.seq, out.qual, out.seq_off, out.start, out.end, out.contig, out.genome, out.read_id, out.flags):
+            a.fill(0)  # fault the pages in now
+        t = time.perf_counter()
+        o = _oracle.simulate_pe(lib, genome, prof, n, args.seed, threads=threads, out=out)
+        return time.perf_counter() - t, o
     n1 = min(args.cpu_sample_reads // 8, 250_000)
-    t = time.perf_counter()
-    _oracle.simulate_pe(lib, genome, prof, n1, args.seed, max_len=176, threads=1)
-    t1 = time.perf_counter() - t
+    t1, _ = timed(n1, 1)
     n = args.cpu_sample_reads
-    t = time.perf_counter()
-    o = _oracle.simulate_pe(lib, genome, prof, n, args.seed, max_len=176, threads=cores)
-    tn = time.perf_counter() - t
+    tn, o = timed(n, cores)
     return {
         "value": n / tn,
         "unit": "reads/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"first {n} reads of the same run (same genome, profile, seed), OpenMP over pairs on {cores} threads, {tn:.1f} s",
+        "sample": f"first {n} reads of the same run (same genome, profile, seed; the reference's ChaCha12 streams), "
+                  f"OpenMP over pairs on {cores} threads, {tn:.1f} s",
         "single_thread_value": n1 / t1,
         "single_thread_sample": f"first {n1} reads, 1 thread, {t1:.1f} s",
         "gbases_per_sec": o.total_bases / tn / 1e9,

@@ -146,11 +146,12 @@ class HostReads:
 
 
 def simulate_pe(lib, genome: HostGenome, profile: ErrorProfilePOD, genome_reads, seed, first=0,
-                count=(1 << 64) - 1, read_id_base=0, max_len=1024, threads=1, qual_offset=0):
+                count=(1 << 64) - 1, read_id_base=0, max_len=1024, threads=1, qual_offset=0, out=None):
     n_pairs = genome_reads // 2
     first = min(first, n_pairs)
     count = min(count, n_pairs - first)
-    out = HostReads(2 * count, 2 * count * max_len, qual_offset)
+    if out is None:
+        out = HostReads(2 * count, 2 * count * max_len, qual_offset)
     tb = C.c_uint64()
     rc = lib.orc_simulate_pe_reads_from_genome(C.byref(genome.c), C.byref(profile), genome_reads, seed, first,
                                                count, read_id_base, C.byref(out.pod), C.byref(tb), threads)
