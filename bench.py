@@ -214,7 +214,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": measured_traffic(args, 2 * pairs_per_gpu),
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": emit_avg_ms,
                 "note": ("HBM-write bound data movement" if args.profile == "perfect-short" else
@@ -229,6 +229,20 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(args, reads_per_gpu):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r1/e_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs of this very
+    command); only reported for the workload it was measured on."""
+    try:
+        t = json.load(open(ROOT / "profiles" / "r1" / "e_traffic.json"))
+    except OSError:
+        return None
+    if args.profile == "minimal-short" and args.rng == "philox" and reads_per_gpu == 100_000_000 \
+            and args.genome_bases == 100_000_000:
+        return t["bytes_raw"]
+    return None
 
 
 def usable_cores():
