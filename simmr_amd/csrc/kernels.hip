@@ -346,18 +346,18 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
     double z = rng.standard_normal(T);
     L = sat_u16_f64(floor(__dadd_rn((double)prof.read_length, __dmul_rn(prof.read_length_std, z))));
     I = sat_u16_f64(floor(__dadd_rn((double)prof.insert_size, __dmul_rn(prof.insert_size_std, z))));
-    rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);  // simulate.rs:227: fresh StdRng
+    rng.restart();  // simulate.rs:227: fresh StdRng::seed_from_u64(pe_seed)
   } else if (prof.kind == SIMMR_K_CUSTOM) {
     // custom_short.rs:237-270: each getter samples its PDF with a fresh StdRng(pe_seed), `as u16`
     bool bad = false;
     L = pdf_sample_lane(rng, prof.custom, prof.custom.pdfs[0], &bad) & 0xffffu;
     I = 0;
     if (prof.custom.pdfs[1].n) {
-      rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);
+      rng.restart();
       I = pdf_sample_lane(rng, prof.custom, prof.custom.pdfs[1], &bad) & 0xffffu;
     }
     if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
-    rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);
+    rng.restart();
   }
   const uint64_t required = prof.required;
   if (size <= required) { atomicOr(err, SIMMR_ERRBIT_GENOME); return; }
@@ -1582,14 +1582,34 @@ SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t k0, uint32_t k1, uint32_t out
   uint32_t c1 = 0u, c2 = 0x73696D6Du, c3 = 0x72000001u;
 #pragma unroll
   for (int r = 0; r < 10; r++) {
-    const uint32_t h0 = __umulhi(M0, c0), l0 = M0 * c0, h1 = __umulhi(M1, c2), l1 = M1 * c2;
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;  // one v_mad_u64_u32 each
+    const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
     c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
     k0 += W0; k1 += W1;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-#define PHILOX_UNITS 32u
+#define PHILOX_UNITS 64u
+
+// bytes a + b with per-byte wrap-around (u8 add of util.rs:46-50)
+SIMMR_DEV uint32_t add_bytes(uint32_t a, uint32_t b) {
+  return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+}
+// keep the low `nb` (0..4) bytes of x
+SIMMR_DEV uint32_t low_bytes(uint32_t x, int nb) {
+  return nb >= 4 ? x : (nb <= 0 ? 0u : (x & ((1u << (8 * nb)) - 1u)));
+}
+// store the low n (< 16) bytes of the 128-bit value (lo, hi)
+SIMMR_DEV void store_tail(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi, uint32_t n) {
+  uint64_t v = lo;
+  uint32_t p = 0;
+  if (n & 8u) { *reinterpret_cast<u64_unaligned*>(d) = lo; v = hi; p = 8; }
+  if (n & 4u) { *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(d + p) = (uint32_t)v; v >>= 32; p += 4; }
+  if (n & 2u) { *reinterpret_cast<uint16_t __attribute__((aligned(1)))*>(d + p) = (uint16_t)v; v >>= 16; p += 2; }
+  if (n & 1u) d[p] = (uint8_t)v;
+}
+
 extern "C" __global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
@@ -1604,16 +1624,17 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   thr[threadIdx.x] = (uint32_t)floorf(T->acc[threadIdx.x] * 16777216.0f);
   uint64_t qsum = 0;
   uint32_t n_subst = 0, n_acgt = 0;
+  const uint32_t qoff4 = (qual_offset & 0xffu) * 0x01010101u;
   const uint64_t n_blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
   for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     const uint64_t u0 = blk * PHILOX_UNITS;
     const uint32_t nu = (n_units - u0) < PHILOX_UNITS ? (uint32_t)(n_units - u0) : PHILOX_UNITS;
     __syncthreads();
-    {  // groups per unit -> exclusive prefix
+    {  // 16-base groups per unit -> exclusive prefix
       uint64_t g = 0;
       if (threadIdx.x < nu) {
         const uint32_t L = pl.len[u0 + threadIdx.x];
-        g = (uint64_t)((L + 7u) >> 3) * (paired ? 2u : 1u);
+        g = (uint64_t)((L + 15u) >> 4) * (paired ? 2u : 1u);
       }
       uint64_t tot;
       const uint64_t ex = wg_exclusive_scan_u64(g, lds4, &tot);
@@ -1623,26 +1644,26 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     __syncthreads();
     const uint32_t n_items = gpre[nu];
     for (uint32_t item = threadIdx.x; item < n_items; item += 256) {
-      // unit of this item: last u with gpre[u] <= item
-      uint32_t lo = 0, hi = nu;
+      uint32_t lo = 0, hi = nu;  // unit of this item: last u with gpre[u] <= item
       while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gpre[mid] <= item) lo = mid; else hi = mid; }
       const uint64_t u = u0 + lo;
       const uint32_t L = pl.len[u];
-      const uint32_t gpm = (L + 7u) >> 3;  // groups per mate
+      const uint32_t gpm = (L + 15u) >> 4;  // groups per mate
       uint32_t g = item - gpre[lo];
       const uint32_t rev = (paired && g >= gpm) ? 1u : 0u;
       if (rev) g -= gpm;
-      const uint32_t b0 = g << 3;
-      const uint32_t n = (L - b0) < 8u ? (L - b0) : 8u;
+      const uint32_t b0 = g << 4;
+      const uint32_t n = (L - b0) < 16u ? (L - b0) : 16u;
       const GenomeDev G = genomes[u_genome ? u_genome[u] : genome_const];
       const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
       const uint64_t off = u_off[u] + (rev ? L : 0u);
       const uint64_t src = G.contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]) + b0;
       const uint32_t codes = fetch_codes16(G.packed, (int64_t)src);
       const uint32_t exc = G.has_exc ? fetch_mask16(G.mask, (int64_t)src) : 0u;
-      uint64_t qbytes = 0, sbytes = 0;
+      const uint32_t lut = rev ? 0x41434754u : 0x54474341u;  // "TGCA" / "ACGT"
+      uint32_t qr[4] = {0, 0, 0, 0}, sw[4] = {0, 0, 0, 0}, smask = 0;
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
+      for (int c = 0; c < 8; c++) {
         uint32_t w[4];
         philox4x32_10((b0 >> 1) + (uint32_t)c, (uint32_t)key, (uint32_t)(key >> 32), w);
 #pragma unroll
@@ -1653,29 +1674,47 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           const uint32_t q = (((A >> 8) & 0xffffu) < (e & 0x1ffffu)) ? (A >> 24) : (e >> 24);
           uint32_t code = (codes >> (2 * j)) & 3u;
           const uint32_t x = (exc >> j) & 1u;
-          const bool live = (uint32_t)j < n;
-          if (live) { qsum += q; n_acgt += x ? 0u : 1u; }
-          if ((B >> 8) > thr[q] && !x) {
-            const uint32_t k = (((((A & 0xffu) << 8) | (B & 0xffu)) * 3u) >> 16);
-            code = k + (k >= code ? 1u : 0u);
-            if (live) n_subst++;
-          }
-          const uint32_t lut = rev ? 0x41434754u : 0x54474341u;  // "TGCA" / "ACGT"
+          const bool mut = (B >> 8) > thr[q] && !x;
+          const uint32_t k = (((((A & 0xffu) << 8) | (B & 0xffu)) * 3u) >> 16);
+          code = mut ? (k + (k >= code ? 1u : 0u)) : code;
+          smask |= (mut ? 1u : 0u) << j;
           const uint32_t ch = x ? ((code & 1u) ? '-' : 'N') : ((lut >> (8 * code)) & 0xffu);
-          if (live) {
-            qbytes |= (uint64_t)((q + qual_offset) & 0xffu) << (8 * j);
-            // mate 2 is reverse-complemented after mutation: base b0+j -> byte L-1-(b0+j)
-            sbytes |= (uint64_t)ch << (8 * (rev ? (n - 1u - (uint32_t)j) : (uint32_t)j));
-          }
+          qr[j >> 2] |= q << (8 * (j & 3));
+          sw[j >> 2] |= ch << (8 * (j & 3));
         }
       }
+      // counters over the live bases of the item
+      const uint32_t live = n >= 16u ? 0xffffu : ((1u << n) - 1u);
+      n_subst += __builtin_popcount(smask & live);
+      n_acgt += __builtin_popcount(~exc & live);
+      uint32_t qs = 0;
+#pragma unroll
+      for (int d = 0; d < 4; d++) qs = __builtin_amdgcn_sad_u8(low_bytes(qr[d], (int)n - 4 * d), 0u, qs);
+      qsum += qs;
+      // qualities: + offset per byte (u8 add), forward order
+      const uint64_t q_lo = (uint64_t)add_bytes(qr[0], qoff4) | ((uint64_t)add_bytes(qr[1], qoff4) << 32);
+      const uint64_t q_hi = (uint64_t)add_bytes(qr[2], qoff4) | ((uint64_t)add_bytes(qr[3], qoff4) << 32);
       uint8_t* qd = qual + off + b0;
-      uint8_t* sd = seq + off + (rev ? (L - b0 - n) : b0);
-      if (n == 8u) {
-        *reinterpret_cast<u64_unaligned*>(qd) = qbytes;
-        *reinterpret_cast<u64_unaligned*>(sd) = sbytes;
+      uint64_t s_lo = (uint64_t)sw[0] | ((uint64_t)sw[1] << 32), s_hi = (uint64_t)sw[2] | ((uint64_t)sw[3] << 32);
+      uint8_t* sd = seq + off + b0;
+      if (rev) {
+        // mate 2 is reverse-complemented after mutation (simulate.rs:283): base b0+j -> byte L-1-(b0+j).
+        // Reverse the 16 bytes, then drop the 16-n dead ones (they end up at the low end).
+        const uint64_t r_lo = __builtin_bswap64(s_hi), r_hi = __builtin_bswap64(s_lo);
+        const uint32_t sh = (16u - n) * 8u;
+        if (sh == 0) { s_lo = r_lo; s_hi = r_hi; }
+        else if (sh >= 64) { s_lo = r_hi >> (sh - 64u); s_hi = 0; }
+        else { s_lo = (r_lo >> sh) | (r_hi << (64u - sh)); s_hi = r_hi >> sh; }
+        sd = seq + off + (L - b0 - n);
+      }
+      if (n == 16u) {
+        *reinterpret_cast<u64_unaligned*>(qd) = q_lo;
+        *reinterpret_cast<u64_unaligned*>(qd + 8) = q_hi;
+        *reinterpret_cast<u64_unaligned*>(sd) = s_lo;
+        *reinterpret_cast<u64_unaligned*>(sd + 8) = s_hi;
       } else {
-        for (uint32_t i = 0; i < n; i++) { qd[i] = (uint8_t)(qbytes >> (8 * i)); sd[i] = (uint8_t)(sbytes >> (8 * i)); }
+        store_tail(qd, q_lo, q_hi, n);
+        store_tail(sd, s_lo, s_hi, n);
       }
     }
   }

@@ -123,6 +123,12 @@ struct LaneRng {
     buf = lds_row;
     words_used = 0;
   }
+  // same seed again (the reference re-creates StdRng::seed_from_u64(seed) for every
+  // profile call): keep the key, and block 0 if it is still the buffered one
+  SIMMR_DEV void restart() {
+    if (next_block == 1) { idx = 0; } else { next_block = 0; idx = 16; }
+    words_used = 0;
+  }
   SIMMR_DEV void refill() {
     uint32_t o[16];
     chacha12_block(key, next_block, o);
