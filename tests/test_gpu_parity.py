@@ -255,6 +255,33 @@ def test_philox_mode_matches_its_specification(engine, oracle, genome_multi, gen
     assert_same(d, o, cols=COLS + ("genome",))
 
 
+@pytest.mark.parametrize("L,I,q", [(20, 20, 30), (7, 3, 10), (150, 600, 45), (333, 100, 2), (16, 16, 60)])
+def test_philox_mode_edge_shapes(engine, oracle, genome_multi, L, I, q):
+    prof = MinimalShortErrorProfile(read_length=L, insert_size=I, mean_phred_score=q, rng_mode=_abi.RNG_PHILOX).pod()
+    dev = engine.simulate_pe_reads_from_genome(1, prof, 2501, 13, first=100, count=900, read_id_base=7)
+    ora = _oracle.simulate_pe(oracle, genome_multi, prof, 2501, 13, first=100, count=900, read_id_base=7, max_len=4096)
+    assert_same(dev.to_host(), ora.trimmed())
+
+
+def test_philox_mode_exceptions(engine, oracle):
+    rng = np.random.default_rng(21)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 30000)].copy()
+    seq[rng.integers(0, 30000, 3000)] = ord("N")
+    seq[rng.integers(0, 30000, 500)] = ord("-")
+    engine.stage_genome(3, [seq])
+    g = _oracle.HostGenome([seq])
+    prof = MinimalShortErrorProfile(mean_phred_score=8, rng_mode=_abi.RNG_PHILOX).pod()
+    dev = engine.simulate_pe_reads_from_genome(3, prof, 3000, 8)
+    ora = _oracle.simulate_pe(oracle, g, prof, 3000, 8)
+    assert_same(dev.to_host(), ora.trimmed())
+    prof = PerfectLongErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()  # different Phred law: refused, not approximated
+    from simmr_amd import SimmrError
+    engine.stage_genome(3, [np.tile(seq, 2)])
+    with pytest.raises(SimmrError) as ei:
+        engine.long_plan([3], [5], prof, 1)
+    assert ei.value.code == _abi.EINVAL
+
+
 def test_philox_mode_tolerances(engine, genome_1m):
     """The tolerances BASELINE.json / SURVEY §8d state for the statistical profiles:
     substitution rate within 2 % of the analytic 0.013404 (mean Phred 30), Phred mean
