@@ -1,0 +1,135 @@
+"""BASELINE.json configs[1] at FULL size (100 M reads of minimal-short 150 bp PE on a
+100 Mbp synthetic genome) checked through size-independent properties, all
+evaluated on the device: determinism (same seed -> same checksums), sharded ==
+whole (position-sensitive checksums of the shard byte ranges), CSR consistency,
+alphabet / quality ranges, mate geometry, id sequence, substitution / Phred
+statistics.  Both generator modes."""
+import numpy as np
+import pytest
+
+from simmr_amd import MinimalShortErrorProfile, PerfectShortErrorProfile, _abi
+
+pytestmark = pytest.mark.gpu
+
+N_READS = 100_000_000
+GENOME = 100_000_000
+
+
+def colsum256(t):
+    """position-mod-256 sensitive checksum of a uint8 CUDA tensor (int64[256])"""
+    import torch
+    n = t.numel() // 256 * 256
+    out = torch.zeros(256, dtype=torch.int64, device=t.device)
+    step = 1 << 30
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        out += t[a:b].view(-1, 256).sum(dim=0, dtype=torch.int64)
+    if n < t.numel():
+        out[: t.numel() - n] += t[n:].to(torch.int64)
+    return out
+
+
+def checksum_range(t, a, b):
+    """colsum256 of t[a:b], phase-aligned to absolute positions"""
+    import torch
+    cs = colsum256(t[a:b])
+    return torch.roll(cs, a % 256)
+
+
+@pytest.fixture(scope="module")
+def big(engine):
+    engine.stage_synthetic(5, [GENOME], 2)
+    return engine
+
+
+@pytest.mark.parametrize("rng_mode", [_abi.RNG_PHILOX, _abi.RNG_REFERENCE])
+def test_c2_full_size_properties(big, rng_mode):
+    import torch
+    eng = big
+    prof = MinimalShortErrorProfile(rng_mode=rng_mode).pod()
+    eng.counters_reset()
+    whole = eng.simulate_pe_reads_from_genome(5, prof, N_READS, 42, qual_offset=33)
+    c = eng.counters()
+    n, tb = whole.n_reads, whole.total_bases
+    assert n == N_READS and c[_abi.CNT_READS] == N_READS and c[_abi.CNT_BASES] == tb
+    off = whole.seq_off[: n + 1]
+    lens = off[1:] - off[:-1]
+    # CSR: monotone, starts at 0, ends at total; mates share a length; lengths ~ floor(N(150, 15))
+    assert int(off[0]) == 0 and int(off[-1]) == tb and bool((lens >= 0).all())
+    assert bool((lens[0::2] == lens[1::2]).all())
+    lm = lens.double().mean().item()
+    assert abs(lm - 149.5) < 0.05 and abs(lens.double().std().item() - 15.0) < 0.1
+    # geometry: forward mates ascend, mate 2 is stored with start > end (simulate.rs:295-296), |end-start| == len
+    st, en, fl = whole.start[:n], whole.end[:n], whole.flags[:n]
+    assert bool(((fl[0::2] & 1) == 0).all()) and bool(((fl[1::2] & 1) == 1).all())
+    assert bool(((en[0::2] - st[0::2]) == lens[0::2]).all()) and bool(((st[1::2] - en[1::2]) == lens[1::2]).all())
+    assert int(st.min()) >= 0 and int(torch.maximum(st, en).max()) <= GENOME
+    # ids: one per pair, in generation order; single contig
+    ids = whole.read_id[:n]
+    assert bool((ids[0::2] == ids[1::2]).all()) and bool((ids[0::2] == torch.arange(n // 2, device=ids.device, dtype=ids.dtype)).all())
+    assert int(whole.contig[:n].max()) == 0
+    # alphabet and quality range (+33; the ziggurat tail does reach Phred 94 = 6.4 sigma at this size)
+    seq, qual = whole.seq[:tb], whole.qual[:tb]
+    hist = torch.bincount(seq[: 2_000_000_000].to(torch.int64), minlength=256)
+    assert int(hist.sum() - hist[[65, 67, 71, 84]].sum()) == 0
+    assert int(qual.min()) >= 33 and int(qual.max()) <= 33 + 105  # 1.5e10 draws reach ~6.4 sigma
+    # statistics from the run counters (SURVEY §8d tolerances)
+    rate = c[_abi.CNT_SUBSTITUTIONS] / c[_abi.CNT_ACGT_BASES]
+    assert abs(rate / 0.013404 - 1) < 0.005, rate
+    assert abs(c[_abi.CNT_QUAL_SUM] / c[_abi.CNT_BASES] - 29.5) < 0.01
+    # the substitutions are really in the bytes: mismatches of forward mates against the staged reference
+    # (reads are picked by INDEX: picking by start position would bias the sample — in the reference
+    #  algorithm the first u64 of StdRng(pe_seed) decides both fwd_start and the first Phred draw)
+    ref = torch.from_numpy(eng.unstage(5, 0, 0, GENOME)).to(seq.device)
+    sel = torch.arange(0, 400_000, 2, device=seq.device)
+    o, s0, ln = off[sel], st[sel], lens[sel]
+    k = torch.arange(64, device=seq.device)
+    got = seq[(o[:, None] + k[None, :]).clamp(max=tb - 1)]
+    want = ref[(s0[:, None] + k[None, :])]
+    valid = k[None, :] < ln[:, None]
+    mism = ((got != want) & valid).sum().item() / valid.sum().item()
+    assert abs(mism / 0.013404 - 1) < 0.03, mism
+    # determinism + sharding: two shards reproduce the whole run byte for byte (checksums)
+    cs_seq, cs_qual = colsum256(seq), colsum256(qual)
+    half = N_READS // 4  # pairs
+    a = eng.simulate_pe_reads_from_genome(5, prof, N_READS, 42, first=0, count=half, qual_offset=33)
+    cut = int(off[2 * half])
+    assert a.total_bases == cut
+    assert bool((checksum_range(seq, 0, cut) == colsum256(a.seq[:cut])).all())
+    assert bool((checksum_range(qual, 0, cut) == colsum256(a.qual[:cut])).all())
+    del a
+    b = eng.simulate_pe_reads_from_genome(5, prof, N_READS, 42, first=half, count=N_READS, qual_offset=33, read_id_base=0)
+    assert b.total_bases == tb - cut and b.n_reads == N_READS - 2 * half
+    assert bool((checksum_range(seq, cut, tb) == torch.roll(colsum256(b.seq[: tb - cut]), cut % 256)).all())
+    assert bool((checksum_range(qual, cut, tb) == torch.roll(colsum256(b.qual[: tb - cut]), cut % 256)).all())
+    assert bool((b.start[: b.n_reads] == st[2 * half:]).all()) and bool((b.read_id[: b.n_reads] == ids[2 * half:]).all())
+    del b
+    again = eng.simulate_pe_reads_from_genome(5, prof, N_READS, 42, qual_offset=33)
+    assert bool((colsum256(again.seq[:tb]) == cs_seq).all()) and bool((colsum256(again.qual[:tb]) == cs_qual).all())
+    # a different seed gives a different run
+    del again
+    other = eng.simulate_pe_reads_from_genome(5, prof, 2_000_000, 43, qual_offset=33)
+    assert not bool((other.start[:1000] == st[:1000]).all())
+
+
+def test_c1_perfect_short_full_roundtrip(big):
+    """perfect-short at 100 M reads: every read equals the reference slice (mate 2: its
+    reverse complement) — checked for ALL reads on the device with gathers."""
+    import torch
+    eng = big
+    prof = PerfectShortErrorProfile().pod()
+    r = eng.simulate_pe_reads_from_genome(5, prof, 20_000_000, 42)
+    n, tb = r.n_reads, r.total_bases
+    assert tb == n * 150 and bool((r.qual[:tb] == 60).all())
+    ref = torch.from_numpy(eng.unstage(5, 0, 0, GENOME)).to(r.seq.device)
+    comp = torch.zeros(256, dtype=torch.uint8, device=ref.device)
+    comp[[65, 67, 71, 84]] = torch.tensor([84, 71, 67, 65], dtype=torch.uint8, device=ref.device)
+    seq = r.seq[:tb].view(n, 150)
+    k = torch.arange(150, device=ref.device)
+    for a in range(0, n, 2_000_000):
+        b = min(n, a + 2_000_000)
+        st, en = r.start[a:b], r.end[a:b]
+        fwd = ref[(st[0::2, None] + k[None, :])]
+        assert bool((seq[a:b:2] == fwd).all())
+        rc = comp[ref[(st[1::2, None] - 1 - k[None, :])].long()]
+        assert bool((seq[a + 1:b:2] == rc).all())
