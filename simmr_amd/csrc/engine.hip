@@ -801,7 +801,11 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
     } else if (e->prof.rng_mode == SIMMR_RNG_PHILOX) {
       const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
       const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
-      hipLaunchKernelGGL(k_emit_philox, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
+      bool exc = false;
+      if (paired) exc = e->genomes[e->plan_genome].has_exc;
+      else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
+      auto kern = exc ? k_emit_philox<true> : k_emit_philox<false>;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
                          e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                          e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
                          out->qual_offset, e->d_tables.as<Tables>(), counters);

@@ -1610,7 +1610,8 @@ SIMMR_DEV void store_tail(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi, uin
   if (n & 1u) d[p] = (uint8_t)v;
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+template <bool HAS_EXC>
+__global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
               const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
@@ -1658,10 +1659,10 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
       const uint64_t off = u_off[u] + (rev ? L : 0u);
       const uint64_t src = G.contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]) + b0;
-      const uint32_t codes = fetch_codes16(G.packed, (int64_t)src);
-      const uint32_t exc = G.has_exc ? fetch_mask16(G.mask, (int64_t)src) : 0u;
-      const uint32_t lut = rev ? 0x41434754u : 0x54474341u;  // "TGCA" / "ACGT"
-      uint32_t qr[4] = {0, 0, 0, 0}, sw[4] = {0, 0, 0, 0}, smask = 0;
+      uint32_t codes = fetch_codes16(G.packed, (int64_t)src);
+      uint32_t exc = (HAS_EXC && G.has_exc) ? fetch_mask16(G.mask, (int64_t)src) : 0u;
+      // per base: Phred (alias table), substitution test bit, replacement rank k; all packed
+      uint32_t qr[4] = {0, 0, 0, 0}, ks = 0, mmask = 0;
 #pragma unroll
       for (int c = 0; c < 8; c++) {
         uint32_t w[4];
@@ -1671,42 +1672,49 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           const int j = 2 * c + h;  // base b0 + j
           const uint32_t A = w[2 * h], B = w[2 * h + 1];
           const uint32_t e = ptab[A >> 24];
-          const uint32_t q = (((A >> 8) & 0xffffu) < (e & 0x1ffffu)) ? (A >> 24) : (e >> 24);
-          uint32_t code = (codes >> (2 * j)) & 3u;
-          const uint32_t x = (exc >> j) & 1u;
-          const bool mut = (B >> 8) > thr[q] && !x;
-          const uint32_t k = (((((A & 0xffu) << 8) | (B & 0xffu)) * 3u) >> 16);
-          code = mut ? (k + (k >= code ? 1u : 0u)) : code;
-          smask |= (mut ? 1u : 0u) << j;
-          const uint32_t ch = x ? ((code & 1u) ? '-' : 'N') : ((lut >> (8 * code)) & 0xffu);
+          const uint32_t q = (__builtin_amdgcn_ubfe(A, 8, 16) < (e & 0x1ffffu)) ? (A >> 24) : (e >> 24);
+          mmask |= (((B >> 8) > thr[q]) ? 1u : 0u) << j;
+          const uint32_t c16 = __builtin_amdgcn_perm(A, B, 0x0c0c0400u);  // ((A & 0xff) << 8) | (B & 0xff)
+          ks |= ((c16 * 3u) >> 16) << (2 * j);
           qr[j >> 2] |= q << (8 * (j & 3));
-          sw[j >> 2] |= ch << (8 * (j & 3));
         }
       }
       // counters over the live bases of the item
       const uint32_t live = n >= 16u ? 0xffffu : ((1u << n) - 1u);
-      n_subst += __builtin_popcount(smask & live);
+      mmask &= ~exc & live;  // only ACGT bases mutate (minimal_short.rs:120-128)
+      n_subst += __builtin_popcount(mmask);
       n_acgt += __builtin_popcount(~exc & live);
       uint32_t qs = 0;
 #pragma unroll
       for (int d = 0; d < 4; d++) qs = __builtin_amdgcn_sad_u8(low_bytes(qr[d], (int)n - 4 * d), 0u, qs);
       qsum += qs;
+      // substitutions in the 2-bit code domain: alt = k + (k >= code), 16 bases at once
+      {
+        const uint32_t ce = codes & 0x33333333u, co = (codes >> 2) & 0x33333333u;
+        const uint32_t ke = ks & 0x33333333u, ko = (ks >> 2) & 0x33333333u;
+        const uint32_t ae = ke + ((((ke | 0x44444444u) - ce) >> 2) & 0x11111111u);
+        const uint32_t ao = ko + ((((ko | 0x44444444u) - co) >> 2) & 0x11111111u);
+        const uint32_t alt = ae | (ao << 2);
+        const uint32_t m32 = spread16(mmask);
+        codes = (codes & ~m32) | (alt & m32);
+      }
       // qualities: + offset per byte (u8 add), forward order
       const uint64_t q_lo = (uint64_t)add_bytes(qr[0], qoff4) | ((uint64_t)add_bytes(qr[1], qoff4) << 32);
       const uint64_t q_hi = (uint64_t)add_bytes(qr[2], qoff4) | ((uint64_t)add_bytes(qr[3], qoff4) << 32);
       uint8_t* qd = qual + off + b0;
-      uint64_t s_lo = (uint64_t)sw[0] | ((uint64_t)sw[1] << 32), s_hi = (uint64_t)sw[2] | ((uint64_t)sw[3] << 32);
       uint8_t* sd = seq + off + b0;
       if (rev) {
-        // mate 2 is reverse-complemented after mutation (simulate.rs:283): base b0+j -> byte L-1-(b0+j).
-        // Reverse the 16 bytes, then drop the 16-n dead ones (they end up at the low end).
-        const uint64_t r_lo = __builtin_bswap64(s_hi), r_hi = __builtin_bswap64(s_lo);
-        const uint32_t sh = (16u - n) * 8u;
-        if (sh == 0) { s_lo = r_lo; s_hi = r_hi; }
-        else if (sh >= 64) { s_lo = r_hi >> (sh - 64u); s_hi = 0; }
-        else { s_lo = (r_lo >> sh) | (r_hi << (64u - sh)); s_hi = r_hi >> sh; }
+        // mate 2 is reverse-complemented after mutation (simulate.rs:283), still in the code domain:
+        // base b0+j -> byte L-1-(b0+j); the 16-n dead groups fall off the low end
+        codes = ~reverse_groups16(codes);
+        if (HAS_EXC) { exc = __builtin_bitreverse32(exc) >> 16; codes ^= spread16(exc); }
+        const uint32_t dead = 16u - n;
+        if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
         sd = seq + off + (L - b0 - n);
       }
+      const uint32_t s0 = expand4(codes & 0xffu, exc & 0xfu), s1 = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
+      const uint32_t s2 = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu), s3 = expand4(codes >> 24, (exc >> 12) & 0xfu);
+      const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
       if (n == 16u) {
         *reinterpret_cast<u64_unaligned*>(qd) = q_lo;
         *reinterpret_cast<u64_unaligned*>(qd + 8) = q_hi;
