@@ -71,6 +71,7 @@ struct ProfileDev {
   double read_length_std, insert_size_std;
   CustomDev custom;
   const uint32_t* philox_phred;  // SIMMR_RNG_PHILOX: 256 alias entries (thr17 | alias << 24)
+  uint32_t philox_qmax;          // largest Phred the alias table can return
 };
 
 struct Key8 {

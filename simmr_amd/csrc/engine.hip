@@ -346,6 +346,12 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
     int rc = upload_vec(e, e->ph_table, table);
     if (rc || (rc = sync_check(e, "philox table upload"))) return rc;
     d.philox_phred = e->ph_table.as<uint32_t>();
+    d.philox_qmax = 0;
+    for (int i = 0; i < 256; i++) {
+      const uint32_t thr = table[i] & 0x1ffffu;
+      if (thr > 0 && (uint32_t)i > d.philox_qmax) d.philox_qmax = (uint32_t)i;
+      if (thr < 65536u && (uint32_t)alias[i] > d.philox_qmax) d.philox_qmax = (uint32_t)alias[i];
+    }
   }
   *out = d;
   return SIMMR_OK;

@@ -1571,12 +1571,23 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
 //    prescribes for the per-base draws; statistical parity).
 //
 // Philox4x32-10 keyed by the read's Phred seed, counter = base index / 2: no
-// draw depends on another, so the work item is simply "8 consecutive bases of
-// one read".  A workgroup takes 32 units (pairs or long reads), builds the
-// prefix of their group counts in LDS and deals the groups to its 256 lanes:
-// consecutive lanes hold consecutive groups, so the 8-byte quality and base
-// stores of a wave coalesce into 512 contiguous bytes.
+// draw depends on another, so the work item is "16 consecutive bases of one
+// read".  A workgroup takes 64 units (128 mates, or 64 long reads), writes one
+// record per read to LDS (key, output offset, source position, length) together
+// with the prefix of their item counts, and deals the items to its 256 lanes:
+// consecutive lanes hold consecutive groups, so a wave's 16-byte quality and
+// base stores are contiguous.  The kernel is bound by integer VALU issue (one
+// wave64 instruction per 4 cycles per SIMD), so everything below is written to
+// minimise the instruction count per base:
+//   * v_mad_u64_u32 gives both halves of a Philox product, v_bitop3_b32 the
+//     three-way xor of a round (4 instructions per round);
+//   * one 16-byte LDS entry per Phred bin holds the alias threshold and, for
+//     either outcome, (substitution threshold << 8 | q): one ds_read_b128, one
+//     select, and the 24-bit substitution test is a single compare;
+//   * a branch-free binary search over the item prefix finds the read.
 // ===========================================================================
+SIMMR_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
 SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t k0, uint32_t k1, uint32_t out[4]) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
   uint32_t c1 = 0u, c2 = 0x73696D6Du, c3 = 0x72000001u;
@@ -1584,13 +1595,14 @@ SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t k0, uint32_t k1, uint32_t out
   for (int r = 0; r < 10; r++) {
     const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;  // one v_mad_u64_u32 each
     const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
-    c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+    c0 = xor3(h1, c1, k0); c1 = l1; c2 = xor3(h0, c3, k1); c3 = l0;
     k0 += W0; k1 += W1;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
 #define PHILOX_UNITS 64u
+#define PHILOX_READS 128u  /* 64 pairs x 2 mates */
 
 // bytes a + b with per-byte wrap-around (u8 add of util.rs:46-50)
 SIMMR_DEV uint32_t add_bytes(uint32_t a, uint32_t b) {
@@ -1610,6 +1622,23 @@ SIMMR_DEV void store_tail(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi, uin
   if (n & 1u) d[p] = (uint8_t)v;
 }
 
+// exclusive scan of one u32 per thread over a 256-thread workgroup
+SIMMR_DEV uint32_t wg_exclusive_scan_u32(uint32_t v, uint32_t* lds4, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc += o;
+  }
+  if (lane == 63) lds4[wave] = inc;
+  __syncthreads();
+  const uint32_t t0 = lds4[0], t1 = lds4[1], t2 = lds4[2], t3 = lds4[3];
+  const uint32_t pre = (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
+  *total = t0 + t1 + t2 + t3;
+  return pre + inc - v;
+}
+
 template <bool HAS_EXC>
 __global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
@@ -1617,66 +1646,94 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
               const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
               const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
               uint32_t qual_offset, const Tables* __restrict__ T, unsigned long long* __restrict__ counters) {
-  __shared__ uint32_t ptab[256];  // Phred alias table
-  __shared__ uint32_t thr[256];   // substitution thresholds
-  __shared__ uint32_t gpre[PHILOX_UNITS + 1];
-  __shared__ uint64_t lds4[4];
-  ptab[threadIdx.x] = prof.philox_phred[threadIdx.x];
-  thr[threadIdx.x] = (uint32_t)floorf(T->acc[threadIdx.x] * 16777216.0f);
-  uint64_t qsum = 0;
-  uint32_t n_subst = 0, n_acgt = 0;
-  const uint32_t qoff4 = (qual_offset & 0xffu) * 0x01010101u;
+  // per Phred bin i: x = alias threshold (17 bits), y = thr[i] << 8 | enc(i), z = thr[alias] << 8 | enc(alias),
+  // enc(q) = (q + qual_offset) as u8 (util.rs:46-50)
+  __shared__ uint4 ptab[256];
+  __shared__ uint32_t asc[256];  // four 2-bit codes -> four ASCII bytes
+  __shared__ uint64_t r_key[PHILOX_READS], r_dst[PHILOX_READS], r_src[PHILOX_READS];
+  __shared__ const uint32_t* r_packed[PHILOX_READS];
+  __shared__ const uint32_t* r_mask[PHILOX_READS];
+  __shared__ uint32_t r_len[PHILOX_READS];     // L | rev << 31
+  __shared__ uint32_t r_gs[PHILOX_READS + 1];  // first item of each read, ~0 past the last read
+  __shared__ uint32_t lds4[4];
+  {
+    const uint32_t t = threadIdx.x;
+    const uint32_t e = prof.philox_phred[t];
+    const uint32_t al = e >> 24;
+    // substitution iff (B >> 8) > floor(accuracy(q) * 2^24) (the reference's 24-bit test,
+    // minimal_short.rs:118); thresholds of 2^24 (accuracy rounds to 1.0f) can never be exceeded,
+    // and neither can 2^24 - 1, which fits the packed form
+    uint32_t ti = (uint32_t)floorf(T->acc[t] * 16777216.0f), ta = (uint32_t)floorf(T->acc[al] * 16777216.0f);
+    ti = ti > 0xffffffu ? 0xffffffu : ti;
+    ta = ta > 0xffffffu ? 0xffffffu : ta;
+    ptab[t] = make_uint4(e & 0x1ffffu, (ti << 8) | ((t + qual_offset) & 0xffu), (ta << 8) | ((al + qual_offset) & 0xffu), 0u);
+    const uint32_t acgt = 0x54474341u;  // "ACGT"
+    asc[t] = ((acgt >> (8 * (t & 3u))) & 0xffu) | (((acgt >> (8 * ((t >> 2) & 3u))) & 0xffu) << 8) |
+             (((acgt >> (8 * ((t >> 4) & 3u))) & 0xffu) << 16) | (((acgt >> (8 * (t >> 6))) & 0xffu) << 24);
+  }
+  uint64_t qsum = 0, n_live = 0;  // qsum adds encoded qualities; the offset is taken off at the end
+  uint32_t n_subst = 0, n_acgt = 0, n_wrap = 0;
+  const uint32_t qoff = qual_offset & 0xffu;
+  const bool q_nowrap = qoff + prof.philox_qmax <= 255u;  // then no encoded quality wraps
+  const uint32_t rpu = paired ? 2u : 1u;
   const uint64_t n_blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
   for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     const uint64_t u0 = blk * PHILOX_UNITS;
     const uint32_t nu = (n_units - u0) < PHILOX_UNITS ? (uint32_t)(n_units - u0) : PHILOX_UNITS;
-    __syncthreads();
-    {  // 16-base groups per unit -> exclusive prefix
-      uint64_t g = 0;
-      if (threadIdx.x < nu) {
-        const uint32_t L = pl.len[u0 + threadIdx.x];
-        g = (uint64_t)((L + 15u) >> 4) * (paired ? 2u : 1u);
-      }
-      uint64_t tot;
-      const uint64_t ex = wg_exclusive_scan_u64(g, lds4, &tot);
-      if (threadIdx.x < nu) gpre[threadIdx.x] = (uint32_t)ex;
-      if (threadIdx.x == 0) gpre[nu] = (uint32_t)tot;
-    }
-    __syncthreads();
-    const uint32_t n_items = gpre[nu];
-    for (uint32_t item = threadIdx.x; item < n_items; item += 256) {
-      uint32_t lo = 0, hi = nu;  // unit of this item: last u with gpre[u] <= item
-      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gpre[mid] <= item) lo = mid; else hi = mid; }
-      const uint64_t u = u0 + lo;
+    const uint32_t nr = nu * rpu;
+    __syncthreads();  // the previous block's items are done with the records
+    uint32_t g = 0;
+    if (threadIdx.x < nr) {
+      const uint32_t t = threadIdx.x;
+      const uint64_t u = u0 + (paired ? (t >> 1) : t);
+      const uint32_t rev = paired ? (t & 1u) : 0u;
       const uint32_t L = pl.len[u];
-      const uint32_t gpm = (L + 15u) >> 4;  // groups per mate
-      uint32_t g = item - gpre[lo];
-      const uint32_t rev = (paired && g >= gpm) ? 1u : 0u;
-      if (rev) g -= gpm;
-      const uint32_t b0 = g << 4;
+      g = (L + 15u) >> 4;
+      const GenomeDev* G = genomes + (u_genome ? u_genome[u] : genome_const);
+      r_key[t] = rev ? pl.qs2[u] : u_seed[u];
+      r_dst[t] = u_off[u] + (rev ? L : 0u);
+      r_src[t] = G->contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]);
+      r_len[t] = L | (rev << 31);
+      r_packed[t] = G->packed;
+      r_mask[t] = (HAS_EXC && G->has_exc) ? G->mask : nullptr;
+    }
+    uint32_t n_items;
+    const uint32_t ex = wg_exclusive_scan_u32(g, lds4, &n_items);
+    if (threadIdx.x <= PHILOX_READS) r_gs[threadIdx.x] = threadIdx.x < nr ? ex : 0xffffffffu;
+    __syncthreads();
+    for (uint32_t item = threadIdx.x; item < n_items; item += 256) {
+      uint32_t r = 0;  // read of this item: last r with r_gs[r] <= item
+#pragma unroll
+      for (uint32_t step = PHILOX_READS / 2; step; step >>= 1)
+        if (r_gs[r + step] <= item) r += step;
+      const uint32_t Lr = r_len[r];
+      const uint32_t L = Lr & 0x7fffffffu, rev = Lr >> 31;
+      const uint32_t b0 = (item - r_gs[r]) << 4;
       const uint32_t n = (L - b0) < 16u ? (L - b0) : 16u;
-      const GenomeDev G = genomes[u_genome ? u_genome[u] : genome_const];
-      const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
-      const uint64_t off = u_off[u] + (rev ? L : 0u);
-      const uint64_t src = G.contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]) + b0;
-      uint32_t codes = fetch_codes16(G.packed, (int64_t)src);
-      uint32_t exc = (HAS_EXC && G.has_exc) ? fetch_mask16(G.mask, (int64_t)src) : 0u;
+      const uint64_t key = r_key[r];
+      const uint64_t off = r_dst[r];
+      const uint64_t src = r_src[r] + b0;
+      uint32_t codes = fetch_codes16(r_packed[r], (int64_t)src);
+      uint32_t exc = 0u;
+      if (HAS_EXC) { const uint32_t* mk = r_mask[r]; if (mk) exc = fetch_mask16(mk, (int64_t)src); }
       // per base: Phred (alias table), substitution test bit, replacement rank k; all packed
       uint32_t qr[4] = {0, 0, 0, 0}, ks = 0, mmask = 0;
 #pragma unroll
-      for (int c = 0; c < 8; c++) {
+      for (int c = 7; c >= 0; c--) {
         uint32_t w[4];
         philox4x32_10((b0 >> 1) + (uint32_t)c, (uint32_t)key, (uint32_t)(key >> 32), w);
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int j = 2 * c + h;  // base b0 + j
+        for (int h = 1; h >= 0; h--) {
+          const int j = 2 * c + h;  // base b0 + j; descending, so base j ends at bit j of mmask
           const uint32_t A = w[2 * h], B = w[2 * h + 1];
-          const uint32_t e = ptab[A >> 24];
-          const uint32_t q = (__builtin_amdgcn_ubfe(A, 8, 16) < (e & 0x1ffffu)) ? (A >> 24) : (e >> 24);
-          mmask |= (((B >> 8) > thr[q]) ? 1u : 0u) << j;
+          const uint4 e = ptab[A >> 24];
+          const uint32_t x = (__builtin_amdgcn_ubfe(A, 8, 16) < e.x) ? e.y : e.z;  // thr[q] << 8 | enc(q)
+          // mmask = mmask << 1 | ((B >> 8) > thr[q]): compare, then shift the carry in
+          asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mmask) : "v"(B & 0xffffff00u), "v"(x) : "vcc");
+          // byte (j & 3) of qr[j >> 2] = enc(q)
+          qr[j >> 2] = __builtin_amdgcn_perm(x, qr[j >> 2], 0x03020100u ^ (0x04u << (8 * (j & 3))) ^ ((uint32_t)(j & 3) << (8 * (j & 3))));
           const uint32_t c16 = __builtin_amdgcn_perm(A, B, 0x0c0c0400u);  // ((A & 0xff) << 8) | (B & 0xff)
           ks |= ((c16 * 3u) >> 16) << (2 * j);
-          qr[j >> 2] |= q << (8 * (j & 3));
         }
       }
       // counters over the live bases of the item
@@ -1688,6 +1745,10 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #pragma unroll
       for (int d = 0; d < 4; d++) qs = __builtin_amdgcn_sad_u8(low_bytes(qr[d], (int)n - 4 * d), 0u, qs);
       qsum += qs;
+      n_live += n;
+      if (!q_nowrap) {
+        for (uint32_t j = 0; j < n; j++) n_wrap += ((qr[j >> 2] >> (8 * (j & 3u))) & 0xffu) < qoff ? 1u : 0u;
+      }
       // substitutions in the 2-bit code domain: alt = k + (k >= code), 16 bases at once
       {
         const uint32_t ce = codes & 0x33333333u, co = (codes >> 2) & 0x33333333u;
@@ -1698,9 +1759,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         const uint32_t m32 = spread16(mmask);
         codes = (codes & ~m32) | (alt & m32);
       }
-      // qualities: + offset per byte (u8 add), forward order
-      const uint64_t q_lo = (uint64_t)add_bytes(qr[0], qoff4) | ((uint64_t)add_bytes(qr[1], qoff4) << 32);
-      const uint64_t q_hi = (uint64_t)add_bytes(qr[2], qoff4) | ((uint64_t)add_bytes(qr[3], qoff4) << 32);
+      // qualities are already offset-encoded, forward order
+      const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
       uint8_t* qd = qual + off + b0;
       uint8_t* sd = seq + off + b0;
       if (rev) {
@@ -1712,8 +1772,13 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
         sd = seq + off + (L - b0 - n);
       }
-      const uint32_t s0 = expand4(codes & 0xffu, exc & 0xfu), s1 = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
-      const uint32_t s2 = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu), s3 = expand4(codes >> 24, (exc >> 12) & 0xfu);
+      uint32_t s0, s1, s2, s3;
+      if (HAS_EXC) {
+        s0 = expand4(codes & 0xffu, exc & 0xfu); s1 = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
+        s2 = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu); s3 = expand4(codes >> 24, (exc >> 12) & 0xfu);
+      } else {
+        s0 = asc[codes & 0xffu]; s1 = asc[(codes >> 8) & 0xffu]; s2 = asc[(codes >> 16) & 0xffu]; s3 = asc[codes >> 24];
+      }
       const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
       if (n == 16u) {
         *reinterpret_cast<u64_unaligned*>(qd) = q_lo;
@@ -1726,6 +1791,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       }
     }
   }
+  qsum = qsum + 256ull * n_wrap - (uint64_t)qoff * n_live;  // sum of the raw Phred values
   for (int d = 32; d > 0; d >>= 1) {
     n_subst += __shfl_down(n_subst, d, 64);
     n_acgt += __shfl_down(n_acgt, d, 64);
