@@ -60,10 +60,12 @@ enum simmr_profile_kind {
  *   by PCG32 seed expansion) consumed exactly as simulate.rs / the profiles
  *   consume them.  Output is bit-identical to the reference for everything the
  *   reference itself makes deterministic under --seed.
- * PHILOX: counter-based Philox4x32-10 keyed by (seed, read, base); positions
- *   and lengths still come from the reference streams, per-base Phred and
- *   substitution draws do not.  Statistical tolerance only (BASELINE.json
- *   north_star). */
+ * PHILOX: counter-based Philox4x32-10 keyed by the read's Phred seed, counter
+ *   = base index / 4, one output word per base; that word draws (Phred,
+ *   substitution) from their joint law with one alias-table lookup (the law
+ *   is stated in DESIGN.md section 4 and restated in oracle/philox.c).
+ *   Positions, lengths and seeds still come from the reference streams.
+ *   Statistical tolerance only (BASELINE.json north_star). */
 enum simmr_rng_mode { SIMMR_RNG_REFERENCE = 0, SIMMR_RNG_PHILOX = 1 };
 
 /* Long-read length policy (Appendix A Q5 of SURVEY.md).

@@ -7,14 +7,18 @@
  * specification lives here and in DESIGN.md §4:
  *   - Philox4x32-10 (Salmon et al., SC'11; Random123 constants), key = the
  *     read's Phred seed (pe_seed / drawn-or-substituted mate-2 seed / read_seed),
- *     counter = (b >> 1, 0, 'simm', 'r\0\0\1'); words 0,1 serve base b even,
- *     words 2,3 base b odd.
- *   - word A: Phred = alias-table sample of P(floor(N(mean,10)) sat. to u8):
- *       idx = A >> 24, frac = (A >> 8) & 0xffff, q = frac < thr[idx] ? idx : alias[idx]
- *   - word B: substitution iff (B >> 8) > floor(accuracy(q) * 2^24) — the same
- *     24-bit test as gen::<f32>() > accuracy (minimal_short.rs:119) — and the
- *     base is ACGT; the replacement is the k-th of the three other bases,
- *     k = ((((A & 0xff) << 8) | (B & 0xff)) * 3) >> 16.
+ *     counter = (b >> 2, 0, 'simm', 'r\0\0\1'); base b takes output word b & 3.
+ *   - that one word W draws the Phred score and the substitution together from
+ *     the joint law of minimal_short.rs:83-140 with an alias table over the 1024
+ *     outcomes o = q | s << 8:
+ *       P(q)      = P(floor(N(mean,10)) saturated to u8 == q)
+ *       p_q       = P(gen::<f32>() > accuracy(q)) = (2^24 - 1 - t) / 2^24,
+ *                   t = min(floor(accuracy(q) * 2^24), 2^24 - 1)   (the reference's 24-bit test)
+ *       w(q, 0)   = P(q) (1 - p_q),   w(q, s) = P(q) p_q / 3 for s = 1, 2, 3
+ *       idx = W >> 22, frac = W & 0x3fffff, o = frac < thr22[idx] ? idx : alias[idx]
+ *   - s > 0 and the base is ACGT: the base becomes "ACGT"[(code + s) & 3] — each of
+ *     the three other bases with probability 1/3, as SliceRandom::choose does
+ *     (minimal_short.rs:121-128); non-ACGT bases are left alone.
  */
 #include <math.h>
 #include <string.h>
@@ -34,22 +38,29 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* table[i] = thr17 | alias << 24 with thr17 in [0, 65536] */
-void orc_philox_phred_table(uint8_t mean_phred, uint32_t table[256]) {
-  double P[256], cdf_prev = 0.0;
+/* table[i] = thr22 | alias << 22 with thr22 in [0, 2^22 - 1], i = q | s << 8 */
+void orc_philox_joint_table(uint8_t mean_phred, uint32_t table[1024]) {
+  enum { N = 1024 };
+  double odds[N];
+  int alias[N], smalls[N], bigs[N];
+  double cdf_prev = 0.0;
   const double mean = (double)mean_phred;
   for (int q = 0; q < 256; q++) {
     /* P(floor(mean + 10 z) saturated == q) */
     double upper = (q == 255) ? 1.0 : 0.5 * erfc(-(((double)(q + 1) - mean) / 10.0) / 1.4142135623730951);
-    P[q] = upper - cdf_prev;
-    if (P[q] < 0.0) P[q] = 0.0;
+    double P = upper - cdf_prev;
+    if (P < 0.0) P = 0.0;
     cdf_prev = upper;
+    float tf = floorf(orc_convert_phred_to_accuracy((uint8_t)q) * 16777216.0f);
+    double t = tf > 16777215.0f ? 16777215.0 : (double)tf;
+    double pq = (16777215.0 - t) / 16777216.0;
+    odds[q] = P * (1.0 - pq) * (double)N;
+    for (int s = 1; s < 4; s++) odds[q + 256 * s] = P * pq / 3.0 * (double)N;
   }
   /* Vose alias method, worklists as LIFO stacks filled in increasing index order */
-  double odds[256];
-  int alias[256], smalls[256], bigs[256], ns = 0, nb = 0;
-  for (int i = 0; i < 256; i++) { odds[i] = P[i] * 256.0; alias[i] = i; }
-  for (int i = 0; i < 256; i++) { if (odds[i] < 1.0) smalls[ns++] = i; else bigs[nb++] = i; }
+  int ns = 0, nb = 0;
+  for (int i = 0; i < N; i++) alias[i] = i;
+  for (int i = 0; i < N; i++) { if (odds[i] < 1.0) smalls[ns++] = i; else bigs[nb++] = i; }
   while (ns > 0 && nb > 0) {
     int s = smalls[--ns], b = bigs[--nb];
     alias[s] = b;
@@ -58,37 +69,34 @@ void orc_philox_phred_table(uint8_t mean_phred, uint32_t table[256]) {
   }
   while (ns > 0) odds[smalls[--ns]] = 1.0;
   while (nb > 0) odds[bigs[--nb]] = 1.0;
-  for (int i = 0; i < 256; i++) {
-    double t = floor(odds[i] * 65536.0);
-    uint32_t thr = t >= 65536.0 ? 65536u : (t <= 0.0 ? 0u : (uint32_t)t);
-    table[i] = thr | ((uint32_t)alias[i] << 24);
+  for (int i = 0; i < N; i++) {
+    double t = floor(odds[i] * 4194304.0);
+    uint32_t thr = t >= 4194303.0 ? 4194303u : (t <= 0.0 ? 0u : (uint32_t)t);
+    table[i] = thr | ((uint32_t)alias[i] << 22);
   }
 }
 
 /* One read: qualities for bases [0, len) and the mutated copy of `seq` (forward-strand slice order). */
 void orc_philox_read(const simmr_error_profile* p, const uint8_t* seq, uint64_t len, uint64_t key64,
                      uint8_t* qual_out, uint8_t* seq_out) {
-  uint32_t table[256];
-  orc_philox_phred_table(p->mean_phred, table);
+  static _Thread_local uint32_t table[1024];
+  static _Thread_local int table_for = -1;
+  if (table_for != (int)p->mean_phred) { orc_philox_joint_table(p->mean_phred, table); table_for = (int)p->mean_phred; }
   const uint32_t key[2] = {(uint32_t)key64, (uint32_t)(key64 >> 32)};
   uint32_t w[4] = {0, 0, 0, 0};
   for (uint64_t b = 0; b < len; b++) {
-    if ((b & 1) == 0) {
-      const uint32_t ctr[4] = {(uint32_t)(b >> 1), 0u, 0x73696D6Du, 0x72000001u};
+    if ((b & 3) == 0) {
+      const uint32_t ctr[4] = {(uint32_t)(b >> 2), 0u, 0x73696D6Du, 0x72000001u};
       orc_philox4x32_10(ctr, key, w);
     }
-    const uint32_t A = w[(b & 1) * 2], B = w[(b & 1) * 2 + 1];
-    const uint32_t e = table[A >> 24];
-    const uint32_t q = (((A >> 8) & 0xffffu) < (e & 0x1ffffu)) ? (A >> 24) : (e >> 24);
+    const uint32_t W = w[b & 3];
+    const uint32_t e = table[W >> 22];
+    const uint32_t o = ((W & 0x3fffffu) < (e & 0x3fffffu)) ? (W >> 22) : (e >> 22);
+    const uint32_t q = o & 0xffu, sft = o >> 8;
     qual_out[b] = (uint8_t)q;
     uint8_t nt = seq[b];
-    const uint32_t thr = (uint32_t)floorf(orc_convert_phred_to_accuracy((uint8_t)q) * 16777216.0f);
     int code = nt == 'A' ? 0 : nt == 'C' ? 1 : nt == 'G' ? 2 : nt == 'T' ? 3 : -1;
-    if ((B >> 8) > thr && code >= 0) {
-      uint32_t k = (((((A & 0xffu) << 8) | (B & 0xffu)) * 3u) >> 16);
-      uint32_t alt = k + (k >= (uint32_t)code ? 1u : 0u);
-      nt = (uint8_t)"ACGT"[alt];
-    }
+    if (sft != 0 && code >= 0) nt = (uint8_t)"ACGT"[((uint32_t)code + sft) & 3u];
     seq_out[b] = nt;
   }
 }

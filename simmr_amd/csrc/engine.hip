@@ -317,18 +317,29 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
       return e->fail(SIMMR_EINVAL, "negative standard deviation");
   }
   if (p->rng_mode == SIMMR_RNG_PHILOX && (p->kind == SIMMR_MINIMAL_SHORT || p->kind == SIMMR_MINIMAL_LONG)) {
-    // Phred alias table: P(floor(N(mean, 10)) saturated to u8 == q), Vose's method with LIFO
-    // worklists filled in increasing index order; entry = thr17 | alias << 24
-    double P[256], prev = 0.0, odds[256];
-    int alias[256], smalls[256], bigs[256], ns = 0, nb = 0;
+    // Joint (Phred, substitution) alias table over the 1024 outcomes o = q | s << 8:
+    // w(q,0) = P(q)(1 - p_q), w(q,s) = P(q) p_q / 3; P(q) = P(floor(N(mean, 10)) saturated to u8 == q),
+    // p_q = the probability of the reference's 24-bit test gen::<f32>() > accuracy(q).  Vose's method
+    // with LIFO worklists filled in increasing index order; entry = thr22 | alias << 22.
+    constexpr int N = 1024;
+    std::vector<double> odds(N);
+    std::vector<int> alias(N), smalls(N), bigs(N);
+    double prev = 0.0;
+    int ns = 0, nb = 0;
     for (int q = 0; q < 256; q++) {
       const double upper = q == 255 ? 1.0 : 0.5 * erfc(-(((double)(q + 1) - (double)p->mean_phred) / 10.0) / 1.4142135623730951);
-      P[q] = upper - prev;
-      if (P[q] < 0.0) P[q] = 0.0;
+      double P = upper - prev;
+      if (P < 0.0) P = 0.0;
       prev = upper;
+      const float acc = 1.0f - powf(10.0f, -((float)q / 10.0f));  // util.rs:69-71,96-98
+      const float tf = floorf(acc * 16777216.0f);
+      const double t = tf > 16777215.0f ? 16777215.0 : (double)tf;
+      const double pq = (16777215.0 - t) / 16777216.0;
+      odds[q] = P * (1.0 - pq) * (double)N;
+      for (int sft = 1; sft < 4; sft++) odds[q + 256 * sft] = P * pq / 3.0 * (double)N;
     }
-    for (int i = 0; i < 256; i++) { odds[i] = P[i] * 256.0; alias[i] = i; }
-    for (int i = 0; i < 256; i++) { if (odds[i] < 1.0) smalls[ns++] = i; else bigs[nb++] = i; }
+    for (int i = 0; i < N; i++) alias[i] = i;
+    for (int i = 0; i < N; i++) { if (odds[i] < 1.0) smalls[ns++] = i; else bigs[nb++] = i; }
     while (ns > 0 && nb > 0) {
       const int sm = smalls[--ns], bg = bigs[--nb];
       alias[sm] = bg;
@@ -337,21 +348,18 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
     }
     while (ns > 0) odds[smalls[--ns]] = 1.0;
     while (nb > 0) odds[bigs[--nb]] = 1.0;
-    std::vector<uint32_t> table(256);
-    for (int i = 0; i < 256; i++) {
-      const double t = floor(odds[i] * 65536.0);
-      const uint32_t thr = t >= 65536.0 ? 65536u : (t <= 0.0 ? 0u : (uint32_t)t);
-      table[i] = thr | ((uint32_t)alias[i] << 24);
+    std::vector<uint32_t> table(N);
+    d.philox_qmax = 0;
+    for (int i = 0; i < N; i++) {
+      const double t = floor(odds[i] * 4194304.0);
+      const uint32_t thr = t >= 4194303.0 ? 4194303u : (t <= 0.0 ? 0u : (uint32_t)t);
+      table[i] = thr | ((uint32_t)alias[i] << 22);
+      if (thr > 0 && (uint32_t)(i & 255) > d.philox_qmax) d.philox_qmax = (uint32_t)(i & 255);
+      if ((uint32_t)(alias[i] & 255) > d.philox_qmax) d.philox_qmax = (uint32_t)(alias[i] & 255);
     }
     int rc = upload_vec(e, e->ph_table, table);
     if (rc || (rc = sync_check(e, "philox table upload"))) return rc;
     d.philox_phred = e->ph_table.as<uint32_t>();
-    d.philox_qmax = 0;
-    for (int i = 0; i < 256; i++) {
-      const uint32_t thr = table[i] & 0x1ffffu;
-      if (thr > 0 && (uint32_t)i > d.philox_qmax) d.philox_qmax = (uint32_t)i;
-      if (thr < 65536u && (uint32_t)alias[i] > d.philox_qmax) d.philox_qmax = (uint32_t)alias[i];
-    }
   }
   *out = d;
   return SIMMR_OK;

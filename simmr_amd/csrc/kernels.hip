@@ -1570,20 +1570,26 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
 // 9. Emit, counter mode (SIMMR_RNG_PHILOX — the design BASELINE.json's north_star
 //    prescribes for the per-base draws; statistical parity).
 //
-// Philox4x32-10 keyed by the read's Phred seed, counter = base index / 2: no
-// draw depends on another, so the work item is "16 consecutive bases of one
-// read".  A workgroup takes 64 units (128 mates, or 64 long reads), writes one
-// record per read to LDS (key, output offset, source position, length) together
-// with the prefix of their item counts, and deals the items to its 256 lanes:
+// Philox4x32-10 keyed by the read's Phred seed, counter = base index / 4, one
+// output word per base.  That word draws the Phred score and the substitution
+// together from their joint law with one alias-table lookup over the 1024
+// outcomes (q, s): s = 0 no substitution, s = 1..3 the base becomes
+// "ACGT"[(code + s) & 3] (oracle/philox.c states the law).  No draw depends on
+// another, so the work item is "16 consecutive bases of one read".  A
+// workgroup takes 64 units (128 mates, or 64 long reads), writes one record per
+// read to LDS (key, output offset, source position, length) together with the
+// prefix of their item counts, and deals the items to its 256 lanes:
 // consecutive lanes hold consecutive groups, so a wave's 16-byte quality and
 // base stores are contiguous.  The kernel is bound by integer VALU issue (one
 // wave64 instruction per 4 cycles per SIMD), so everything below is written to
 // minimise the instruction count per base:
 //   * v_mad_u64_u32 gives both halves of a Philox product, v_bitop3_b32 the
-//     three-way xor of a round (4 instructions per round);
-//   * one 16-byte LDS entry per Phred bin holds the alias threshold and, for
-//     either outcome, (substitution threshold << 8 | q): one ds_read_b128, one
-//     select, and the 24-bit substitution test is a single compare;
+//     three-way xor of a round (4 instructions per round, 10 per word);
+//   * one 16-byte LDS entry per outcome column holds the alias threshold and,
+//     for either result, (enc(q) << 8 | s): one ds_read_b96, one compare, one
+//     select; v_alignbit_b32 shifts s into the packed substitution word and
+//     v_perm_b32 drops the quality byte into place;
+//   * the substitutions are one SWAR add modulo 4 on the packed 2-bit codes;
 //   * a branch-free binary search over the item prefix finds the read.
 // ===========================================================================
 SIMMR_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
@@ -1646,9 +1652,10 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
               const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
               const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
               uint32_t qual_offset, const Tables* __restrict__ T, unsigned long long* __restrict__ counters) {
-  // per Phred bin i: x = alias threshold (17 bits), y = thr[i] << 8 | enc(i), z = thr[alias] << 8 | enc(alias),
-  // enc(q) = (q + qual_offset) as u8 (util.rs:46-50)
-  __shared__ uint4 ptab[256];
+  // per outcome column i = q | s << 8: x = alias threshold << 10 (compared with W << 10),
+  // y = result i, z = result alias(i), both as enc(q) << 8 | s with enc(q) = (q + qual_offset) as u8
+  // (util.rs:46-50)
+  __shared__ uint4 jtab[1024];
   __shared__ uint32_t asc[256];  // four 2-bit codes -> four ASCII bytes
   __shared__ uint64_t r_key[PHILOX_READS], r_dst[PHILOX_READS], r_src[PHILOX_READS];
   __shared__ const uint32_t* r_packed[PHILOX_READS];
@@ -1658,15 +1665,13 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ uint32_t lds4[4];
   {
     const uint32_t t = threadIdx.x;
-    const uint32_t e = prof.philox_phred[t];
-    const uint32_t al = e >> 24;
-    // substitution iff (B >> 8) > floor(accuracy(q) * 2^24) (the reference's 24-bit test,
-    // minimal_short.rs:118); thresholds of 2^24 (accuracy rounds to 1.0f) can never be exceeded,
-    // and neither can 2^24 - 1, which fits the packed form
-    uint32_t ti = (uint32_t)floorf(T->acc[t] * 16777216.0f), ta = (uint32_t)floorf(T->acc[al] * 16777216.0f);
-    ti = ti > 0xffffffu ? 0xffffffu : ti;
-    ta = ta > 0xffffffu ? 0xffffffu : ta;
-    ptab[t] = make_uint4(e & 0x1ffffu, (ti << 8) | ((t + qual_offset) & 0xffu), (ta << 8) | ((al + qual_offset) & 0xffu), 0u);
+#pragma unroll
+    for (uint32_t i = t; i < 1024u; i += 256u) {
+      const uint32_t e = prof.philox_phred[i];
+      const uint32_t al = e >> 22;
+      jtab[i] = make_uint4((e & 0x3fffffu) << 10, (((i + qual_offset) & 0xffu) << 8) | (i >> 8),
+                           (((al + qual_offset) & 0xffu) << 8) | (al >> 8), 0u);
+    }
     const uint32_t acgt = 0x54474341u;  // "ACGT"
     asc[t] = ((acgt >> (8 * (t & 3u))) & 0xffu) | (((acgt >> (8 * ((t >> 2) & 3u))) & 0xffu) << 8) |
              (((acgt >> (8 * ((t >> 4) & 3u))) & 0xffu) << 16) | (((acgt >> (8 * (t >> 6))) & 0xffu) << 24);
@@ -1716,30 +1721,28 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       uint32_t codes = fetch_codes16(r_packed[r], (int64_t)src);
       uint32_t exc = 0u;
       if (HAS_EXC) { const uint32_t* mk = r_mask[r]; if (mk) exc = fetch_mask16(mk, (int64_t)src); }
-      // per base: Phred (alias table), substitution test bit, replacement rank k; all packed
-      uint32_t qr[4] = {0, 0, 0, 0}, ks = 0, mmask = 0;
+      // per base: one word -> (Phred, substitution shift s); qualities packed as bytes, s as 2-bit fields
+      uint32_t qr[4] = {0, 0, 0, 0}, ss = 0;
 #pragma unroll
-      for (int c = 7; c >= 0; c--) {
+      for (int c = 0; c < 4; c++) {
         uint32_t w[4];
-        philox4x32_10((b0 >> 1) + (uint32_t)c, (uint32_t)key, (uint32_t)(key >> 32), w);
+        philox4x32_10((b0 >> 2) + (uint32_t)c, (uint32_t)key, (uint32_t)(key >> 32), w);
 #pragma unroll
-        for (int h = 1; h >= 0; h--) {
-          const int j = 2 * c + h;  // base b0 + j; descending, so base j ends at bit j of mmask
-          const uint32_t A = w[2 * h], B = w[2 * h + 1];
-          const uint4 e = ptab[A >> 24];
-          const uint32_t x = (__builtin_amdgcn_ubfe(A, 8, 16) < e.x) ? e.y : e.z;  // thr[q] << 8 | enc(q)
-          // mmask = mmask << 1 | ((B >> 8) > thr[q]): compare, then shift the carry in
-          asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mmask) : "v"(B & 0xffffff00u), "v"(x) : "vcc");
-          // byte (j & 3) of qr[j >> 2] = enc(q)
-          qr[j >> 2] = __builtin_amdgcn_perm(x, qr[j >> 2], 0x03020100u ^ (0x04u << (8 * (j & 3))) ^ ((uint32_t)(j & 3) << (8 * (j & 3))));
-          const uint32_t c16 = __builtin_amdgcn_perm(A, B, 0x0c0c0400u);  // ((A & 0xff) << 8) | (B & 0xff)
-          ks |= ((c16 * 3u) >> 16) << (2 * j);
+        for (int h = 0; h < 4; h++) {
+          const int j = 4 * c + h;  // base b0 + j; ascending, so base j ends at bits 2j of ss
+          const uint32_t W = w[h];
+          const uint4 e = jtab[W >> 22];
+          const uint32_t x = ((W << 10) < e.x) ? e.y : e.z;  // enc(q) << 8 | s
+          ss = __builtin_amdgcn_alignbit(x, ss, 2);
+          // byte (j & 3) of qr[j >> 2] = enc(q) = byte 1 of x
+          qr[j >> 2] = __builtin_amdgcn_perm(x, qr[j >> 2], 0x03020100u ^ ((uint32_t)((j & 3) ^ 5) << (8 * (j & 3))));
         }
       }
-      // counters over the live bases of the item
+      // only live ACGT bases mutate (minimal_short.rs:120-128)
       const uint32_t live = n >= 16u ? 0xffffu : ((1u << n) - 1u);
-      mmask &= ~exc & live;  // only ACGT bases mutate (minimal_short.rs:120-128)
-      n_subst += __builtin_popcount(mmask);
+      if (HAS_EXC) ss &= ~spread16(exc);
+      if (n < 16u) ss &= (1u << (2u * n)) - 1u;
+      n_subst += __builtin_popcount((ss | (ss >> 1)) & 0x55555555u);
       n_acgt += __builtin_popcount(~exc & live);
       uint32_t qs = 0;
 #pragma unroll
@@ -1749,16 +1752,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       if (!q_nowrap) {
         for (uint32_t j = 0; j < n; j++) n_wrap += ((qr[j >> 2] >> (8 * (j & 3u))) & 0xffu) < qoff ? 1u : 0u;
       }
-      // substitutions in the 2-bit code domain: alt = k + (k >= code), 16 bases at once
-      {
-        const uint32_t ce = codes & 0x33333333u, co = (codes >> 2) & 0x33333333u;
-        const uint32_t ke = ks & 0x33333333u, ko = (ks >> 2) & 0x33333333u;
-        const uint32_t ae = ke + ((((ke | 0x44444444u) - ce) >> 2) & 0x11111111u);
-        const uint32_t ao = ko + ((((ko | 0x44444444u) - co) >> 2) & 0x11111111u);
-        const uint32_t alt = ae | (ao << 2);
-        const uint32_t m32 = spread16(mmask);
-        codes = (codes & ~m32) | (alt & m32);
-      }
+      // substitutions in the 2-bit code domain: code' = (code + s) mod 4, 16 bases at once
+      codes = (((codes & 0x33333333u) + (ss & 0x33333333u)) & 0x33333333u) |
+              (((codes & 0xccccccccu) + (ss & 0xccccccccu)) & 0xccccccccu);
       // qualities are already offset-encoded, forward order
       const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
       uint8_t* qd = qual + off + b0;

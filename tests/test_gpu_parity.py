@@ -263,6 +263,20 @@ def test_philox_mode_edge_shapes(engine, oracle, genome_multi, L, I, q):
     assert_same(dev.to_host(), ora.trimmed())
 
 
+def test_philox_mode_quality_offset_wraps(engine, oracle, genome_multi):
+    """q + 33 is an unchecked u8 add in the reference (util.rs:46-50): with a mean Phred of 240 most
+    encoded qualities wrap; the bytes and the QUAL_SUM counter (raw Phred) must still be right."""
+    prof = MinimalShortErrorProfile(read_length=37, insert_size=50, mean_phred_score=240, rng_mode=_abi.RNG_PHILOX).pod()
+    for qoff in (33, 0, 200):
+        engine.counters_reset()
+        dev = engine.simulate_pe_reads_from_genome(1, prof, 2000, 3, qual_offset=qoff)
+        ora = _oracle.simulate_pe(oracle, genome_multi, prof, 2000, 3, qual_offset=qoff)
+        d, o = dev.to_host(), ora.trimmed()
+        assert_same(d, o)
+        raw = (d["qual"].astype(np.int64) - qoff) % 256
+        assert engine.counters()[_abi.CNT_QUAL_SUM] == raw.sum()
+
+
 def test_philox_mode_exceptions(engine, oracle):
     rng = np.random.default_rng(21)
     seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 30000)].copy()

@@ -111,21 +111,33 @@ def test_philox4x32_10_random123_vectors(oracle):
     assert ph([0xffffffff] * 4, [0xffffffff] * 2) == "408f276d 41c83b0e a20bc7c6 6d5451fd"
     assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         "d16cfe09 94fdcceb 5001e420 24126ea1"
-    # Phred alias table: exact probabilities of floor(N(30, 10)) saturated to u8
-    t = (C.c_uint32 * 256)()
-    oracle.orc_philox_phred_table(30, t)
+    # joint (Phred, substitution) alias table: implied outcome probabilities vs the analytic law
+    t = (C.c_uint32 * 1024)()
+    oracle.orc_philox_joint_table(30, t)
     tab = np.array(list(t), dtype=np.uint64)
-    thr, al = (tab & 0x1ffff).astype(float), (tab >> 24).astype(int)
-    P = np.zeros(256)
-    for i in range(256):
-        P[i] += thr[i] / 65536 / 256
-        P[al[i]] += (1 - thr[i] / 65536) / 256
+    thr, al = (tab & 0x3fffff).astype(float), (tab >> 22).astype(int)
+    P = np.zeros(1024)
+    for i in range(1024):
+        P[i] += thr[i] / 4194304 / 1024
+        P[al[i]] += (1 - thr[i] / 4194304) / 1024
+    assert abs(P.sum() - 1) < 1e-12
     from math import erf, sqrt
     cdf = lambda x: 0.5 * (1 + erf((x - 30.0) / 10.0 / sqrt(2)))
+    Pq = P.reshape(4, 256).sum(axis=0)
     for q in (0, 1, 10, 29, 30, 45, 70):
         want = cdf(1) if q == 0 else cdf(q + 1) - cdf(q)
-        assert abs(P[q] - want) < 2.0 / 65536 / 256 * 256, q
-    assert abs((P * np.arange(256)).sum() - 29.5) < 0.01
+        assert abs(Pq[q] - want) < 64 * 2.0 ** -32, q  # floor() of each donated column: <= 2^-32 each
+    assert abs((Pq * np.arange(256)).sum() - 29.5) < 0.01
+    # substitution probability given q is the reference's 24-bit test; the three shifts are equally likely
+    for q in (0, 3, 10, 20, 30, 40):
+        acc = np.float32(1.0) - np.float32(10.0) ** np.float32(-(np.float32(q) / np.float32(10.0)))
+        tq = min(np.floor(np.float32(acc) * np.float32(16777216.0)), 16777215.0)
+        pq = (16777215.0 - float(tq)) / 16777216.0
+        sub = P[q + 256], P[q + 512], P[q + 768]
+        assert abs(sum(sub) / Pq[q] - pq) < 1e-3 * pq + 3 * 2.0 ** -32 / Pq[q], q
+        assert max(sub) - min(sub) <= 2 * 2.0 ** -32, q
+    rate = P[256:].sum()
+    assert abs(rate / 0.013404 - 1) < 1e-3, rate
 
 
 # ---- reference unit tests restated ------------------------------------------
