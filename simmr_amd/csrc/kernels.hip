@@ -1574,7 +1574,7 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
 // output word per base.  That word draws the Phred score and the substitution
 // together from their joint law with one alias-table lookup over the 1024
 // outcomes (q, s): s = 0 no substitution, s = 1..3 the base becomes
-// "ACGT"[(code + s) & 3] (oracle/philox.c states the law).  No draw depends on
+// "ACGT"[(code + s) & 3] (DESIGN.md section 4 states the law).  No draw depends on
 // another, so the work item is "16 consecutive bases of one read".  A
 // workgroup takes 64 units (128 mates, or 64 long reads), writes one record per
 // read to LDS (key, output offset, source position, length) together with the
