@@ -261,7 +261,7 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
   if ((rc = sync_check(e, "custom table upload"))) return rc;  // the host vectors go out of scope
   ProfileDev d{};
   d.kind = SIMMR_K_CUSTOM;
-  d.rng_mode = p->rng_mode;
+  d.rng_mode = SIMMR_RNG_REFERENCE;  // checked by the caller: the empirical PDFs have no counter mode
   // custom_short.rs:535-538: (2.0 * read_length_mean + insert_size_mean) as u16 (saturating)
   const double req = 2.0 * m.read_length_mean + m.insert_size_mean;
   d.required = !(req == req) || req <= 0.0 ? 0u : (req >= 65535.0 ? 65535u : (uint32_t)req);
@@ -280,8 +280,10 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
 int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, ProfileDev* out) {
   if (!p) return e->fail(SIMMR_EINVAL, "profile is NULL");
   if (p->kind > SIMMR_CUSTOM) return e->fail(SIMMR_EINVAL, "unknown profile kind %u", p->kind);
-  if (p->kind == SIMMR_CUSTOM) return make_custom_profile(e, p, want_long, out);
   if (p->rng_mode > SIMMR_RNG_PHILOX) return e->fail(SIMMR_EINVAL, "unknown rng_mode %u", p->rng_mode);
+  if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_CUSTOM)
+    return e->fail(SIMMR_EINVAL, "SIMMR_RNG_PHILOX covers the Normal(mean, 10) Phred profiles (minimal-short, minimal-long)");
+  if (p->kind == SIMMR_CUSTOM) return make_custom_profile(e, p, want_long, out);
   if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_PERFECT_LONG)
     return e->fail(SIMMR_EINVAL, "SIMMR_RNG_PHILOX covers the Normal(mean, 10) Phred profiles (minimal-short, minimal-long)");
   const bool is_long = p->kind == SIMMR_PERFECT_LONG || p->kind == SIMMR_MINIMAL_LONG;
@@ -800,9 +802,13 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
   const bool seeds2 = paired && e->prof.kind != SIMMR_K_PERFECT_SHORT;
   PlanArrays pl = plan_arrays(e, seeds2);
   const uint32_t* u_genome = paired ? nullptr : e->u_genome.as<uint32_t>();
-  hipLaunchKernelGGL(k_write_meta, dim3(grid_for(n_units + 1, 256)), dim3(256), 0, e->stream,
-                     paired ? 1u : 0u, n_units, e->plan_first, read_id_base, e->plan_genome, pl,
-                     e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome, out_cols(out));
+  // the Philox emit kernel writes the metadata columns and the plan counters itself
+  const bool fused = n_units > 0 && e->prof.kind != SIMMR_K_PERFECT_SHORT && e->prof.kind != SIMMR_K_CUSTOM &&
+                     e->prof.rng_mode == SIMMR_RNG_PHILOX;
+  if (!fused)
+    hipLaunchKernelGGL(k_write_meta, dim3(grid_for(n_units + 1, 256)), dim3(256), 0, e->stream,
+                       paired ? 1u : 0u, n_units, e->plan_first, read_id_base, e->plan_genome, pl,
+                       e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome, out_cols(out));
   unsigned long long* counters = e->d_counters.as<unsigned long long>();
   HIP_TRY(e, hipEventRecord(e->ev_c, e->stream));
   if (n_units > 0) {
@@ -822,7 +828,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
                          e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                          e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
-                         out->qual_offset, e->d_tables.as<Tables>(), counters);
+                         out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
     } else if (e->prof.kind == SIMMR_K_CUSTOM) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
       const uint32_t grid = (uint32_t)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 16);
@@ -861,7 +867,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
     }
   }
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
-  if (n_units > 0) {
+  if (n_units > 0 && !fused) {
     const bool perfect = e->prof.kind == SIMMR_K_PERFECT_SHORT;
     const bool acgt_all = perfect && !e->genomes[e->plan_genome].has_exc;
     hipLaunchKernelGGL(k_count_plan, dim3(std::min<uint32_t>(grid_for(n_units, 256), (uint32_t)e->n_cu * 4)), dim3(256), 0, e->stream, paired ? 1u : 0u,

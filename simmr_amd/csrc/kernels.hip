@@ -1651,7 +1651,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
               const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
               const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
-              uint32_t qual_offset, const Tables* __restrict__ T, unsigned long long* __restrict__ counters) {
+              uint32_t qual_offset, uint64_t first_unit, uint32_t read_id_base, OutCols o,
+              unsigned long long* __restrict__ counters) {
   // per outcome column i = q | s << 8: x = alias threshold << 10 (compared with W << 10),
   // y = result i, z = result alias(i), both as enc(q) << 8 | s with enc(q) = (q + qual_offset) as u8
   // (util.rs:46-50)
@@ -1678,6 +1679,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   }
   uint64_t qsum = 0, n_live = 0;  // qsum adds encoded qualities; the offset is taken off at the end
   uint32_t n_subst = 0, n_acgt = 0, n_wrap = 0;
+  uint64_t p_bases = 0;  // plan-derived counters, gathered while the read records are written
+  uint32_t p_redrawn = 0, p_seedsubst = 0;
+  const uint64_t n_reads = paired ? 2 * n_units : n_units;
   const uint32_t qoff = qual_offset & 0xffu;
   const bool q_nowrap = qoff + prof.philox_qmax <= 255u;  // then no encoded quality wraps
   const uint32_t rpu = paired ? 2u : 1u;
@@ -1695,12 +1699,36 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint32_t L = pl.len[u];
       g = (L + 15u) >> 4;
       const GenomeDev* G = genomes + (u_genome ? u_genome[u] : genome_const);
+      const uint32_t contig = u_contig[u];
+      const uint64_t dst = u_off[u] + (rev ? L : 0u);
+      const uint64_t pos = rev ? pl.b[u] : pl.a[u];  // first source base of this read on the contig
       r_key[t] = rev ? pl.qs2[u] : u_seed[u];
-      r_dst[t] = u_off[u] + (rev ? L : 0u);
-      r_src[t] = G->contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]);
+      r_dst[t] = dst;
+      r_src[t] = G->contigs[contig].base + pos;
       r_len[t] = L | (rev << 31);
       r_packed[t] = G->packed;
       r_mask[t] = (HAS_EXC && G->has_exc) ? G->mask : nullptr;
+      // metadata columns of this read (the other emit kernels leave them to k_write_meta)
+      const uint64_t rd = paired ? 2 * u + rev : u;
+      const uint32_t fl = pl.flags[u];
+      o.seq_off[rd] = dst;
+      if (rd + 1 == n_reads) o.seq_off[n_reads] = u_off[n_units];  // closing CSR offset
+      if (paired) {
+        if (o.start) o.start[rd] = rev ? pos + L : pos;  // simulate.rs:289,295
+        if (o.end) o.end[rd] = rev ? pos : pos + L;      // simulate.rs:290,296
+      } else {
+        if (o.start) o.start[rd] = pos;                  // simulate.rs:515
+        if (o.end) o.end[rd] = pl.b[u];                  // simulate.rs:516
+      }
+      if (o.contig) o.contig[rd] = contig;
+      if (o.genome) o.genome[rd] = u_genome ? u_genome[u] : genome_const;
+      if (o.read_id) o.read_id[rd] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
+      if (o.flags) o.flags[rd] = (paired && !rev) ? 0 : (uint8_t)fl;
+      if (!rev) {
+        p_bases += pl.bytes[u];
+        p_redrawn += (fl & SIMMR_FLAG_REDRAWN) ? 1u : 0u;
+        p_seedsubst += ((fl & SIMMR_FLAG_QSEED_SUBST) ? 1u : 0u) + ((fl & SIMMR_FLAG_MSEED_SUBST) ? 1u : 0u);
+      }
     }
     uint32_t n_items;
     const uint32_t ex = wg_exclusive_scan_u32(g, lds4, &n_items);
@@ -1792,11 +1820,18 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     n_subst += __shfl_down(n_subst, d, 64);
     n_acgt += __shfl_down(n_acgt, d, 64);
     qsum += __shfl_down(qsum, d, 64);
+    p_bases += __shfl_down(p_bases, d, 64);
+    p_redrawn += __shfl_down(p_redrawn, d, 64);
+    p_seedsubst += __shfl_down(p_seedsubst, d, 64);
   }
   if ((threadIdx.x & 63u) == 0 && counters) {
     atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
     atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
     atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
+    if (p_bases) atomicAdd(&counters[SIMMR_CNT_BASES], (unsigned long long)p_bases);
+    if (p_redrawn) atomicAdd(&counters[SIMMR_CNT_REDRAWN], (unsigned long long)p_redrawn);
+    if (p_seedsubst) atomicAdd(&counters[SIMMR_CNT_SEED_SUBST], (unsigned long long)p_seedsubst);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[SIMMR_CNT_READS], (unsigned long long)n_reads);
   }
 }
 

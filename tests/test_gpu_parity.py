@@ -294,6 +294,14 @@ def test_philox_mode_exceptions(engine, oracle):
     with pytest.raises(SimmrError) as ei:
         engine.long_plan([3], [5], prof, 1)
     assert ei.value.code == _abi.EINVAL
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    keep = CustomShortErrorProfile(_model.synthetic_short_model(n_positions=40, seed=5))
+    cp = keep.pod()
+    cp.rng_mode = _abi.RNG_PHILOX  # empirical PDFs have no counter mode either
+    with pytest.raises(SimmrError) as ei:
+        engine.pe_plan(3, cp, 10, 1)
+    assert ei.value.code == _abi.EINVAL
 
 
 def test_philox_mode_tolerances(engine, genome_1m):
