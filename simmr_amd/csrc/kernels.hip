@@ -678,38 +678,44 @@ SIMMR_DEV void gather_piece(const GenomeDev& G, const PieceSrc& s, uint32_t k, u
 
 #define PERFECT_GROUP 256u /* reads per workgroup iteration: 256*L is a multiple of 16 */
 
-SIMMR_DEV PieceSrc perfect_src(const GenomeDev& G, const PlanArrays& pl,
-                               const uint32_t* __restrict__ u_contig, uint64_t r, uint32_t L) {
-  const uint64_t u = r >> 1;
-  const uint64_t base = G.contigs[u_contig[u]].base;
-  PieceSrc s;
-  s.rev = (uint32_t)(r & 1u);
-  s.pos = (int64_t)(base + (s.rev ? pl.b[u] + L - 1 : pl.a[u]));
-  return s;
-}
-
+// A workgroup takes 256 consecutive reads (128 pairs): their 256*L output bytes start at a multiple
+// of 16, so the group is a whole number of aligned 16-byte chunks except at the end of the shard.
+// Each thread first writes the source position of one read to LDS (one coalesced pass over the plan
+// columns, one contig-table lookup per read instead of one per chunk); the chunk loop then needs
+// only LDS and the packed plane.  Chunk -> (read, offset) advances incrementally (no division).
 extern "C" __global__ void __launch_bounds__(256)
 k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
                   uint32_t L, PlanArrays pl, const uint32_t* __restrict__ u_contig,
                   uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_byte) {
+  __shared__ int64_t r_pos[PERFECT_GROUP];  // absolute base position of output byte 0's source
   const GenomeDev G = genomes[genome];
   const uint64_t n_reads = 2 * n_units;
   const uint64_t n_groups = (n_reads + PERFECT_GROUP - 1) / PERFECT_GROUP;
   const uint32_t q4 = qual_byte * 0x01010101u;
   const uint4 qv = make_uint4(q4, q4, q4, q4);
+  // this thread's chunks are cl = threadIdx.x + 256 j: byte lb = 16 cl advances by 4096 per step
+  const uint32_t step_r = 4096u / L, step_k = 4096u % L;
+  const uint32_t rl0 = (threadIdx.x << 4) / L, k00 = (threadIdx.x << 4) - rl0 * L;
   for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const uint64_t r_base = g * PERFECT_GROUP;
     const uint32_t n_in = (n_reads - r_base) < PERFECT_GROUP ? (uint32_t)(n_reads - r_base) : PERFECT_GROUP;
     const uint32_t gbytes = n_in * L;  // < 2^24
     const uint32_t n_chunks = (gbytes + 15u) >> 4;
     const uint64_t gbyte0 = r_base * L;  // multiple of 16
+    __syncthreads();  // the previous group's chunks are done with r_pos
+    if (threadIdx.x < n_in) {
+      const uint64_t r = r_base + threadIdx.x;
+      const uint64_t u = r >> 1;
+      const uint64_t base = G.contigs[u_contig[u]].base;
+      r_pos[threadIdx.x] = (int64_t)(base + ((r & 1u) ? pl.b[u] + L - 1 : pl.a[u]));  // mate 2: byte k comes from pos - k
+    }
+    __syncthreads();
+    uint32_t rl = rl0, k0 = k00;
     for (uint32_t cl = threadIdx.x; cl < n_chunks; cl += 256) {
       const uint32_t lb = cl << 4;
-      const uint32_t rl = lb / L;
-      const uint32_t k0 = lb - rl * L;
       const uint32_t na = (L - k0) < 16u ? (L - k0) : 16u;  // bytes taken from read r_base + rl
       uint32_t codes, exc;
-      gather_piece(G, perfect_src(G, pl, u_contig, r_base + rl, L), k0, codes, exc);
+      gather_piece(G, PieceSrc{r_pos[rl], rl & 1u}, k0, codes, exc);
       if (na < 16u) {
         // splice in the following read(s) (several only if L < 16)
         uint32_t filled = na, r = rl + 1;
@@ -717,7 +723,7 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64
         exc &= (1u << filled) - 1u;
         while (filled < 16u && r < n_in) {
           uint32_t c2, e2;
-          gather_piece(G, perfect_src(G, pl, u_contig, r_base + r, L), 0, c2, e2);
+          gather_piece(G, PieceSrc{r_pos[r], r & 1u}, 0, c2, e2);
           const uint32_t take = (16u - filled) < L ? (16u - filled) : L;
           if (take < 16u) { c2 &= (1u << (2 * take)) - 1u; e2 &= (1u << take) - 1u; }
           codes |= c2 << (2 * filled);
@@ -742,6 +748,9 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64
           qual[byte0 + i] = (uint8_t)qual_byte;
         }
       }
+      rl += step_r;
+      k0 += step_k;
+      if (k0 >= L) { k0 -= L; rl++; }
     }
   }
 }
