@@ -616,17 +616,18 @@ k_write_meta(uint32_t paired, uint64_t n_units, uint64_t first_unit, uint32_t re
 
 // 16 bases (32 bits of codes) starting at absolute base position p (may be
 // slightly negative: the plane has front padding).
+// The planes live in device memory: say so (a pointer that came out of a struct or out of LDS is a
+// generic pointer, and a flat load is slower than a global one).
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef const __attribute__((address_space(1))) u64_unaligned* global_u64_unaligned_ptr;
+SIMMR_DEV uint64_t load_plane_u64(const uint32_t* __restrict__ plane, int64_t word) {
+  return *(global_u64_unaligned_ptr)(plane + word);  // words `word` and `word + 1`, 4-byte aligned
+}
 SIMMR_DEV uint32_t fetch_codes16(const uint32_t* __restrict__ packed, int64_t p) {
-  int64_t wi = p >> 4;
-  uint32_t sh = (uint32_t)(p & 15) * 2u;
-  uint32_t lo = packed[wi], hi = packed[wi + 1];
-  return __builtin_amdgcn_alignbit(hi, lo, sh);
+  return (uint32_t)(load_plane_u64(packed, p >> 4) >> ((uint32_t)(p & 15) * 2u));
 }
 SIMMR_DEV uint32_t fetch_mask16(const uint32_t* __restrict__ mask, int64_t p) {
-  int64_t wi = p >> 5;
-  uint32_t sh = (uint32_t)(p & 31);
-  uint32_t lo = mask[wi], hi = mask[wi + 1];
-  return __builtin_amdgcn_alignbit(hi, lo, sh) & 0xffffu;
+  return (uint32_t)(load_plane_u64(mask, p >> 5) >> (uint32_t)(p & 31)) & 0xffffu;
 }
 // reverse the order of the sixteen 2-bit groups
 SIMMR_DEV uint32_t reverse_groups16(uint32_t x) {
@@ -677,6 +678,7 @@ SIMMR_DEV void gather_piece(const GenomeDev& G, const PieceSrc& s, uint32_t k, u
 }
 
 #define PERFECT_GROUP 256u /* reads per workgroup iteration: 256*L is a multiple of 16 */
+#define PERFECT_UNROLL 2
 
 // A workgroup takes 256 consecutive reads (128 pairs): their 256*L output bytes start at a multiple
 // of 16, so the group is a whole number of aligned 16-byte chunks except at the end of the shard.
@@ -711,13 +713,87 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64
     }
     __syncthreads();
     uint32_t rl = rl0, k0 = k00;
-    for (uint32_t cl = threadIdx.x; cl < n_chunks; cl += 256) {
+    if (L >= 16u) {
+      // A chunk has at most two pieces.  PERFECT_UNROLL chunks per thread are in flight at once: all their
+      // packed-plane loads are issued before the first is consumed.
+      for (uint32_t cl0 = threadIdx.x; cl0 < n_chunks; cl0 += 256 * PERFECT_UNROLL) {
+        uint64_t raw[PERFECT_UNROLL][2], rawm[PERFECT_UNROLL][2];
+        uint32_t sh[PERFECT_UNROLL][2], shm[PERFECT_UNROLL][2], crl[PERFECT_UNROLL], cna[PERFECT_UNROLL];
+#pragma unroll
+        for (int j = 0; j < PERFECT_UNROLL; j++) {
+          const uint32_t cl = cl0 + 256u * j;
+          crl[j] = rl;
+          cna[j] = (L - k0) < 16u ? (L - k0) : 16u;
+          raw[j][0] = raw[j][1] = rawm[j][0] = rawm[j][1] = 0;
+          sh[j][0] = sh[j][1] = shm[j][0] = shm[j][1] = 0;
+          if (cl < n_chunks) {
+#pragma unroll
+            for (int pc = 0; pc < 2; pc++) {
+              const uint32_t r = rl + pc;
+              if (pc == 1 && !(cna[j] < 16u && r < n_in)) continue;
+              const int64_t pos = r_pos[r];
+              const int64_t p = (r & 1u) ? pos - (int64_t)(pc ? 0u : k0) - 15 : pos + (int64_t)(pc ? 0u : k0);
+              raw[j][pc] = load_plane_u64(G.packed, p >> 4);
+              sh[j][pc] = (uint32_t)(p & 15) * 2u;
+              if (G.has_exc) {
+                rawm[j][pc] = load_plane_u64(G.mask, p >> 5);
+                shm[j][pc] = (uint32_t)(p & 31);
+              }
+            }
+          }
+          rl += step_r;
+          k0 += step_k;
+          if (k0 >= L) { k0 -= L; rl++; }
+        }
+#pragma unroll
+        for (int j = 0; j < PERFECT_UNROLL; j++) {
+          const uint32_t cl = cl0 + 256u * j;
+          if (cl >= n_chunks) continue;
+          uint32_t pc_codes[2], pc_exc[2];
+#pragma unroll
+          for (int pc = 0; pc < 2; pc++) {
+            uint32_t c = (uint32_t)(raw[j][pc] >> sh[j][pc]);
+            uint32_t m = G.has_exc ? ((uint32_t)(rawm[j][pc] >> shm[j][pc]) & 0xffffu) : 0u;
+            if ((crl[j] + pc) & 1u) {  // mate 2: complement-reverse in the code domain
+              c = ~reverse_groups16(c);
+              if (G.has_exc) { m = __builtin_bitreverse32(m) >> 16; c ^= spread16(m); }
+            }
+            pc_codes[pc] = c;
+            pc_exc[pc] = m;
+          }
+          uint32_t codes = pc_codes[0], exc = pc_exc[0];
+          const uint32_t na = cna[j];
+          if (na < 16u) {
+            codes = (codes & ((1u << (2 * na)) - 1u)) | (pc_codes[1] << (2 * na));
+            exc = (exc & ((1u << na) - 1u)) | (pc_exc[1] << na);
+          }
+          uint4 out;
+          out.x = expand4(codes & 0xffu, exc & 0xfu);
+          out.y = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
+          out.z = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu);
+          out.w = expand4(codes >> 24, (exc >> 12) & 0xfu);
+          const uint32_t lb = cl << 4;
+          const uint64_t byte0 = gbyte0 + lb;
+          if (lb + 16u <= gbytes) {
+            *reinterpret_cast<uint4*>(seq + byte0) = out;
+            *reinterpret_cast<uint4*>(qual + byte0) = qv;
+          } else {  // last partial chunk of the shard
+            const uint32_t words[4] = {out.x, out.y, out.z, out.w};
+            for (uint32_t i = 0; lb + i < gbytes; i++) {
+              seq[byte0 + i] = (uint8_t)(words[i >> 2] >> (8 * (i & 3)));
+              qual[byte0 + i] = (uint8_t)qual_byte;
+            }
+          }
+        }
+      }
+      continue;
+    }
+    for (uint32_t cl = threadIdx.x; cl < n_chunks; cl += 256) {  // L < 16: a chunk can span several reads
       const uint32_t lb = cl << 4;
       const uint32_t na = (L - k0) < 16u ? (L - k0) : 16u;  // bytes taken from read r_base + rl
       uint32_t codes, exc;
       gather_piece(G, PieceSrc{r_pos[rl], rl & 1u}, k0, codes, exc);
       if (na < 16u) {
-        // splice in the following read(s) (several only if L < 16)
         uint32_t filled = na, r = rl + 1;
         codes &= (1u << (2 * filled)) - 1u;
         exc &= (1u << filled) - 1u;
@@ -1233,7 +1309,6 @@ k_len_scatter(const uint32_t* __restrict__ len, uint64_t n, uint32_t shift, uint
   }
 }
 
-typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 
 SIMMR_DEV void store_bytes(uint8_t* __restrict__ p, uint64_t v, uint32_t n) {
   if (n == 8) {
