@@ -802,9 +802,9 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
   const bool seeds2 = paired && e->prof.kind != SIMMR_K_PERFECT_SHORT;
   PlanArrays pl = plan_arrays(e, seeds2);
   const uint32_t* u_genome = paired ? nullptr : e->u_genome.as<uint32_t>();
-  // the Philox emit kernel writes the metadata columns and the plan counters itself
-  const bool fused = n_units > 0 && e->prof.kind != SIMMR_K_PERFECT_SHORT && e->prof.kind != SIMMR_K_CUSTOM &&
-                     e->prof.rng_mode == SIMMR_RNG_PHILOX;
+  // the Philox and perfect-short emit kernels write the metadata columns and the plan counters themselves
+  const bool fused = n_units > 0 && (e->prof.kind == SIMMR_K_PERFECT_SHORT ||
+                                     (e->prof.kind != SIMMR_K_CUSTOM && e->prof.rng_mode == SIMMR_RNG_PHILOX));
   if (!fused)
     hipLaunchKernelGGL(k_write_meta, dim3(grid_for(n_units + 1, 256)), dim3(256), 0, e->stream,
                        paired ? 1u : 0u, n_units, e->plan_first, read_id_base, e->plan_genome, pl,
@@ -817,7 +817,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       const uint32_t grid = (uint32_t)std::min<uint64_t>(groups, (uint64_t)e->n_cu * 8);
       hipLaunchKernelGGL(k_emit_perfect_pe, dim3(grid), dim3(256), 0, e->stream, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, e->prof.read_length, pl, e->u_contig.as<uint32_t>(), out->seq,
-                         out->qual, 60u + out->qual_offset);
+                         out->qual, 60u + out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
     } else if (e->prof.rng_mode == SIMMR_RNG_PHILOX) {
       const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
       const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);

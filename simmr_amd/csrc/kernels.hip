@@ -688,7 +688,8 @@ SIMMR_DEV void gather_piece(const GenomeDev& G, const PieceSrc& s, uint32_t k, u
 extern "C" __global__ void __launch_bounds__(256)
 k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
                   uint32_t L, PlanArrays pl, const uint32_t* __restrict__ u_contig,
-                  uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_byte) {
+                  uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_byte,
+                  uint64_t first_unit, uint32_t read_id_base, OutCols o, unsigned long long* __restrict__ counters) {
   __shared__ int64_t r_pos[PERFECT_GROUP];  // absolute base position of output byte 0's source
   const GenomeDev G = genomes[genome];
   const uint64_t n_reads = 2 * n_units;
@@ -708,8 +709,19 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64
     if (threadIdx.x < n_in) {
       const uint64_t r = r_base + threadIdx.x;
       const uint64_t u = r >> 1;
-      const uint64_t base = G.contigs[u_contig[u]].base;
-      r_pos[threadIdx.x] = (int64_t)(base + ((r & 1u) ? pl.b[u] + L - 1 : pl.a[u]));  // mate 2: byte k comes from pos - k
+      const uint32_t contig = u_contig[u];
+      const uint32_t rev = (uint32_t)(r & 1u);
+      const uint64_t pos = rev ? pl.b[u] : pl.a[u];
+      r_pos[threadIdx.x] = (int64_t)(G.contigs[contig].base + (rev ? pos + L - 1 : pos));  // mate 2: byte k comes from pos - k
+      // metadata columns of this read (k_write_meta is not launched for this kernel)
+      o.seq_off[r] = r * L;
+      if (r + 1 == n_reads) o.seq_off[n_reads] = n_reads * L;  // closing CSR offset
+      if (o.start) o.start[r] = rev ? pos + L : pos;  // simulate.rs:289,295
+      if (o.end) o.end[r] = rev ? pos : pos + L;      // simulate.rs:290,296
+      if (o.contig) o.contig[r] = contig;
+      if (o.genome) o.genome[r] = genome;
+      if (o.read_id) o.read_id[r] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
+      if (o.flags) o.flags[r] = rev ? (uint8_t)pl.flags[u] : 0;
     }
     __syncthreads();
     uint32_t rl = rl0, k0 = k00;
@@ -828,6 +840,14 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64
       k0 += step_k;
       if (k0 >= L) { k0 -= L; rl++; }
     }
+  }
+  // perfect-short has no per-base draws: every counter follows from the plan
+  if (blockIdx.x == 0 && threadIdx.x == 0 && counters) {
+    const uint64_t bases = n_reads * L;
+    atomicAdd(&counters[SIMMR_CNT_READS], (unsigned long long)n_reads);
+    atomicAdd(&counters[SIMMR_CNT_BASES], (unsigned long long)bases);
+    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)(bases * 60u));  // perfect_short.rs:42-44
+    if (!G.has_exc) atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)bases);
   }
 }
 
