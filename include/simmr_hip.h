@@ -43,6 +43,8 @@ extern "C" {
 #define SIMMR_ENODEV (-19)  /* no usable gfx950 device / HIP runtime error    */
 #define SIMMR_ERANGE (-34)  /* output capacity too small / value out of range */
 #define SIMMR_ESTATE (-1)   /* call order violated (emit before plan, ...)    */
+#define SIMMR_ENOTSUP (-95) /* valid request this library leaves to the host
+                               (simmr_fastq_plan: see there)                  */
 #define SIMMR_EGENOME (-61) /* genome unusable (reference: Err(String) at
                                simulate.rs:220-225 / infinite loop at :370)   */
 
@@ -233,6 +235,38 @@ int simmr_last_plan_ms(simmr_engine* e, float* ms);
  * seed, 2 for the mutation seed.  Also used to derive per-read seeds in
  * SIMMR_LEN_PER_READ mode (which = 3, x = seed ^ read index mix). */
 uint64_t simmr_entropy_substitute(uint64_t x, uint32_t which);
+
+/* ---- FASTQ framing on the device: replaces fastq::write_to_fastq
+ * (simmr/src/fastq.rs:14-124) up to the file write.  The record of read r is
+ *     header '\n' bases '\n' '+' '\n' qualities '\n'      (fastq.rs:58-66, 93-103)
+ * with the header built from `header_format` by the reference's chain of
+ * String::replace calls (fastq.rs:34-56, 69-91): {:genome_id:} {:read_id:}
+ * {:sequence_id:} {:start_position:} {:end_position:} {:reverse_complement:}
+ * (t / f) {:pair:} (1 / 2).  Qualities are copied as they are: emit them with
+ * qual_offset = 33 (util::encode_quality_scores, util.rs:46-57).
+ *
+ * names: the text of {:genome_id:} per genome (Genome.uuid, main.rs:73-75) and of
+ * {:sequence_id:} per contig (Seq.id, genome.rs:100-112), for every engine genome
+ * slot the reads' `genome` column can hold.
+ *
+ * simmr_fastq_plan sizes every record (device), scans the sizes and returns the
+ * total; simmr_fastq_emit writes the n_reads records back to back into dst
+ * (device memory, >= total bytes).  `reads` must carry every column.
+ *
+ * SIMMR_ENOTSUP (nothing written; use the host writer): a genome or sequence id
+ * containing '{' or '}' (the chained replace could then re-expand it), more than
+ * 24 template pieces, or a header longer than 255 bytes. */
+typedef struct simmr_fastq_names {
+  uint32_t n_genomes;
+  const uint32_t* genome_idx;      /* engine genome slot of each entry */
+  const char* const* genome_id;    /* NUL-terminated */
+  const uint32_t* n_contigs;       /* contigs of each entry, as staged */
+  const char* const* sequence_id;  /* flattened entry by entry, NUL-terminated */
+} simmr_fastq_names;
+
+int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fastq_names* names,
+                     const simmr_reads_out* reads, uint64_t n_reads, int paired, uint64_t* total_bytes);
+int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst, uint64_t dst_capacity);
 
 #ifdef __cplusplus
 }

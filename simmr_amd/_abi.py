@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parent
 LIB_PATH = ROOT / "csrc" / "libsimmr_hip.so"
 
 # status codes
-OK, EINVAL, ENOMEM, ENODEV, ERANGE, ESTATE, EGENOME = 0, -22, -12, -19, -34, -1, -61
+OK, EINVAL, ENOMEM, ENODEV, ERANGE, ESTATE, EGENOME, ENOTSUP = 0, -22, -12, -19, -34, -1, -61, -95
 
 # enum simmr_profile_kind
 PERFECT_SHORT, MINIMAL_SHORT, PERFECT_LONG, MINIMAL_LONG, CUSTOM = range(5)
@@ -89,6 +89,17 @@ class ReadsOut(C.Structure):
     ]
 
 
+class FastqNames(C.Structure):
+    """struct simmr_fastq_names"""
+    _fields_ = [
+        ("n_genomes", C.c_uint32),
+        ("genome_idx", C.POINTER(C.c_uint32)),
+        ("genome_id", C.POINTER(C.c_char_p)),
+        ("n_contigs", C.POINTER(C.c_uint32)),
+        ("sequence_id", C.POINTER(C.c_char_p)),
+    ]
+
+
 # every symbol include/simmr_hip.h declares: name -> (restype, argtypes)
 _P = C.POINTER
 SYMBOLS = {
@@ -115,6 +126,9 @@ SYMBOLS = {
     "simmr_last_emit_kernel_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "simmr_last_plan_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "simmr_entropy_substitute": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+    "simmr_fastq_plan": (C.c_int, [C.c_void_p, C.c_char_p, _P(FastqNames), _P(ReadsOut), C.c_uint64, C.c_int,
+                                   _P(C.c_uint64)]),
+    "simmr_fastq_emit": (C.c_int, [C.c_void_p, _P(ReadsOut), C.c_void_p, C.c_uint64]),
 }
 
 _lib = None

@@ -34,6 +34,7 @@ struct GenomeDev {
 };
 
 #define SIMMR_K_CUSTOM 4u
+#define SIMMR_ERRBIT_FASTQ 8u /* a FASTQ header does not fit, or a genome / contig index has no name */
 #define SIMMR_ERRBIT_PDF 4u /* custom PDF picked a bin without a range (a reference panic) or ran out of words */
 
 // One CustomPDF entry (custom_short.rs:28-35): WeightedAliasIndex<f64> + per-bin Uniform<u32>,

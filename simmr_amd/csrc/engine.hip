@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "kernels.hip"
+#include "fastq_kernels.hip"
 #include "custom_model.hpp"
 
 using namespace simmr;
@@ -86,6 +87,12 @@ struct simmr_engine {
   DevBuf d_runs, d_usable;
   // custom profile tables
   DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, ph_table;
+  // FASTQ framing
+  DevBuf fq_blob, fq_gid_off, fq_gid_len, fq_cbase, fq_ncontig, fq_coff, fq_clen, fq_len, fq_off;
+  FqTemplate fq_tpl{};
+  uint64_t fq_reads = 0, fq_total = 0;
+  uint32_t fq_slots = 0, fq_lit_bytes = 0;
+  bool fq_paired = false, fq_ready = false;
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -466,11 +473,11 @@ int sort_by_length(simmr_engine* e, uint64_t count, uint32_t shift) {
   return SIMMR_OK;
 }
 
-// exclusive scan of u_bytes -> u_off (n + 1 entries); returns the total
-int scan_offsets(simmr_engine* e, uint64_t n, uint64_t* total) {
-  if (!e->u_off.ensure((n + 1) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
+// exclusive scan of `in` (n u64) -> `out` (n + 1 entries); returns the total
+int scan_u64(simmr_engine* e, DevBuf& in, uint64_t n, DevBuf& out, uint64_t* total) {
+  if (!out.ensure((n + 1) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
   if (n == 0) {
-    HIP_TRY(e, hipMemsetAsync(e->u_off.p, 0, 8, e->stream));
+    HIP_TRY(e, hipMemsetAsync(out.p, 0, 8, e->stream));
     *total = 0;
     return SIMMR_OK;
   }
@@ -480,13 +487,15 @@ int scan_offsets(simmr_engine* e, uint64_t n, uint64_t* total) {
   uint64_t* wg_tot = e->scan_tmp.as<uint64_t>();
   uint64_t* grand = wg_tot + n_wg;
   hipLaunchKernelGGL(k_scan_reduce, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
-                     e->u_bytes.as<uint64_t>(), n, wg_tot);
+                     in.as<uint64_t>(), n, wg_tot);
   hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_THREADS), 0, e->stream, wg_tot, n_wg, grand);
   hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
-                     e->u_bytes.as<uint64_t>(), n, wg_tot, e->u_off.as<uint64_t>());
+                     in.as<uint64_t>(), n, wg_tot, out.as<uint64_t>());
   HIP_TRY(e, hipMemcpyAsync(total, grand, 8, hipMemcpyDeviceToHost, e->stream));
   return sync_check(e, "offset scan");
 }
+// exclusive scan of u_bytes -> u_off
+int scan_offsets(simmr_engine* e, uint64_t n, uint64_t* total) { return scan_u64(e, e->u_bytes, n, e->u_off, total); }
 
 int ensure_plan_arrays(simmr_engine* e, uint64_t n, bool need_seeds2, bool need_genome) {
   const uint64_t m = std::max<uint64_t>(n, 1);
@@ -619,7 +628,9 @@ void simmr_engine_destroy(simmr_engine* e) {
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_bytes, &e->u_qs2,
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
-                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->ph_table};
+                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->ph_table,
+                    &e->fq_blob, &e->fq_gid_off, &e->fq_gid_len, &e->fq_cbase, &e->fq_ncontig, &e->fq_coff, &e->fq_clen,
+                    &e->fq_len, &e->fq_off};
   for (DevBuf* b : bufs) b->release();
   if (e->ev_a) (void)hipEventDestroy(e->ev_a);
   if (e->ev_b) (void)hipEventDestroy(e->ev_b);
@@ -765,7 +776,11 @@ int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profil
   if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0 &&
       (rc = sort_by_length(e, count, 0)))
     return rc;
-  if ((rc = scan_offsets(e, count, &total))) return rc;
+  if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
+    total = count * 2ull * prof.read_length;  // constant lengths (perfect_short.rs:22-40): read r starts at r * L
+  } else if ((rc = scan_offsets(e, count, &total))) {
+    return rc;
+  }
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;
   if ((rc = read_err_word(e, &errw))) return rc;
@@ -1030,6 +1045,149 @@ int simmr_long_emit(simmr_engine* e, uint32_t read_id_base, const simmr_reads_ou
   if (e->plan_kind != PLAN_LONG) return e->fail(SIMMR_ESTATE, "simmr_long_emit called without a long-read plan");
   HIP_TRY(e, hipSetDevice(e->device));
   return emit_common(e, read_id_base, out);
+}
+
+// ---- FASTQ framing (fastq.rs:14-124) -------------------------------------------------
+namespace {
+// fastq.rs:34-56 chains String::replace over the template in this order.  With ids free of braces
+// no replacement can create or complete a placeholder for a later step, so the chain equals one
+// left-to-right scan for the seven patterns; that scan is compiled here into literal / field pieces.
+bool compile_header_format(const char* fmt, std::vector<uint8_t>* blob, FqTemplate* tp) {
+  static const struct { const char* pat; uint32_t kind; } pats[] = {
+      {"{:genome_id:}", FQ_GENOME_ID}, {"{:read_id:}", FQ_READ_ID}, {"{:sequence_id:}", FQ_SEQUENCE_ID},
+      {"{:start_position:}", FQ_START}, {"{:end_position:}", FQ_END}, {"{:reverse_complement:}", FQ_REVCOMP},
+      {"{:pair:}", FQ_PAIR}};
+  tp->n_segs = 0;
+  const size_t n = strlen(fmt);
+  size_t i = 0, lit0 = 0;
+  auto push = [&](uint32_t kind, uint32_t off, uint32_t len) {
+    if (tp->n_segs >= FQ_MAX_SEGS) return false;
+    tp->segs[tp->n_segs++] = FqSeg{kind, off, len};
+    return true;
+  };
+  auto flush = [&](size_t end) {
+    if (end == lit0) return true;
+    const uint32_t off = (uint32_t)blob->size();
+    blob->insert(blob->end(), fmt + lit0, fmt + end);
+    return push(FQ_LITERAL, off, (uint32_t)(end - lit0));
+  };
+  while (i < n) {
+    bool hit = false;
+    if (fmt[i] == '{')
+      for (const auto& p : pats) {
+        const size_t m = strlen(p.pat);
+        if (strncmp(fmt + i, p.pat, m) == 0) {
+          if (!flush(i) || !push(p.kind, 0, 0)) return false;
+          i += m;
+          lit0 = i;
+          hit = true;
+          break;
+        }
+      }
+    if (!hit) i++;
+  }
+  return flush(n);
+}
+bool has_brace(const char* s) { return strchr(s, '{') || strchr(s, '}'); }
+}  // namespace
+
+int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fastq_names* names,
+                     const simmr_reads_out* reads, uint64_t n_reads, int paired, uint64_t* total_bytes) {
+  if (!e) return SIMMR_EINVAL;
+  e->fq_ready = false;
+  if (!header_format || !names || !reads || !total_bytes) return e->fail(SIMMR_EINVAL, "simmr_fastq_plan: NULL argument");
+  if (!reads->seq_off || !reads->start || !reads->end || !reads->contig || !reads->genome || !reads->read_id ||
+      !reads->flags || (n_reads > 0 && (!reads->seq || !reads->qual)))
+    return e->fail(SIMMR_EINVAL, "simmr_fastq_plan needs every column of simmr_reads_out");
+  HIP_TRY(e, hipSetDevice(e->device));
+  std::vector<uint8_t> blob;
+  if (!compile_header_format(header_format, &blob, &e->fq_tpl))
+    return e->fail(SIMMR_ENOTSUP, "header format has more than %d pieces", FQ_MAX_SEGS);
+  const uint32_t lit_bytes = (uint32_t)blob.size();  // the literals come first in the blob
+  if (lit_bytes > FQ_LIT_MAX) return e->fail(SIMMR_ENOTSUP, "header format has more than %u literal bytes", FQ_LIT_MAX);
+  uint32_t n_slots = 0;
+  for (uint32_t g = 0; g < names->n_genomes; g++) n_slots = std::max(n_slots, names->genome_idx[g] + 1);
+  std::vector<uint32_t> gid_off(std::max(n_slots, 1u), 0), gid_len(std::max(n_slots, 1u), 0), cbase(std::max(n_slots, 1u), 0),
+      ncontig(std::max(n_slots, 1u), 0), coff, clen;
+  size_t row = 0;
+  for (uint32_t g = 0; g < names->n_genomes; g++) {
+    const uint32_t slot = names->genome_idx[g];
+    const char* id = names->genome_id[g];
+    if (!id) return e->fail(SIMMR_EINVAL, "genome id %u is NULL", g);
+    if (has_brace(id)) return e->fail(SIMMR_ENOTSUP, "genome id '%s' contains a brace", id);
+    gid_off[slot] = (uint32_t)blob.size();
+    gid_len[slot] = (uint32_t)strlen(id);
+    blob.insert(blob.end(), id, id + strlen(id));
+    cbase[slot] = (uint32_t)coff.size();
+    ncontig[slot] = names->n_contigs[g];
+    for (uint32_t c = 0; c < names->n_contigs[g]; c++, row++) {
+      const char* sid = names->sequence_id[row];
+      if (!sid) return e->fail(SIMMR_EINVAL, "sequence id %zu is NULL", row);
+      if (has_brace(sid)) return e->fail(SIMMR_ENOTSUP, "sequence id '%s' contains a brace", sid);
+      coff.push_back((uint32_t)blob.size());
+      clen.push_back((uint32_t)strlen(sid));
+      blob.insert(blob.end(), sid, sid + strlen(sid));
+    }
+  }
+  if (blob.size() > 0xfffffff0ull) return e->fail(SIMMR_ENOTSUP, "names exceed 4 GiB");
+  blob.insert(blob.end(), 8, 0);  // ids are read in 8-byte pieces
+  int rc;
+  if ((rc = upload_vec(e, e->fq_blob, blob)) || (rc = upload_vec(e, e->fq_gid_off, gid_off)) ||
+      (rc = upload_vec(e, e->fq_gid_len, gid_len)) || (rc = upload_vec(e, e->fq_cbase, cbase)) ||
+      (rc = upload_vec(e, e->fq_ncontig, ncontig)) || (rc = upload_vec(e, e->fq_coff, coff)) ||
+      (rc = upload_vec(e, e->fq_clen, clen)))
+    return rc;
+  if (!e->fq_len.ensure(std::max<uint64_t>(n_reads, 1) * 8)) return e->fail(SIMMR_ENOMEM, "record length allocation failed");
+  HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
+  const FqTables tb{e->fq_blob.as<uint8_t>(), e->fq_gid_off.as<uint32_t>(), e->fq_gid_len.as<uint32_t>(),
+                    e->fq_cbase.as<uint32_t>(), e->fq_ncontig.as<uint32_t>(), e->fq_coff.as<uint32_t>(),
+                    e->fq_clen.as<uint32_t>(), n_slots};
+  const FqReads rd{reads->seq, reads->qual, reads->seq_off, reads->start, reads->end, reads->contig, reads->genome,
+                   reads->read_id, reads->flags};
+  if (n_reads > 0)
+    hipLaunchKernelGGL(k_fastq_size, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, e->fq_tpl, tb, rd, n_reads,
+                       e->fq_len.as<uint64_t>(), e->d_err.as<uint32_t>());
+  uint64_t total = 0;
+  if ((rc = scan_u64(e, e->fq_len, n_reads, e->fq_off, &total))) return rc;  // also waits for the uploads
+  uint32_t errw = 0;
+  if ((rc = read_err_word(e, &errw))) return rc;
+  if (errw & SIMMR_ERRBIT_FASTQ)
+    return e->fail(SIMMR_ENOTSUP, "a FASTQ header is longer than %u bytes, or a read names a genome / contig without an id", FQ_HMAX - 1);
+  e->fq_reads = n_reads;
+  e->fq_total = total;
+  e->fq_slots = n_slots;
+  e->fq_lit_bytes = lit_bytes;
+  e->fq_paired = paired != 0;
+  e->fq_ready = true;
+  *total_bytes = total;
+  return SIMMR_OK;
+}
+
+int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst, uint64_t dst_capacity) {
+  if (!e) return SIMMR_EINVAL;
+  if (!e->fq_ready) return e->fail(SIMMR_ESTATE, "simmr_fastq_emit called without simmr_fastq_plan");
+  if (!reads) return e->fail(SIMMR_EINVAL, "reads is NULL");
+  if (dst_capacity < e->fq_total)
+    return e->fail(SIMMR_ERANGE, "dst_capacity %llu < %llu bytes planned", (unsigned long long)dst_capacity,
+                   (unsigned long long)e->fq_total);
+  if (e->fq_reads == 0) return SIMMR_OK;
+  if (!dst) return e->fail(SIMMR_EINVAL, "dst is NULL");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint32_t n_slots = e->fq_slots;
+  const FqTables tb{e->fq_blob.as<uint8_t>(), e->fq_gid_off.as<uint32_t>(), e->fq_gid_len.as<uint32_t>(),
+                    e->fq_cbase.as<uint32_t>(), e->fq_ncontig.as<uint32_t>(), e->fq_coff.as<uint32_t>(),
+                    e->fq_clen.as<uint32_t>(), n_slots};
+  const FqReads rd{reads->seq, reads->qual, reads->seq_off, reads->start, reads->end, reads->contig, reads->genome,
+                   reads->read_id, reads->flags};
+  const uint64_t n_batches = (e->fq_reads + FQ_BATCH - 1) / FQ_BATCH;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 4);
+  HIP_TRY(e, hipEventRecord(e->ev_c, e->stream));
+  hipLaunchKernelGGL(k_fastq_write, dim3(grid), dim3(256), 0, e->stream, e->fq_tpl, tb, rd, e->fq_reads,
+                     e->fq_paired ? 1u : 0u, e->fq_lit_bytes, e->fq_off.as<uint64_t>(), dst);
+  HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
+  hipError_t s = hipGetLastError();
+  if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "fastq launch failed: %s", hipGetErrorString(s));
+  return SIMMR_OK;
 }
 
 // ---- counters / timing ---------------------------------------------------------------

@@ -199,6 +199,27 @@ class Engine:
         self.long_emit(read_id_base, out)
         return out
 
+    # -- FASTQ framing (fastq.rs:14-124) ------------------------------------------
+    def fastq(self, reads: Reads, header_format: str, names, paired: bool):
+        """FASTQ text of `reads` as a CUDA uint8 tensor.  `names` = [(engine genome slot, genome id,
+        [sequence id per contig]), ...]; qualities must have been emitted with qual_offset=33.
+        Raises SimmrError(ENOTSUP) for the cases the library leaves to the host writer."""
+        torch = _torch()
+        n = len(names)
+        gi = (C.c_uint32 * max(n, 1))(*[int(x[0]) for x in names])
+        gid = (C.c_char_p * max(n, 1))(*[str(x[1]).encode() for x in names])
+        nc = (C.c_uint32 * max(n, 1))(*[len(x[2]) for x in names])
+        flat = [str(sid).encode() for x in names for sid in x[2]]
+        sids = (C.c_char_p * max(len(flat), 1))(*flat)
+        fn = _abi.FastqNames(n, gi, gid, nc, sids)
+        pod = reads.pod()
+        total = C.c_uint64(0)
+        self._check(self.lib.simmr_fastq_plan(self._h, header_format.encode(), C.byref(fn), C.byref(pod),
+                                              reads.n_reads, 1 if paired else 0, C.byref(total)))
+        out = torch.empty(max(total.value, 1), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.simmr_fastq_emit(self._h, C.byref(pod), C.c_void_p(out.data_ptr()), total.value))
+        return out[: total.value]
+
     # -- counters / timing --------------------------------------------------------
     def counters(self) -> np.ndarray:
         host = (C.c_uint64 * _abi.N_COUNTERS)()

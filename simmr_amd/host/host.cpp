@@ -371,7 +371,7 @@ std::string usage() {
          "  --seed <N>                    Random seed\n"
          "  --size-adjusted               Adjust by genome size\n"
          "  --contiguous                  Treat separate sequences in a genome as one contiguous sequence\n"
-         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths\n";
+         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths  --host-fastq\n";
 }
 
 static bool parse_u64(const std::string& s, uint64_t max, uint64_t* out) {
@@ -428,6 +428,7 @@ bool parse_cli_args(int argc, const char* const* argv, CliArgs* a, std::string* 
     else if (arg == "--seed") { if (!need(&v) || !parse_u64(v, UINT64_MAX, &u)) { *err = "invalid value for --seed"; return false; } a->seed = u; }
     else if (arg == "--size-adjusted") a->size_adjusted = true;
     else if (arg == "--contiguous") a->contiguous = true;
+    else if (arg == "--host-fastq") a->host_fastq = true;
     else if (arg == "--device") { if (!need(&v) || !parse_u64(v, 1023, &u)) { *err = "invalid value for --device"; return false; } a->device = (int)u; }
     else if (arg == "--gamma") {
       if (!need(&v)) return false;

@@ -51,6 +51,39 @@ struct DeviceOut {
   }
 };
 
+// FASTQ text built on the device (simmr_fastq_plan / simmr_fastq_emit), appended to `output`.
+// Returns 1 when the library leaves this input to the host writer (SIMMR_ENOTSUP), -1 on error.
+static int write_fastq_device(simmr_engine* eng, const std::string& fmt, const std::vector<Genome>& genomes, size_t g0,
+                              size_t g1, const simmr_reads_out& reads, uint64_t n_reads, bool paired,
+                              const std::string& output, std::string* err) {
+  std::vector<uint32_t> idx, ncontigs;
+  std::vector<const char*> gids, sids;
+  for (size_t gi = g0; gi < g1; gi++) {
+    idx.push_back((uint32_t)gi);
+    gids.push_back(genomes[gi].uuid.c_str());
+    ncontigs.push_back((uint32_t)genomes[gi].sequence.size());
+    for (const Seq& s : genomes[gi].sequence) sids.push_back(s.id.c_str());
+  }
+  const simmr_fastq_names names{(uint32_t)idx.size(), idx.data(), gids.data(), ncontigs.data(), sids.data()};
+  uint64_t total = 0;
+  int rc = simmr_fastq_plan(eng, fmt.c_str(), &names, &reads, n_reads, paired ? 1 : 0, &total);
+  if (rc == SIMMR_ENOTSUP) return 1;
+  if (rc != SIMMR_OK) { *err = simmr_last_error(eng); return -1; }
+  void* dev = nullptr;
+  if (hipMalloc(&dev, total ? total : 1) != hipSuccess) { *err = "device allocation failed"; return -1; }
+  std::vector<char> host(total);
+  rc = simmr_fastq_emit(eng, &reads, (uint8_t*)dev, total);
+  const bool ok = rc == SIMMR_OK && (total == 0 || hipMemcpy(host.data(), dev, total, hipMemcpyDeviceToHost) == hipSuccess);
+  (void)hipFree(dev);
+  if (!ok) { *err = rc != SIMMR_OK ? simmr_last_error(eng) : "copy back failed"; return -1; }
+  FILE* f = fopen(output.c_str(), "ab");
+  if (!f) { *err = "cannot open " + output; return -1; }
+  const bool wrote = total == 0 || fwrite(host.data(), 1, total, f) == total;
+  fclose(f);
+  if (!wrote) { *err = "short write to " + output; return -1; }
+  return 0;
+}
+
 static int run_main(int argc, char** argv) {
   CliArgs args;
   std::string err;
@@ -156,10 +189,15 @@ static int run_main(int argc, char** argv) {
       DeviceOut d;
       if (!d.init(pi.n_reads, pi.total_bases)) return die("device allocation failed");
       if (simmr_pe_emit(eng, id_base, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
-      HostReads h;
-      if (!d.to_host(pi.n_reads, pi.total_bases, true, &h)) return die("copy back failed");
-      if (!write_to_fastq(genomes[gi].uuid, genomes[gi], h, 0, pi.n_reads, args.output, args.read_header_format, true, &err))
-        fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+      int fq = args.host_fastq ? 1 : write_fastq_device(eng, args.read_header_format, genomes, gi, gi + 1, d.o, pi.n_reads, true,
+                                                      args.output, &err);
+      if (fq < 0) fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+      if (fq > 0) {  // host writer (fastq.rs restated in host.cpp)
+        HostReads h;
+        if (!d.to_host(pi.n_reads, pi.total_bases, true, &h)) return die("copy back failed");
+        if (!write_to_fastq(genomes[gi].uuid, genomes[gi], h, 0, pi.n_reads, args.output, args.read_header_format, true, &err))
+          fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+      }
       id_base += (uint32_t)pi.n_units;
     }
   } else {
@@ -173,13 +211,18 @@ static int run_main(int argc, char** argv) {
     DeviceOut d;
     if (!d.init(pi.n_reads, pi.total_bases)) return die("device allocation failed");
     if (simmr_long_emit(eng, 0, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
-    HostReads h;
-    if (!d.to_host(pi.n_reads, pi.total_bases, false, &h)) return die("copy back failed");
-    uint64_t first = 0;
-    for (size_t gi = 0; gi < genomes.size(); gi++) {
-      if (!write_to_fastq(genomes[gi].uuid, genomes[gi], h, first, reads[gi], args.output, args.read_header_format, true, &err))
-        fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
-      first += reads[gi];
+    int fq = args.host_fastq ? 1 : write_fastq_device(eng, args.read_header_format, genomes, 0, genomes.size(), d.o, pi.n_reads,
+                                                    false, args.output, &err);
+    if (fq < 0) fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+    if (fq > 0) {
+      HostReads h;
+      if (!d.to_host(pi.n_reads, pi.total_bases, false, &h)) return die("copy back failed");
+      uint64_t first = 0;
+      for (size_t gi = 0; gi < genomes.size(); gi++) {
+        if (!write_to_fastq(genomes[gi].uuid, genomes[gi], h, first, reads[gi], args.output, args.read_header_format, true, &err))
+          fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+        first += reads[gi];
+      }
     }
   }
   info(("Writing simulated reads to " + args.output).c_str());

@@ -177,6 +177,7 @@ struct CliArgs {  // cli.rs:93-220, same flags and defaults
   bool contiguous = false;
   // extensions of this implementation (not reference flags)
   int device = 0;
+  bool host_fastq = false;  // --host-fastq: frame the FASTQ on the host instead of the device
   std::optional<std::pair<float, float>> gamma;  // --gamma mean,std
   bool per_read_lengths = false;                 // --per-read-lengths (SIMMR_LEN_PER_READ)
 };

@@ -120,3 +120,17 @@ def test_cli_contiguous(workdir, oracle):
     o = _oracle.simulate_pe(oracle, g, PerfectShortErrorProfile().pod(), 400, 3, qual_offset=33)
     exp = fastq_of(o.trimmed(), o.n_reads, ["whole genome"], "x", True, fmt="@{:read_id:}/{:pair:} {:sequence_id:}")
     assert out.read_bytes() == exp
+
+
+def test_cli_device_and_host_fastq_agree(workdir):
+    """The FASTQ is framed on the device by default; --host-fastq keeps the C++ restatement of
+    fastq.rs as a second, independently written writer.  Same bytes, also for an odd template."""
+    d, _ = workdir
+    fmt = "@{:read_id:}/{:pair:} {:genome_id:}|{:sequence_id:} {:start_position:}..{:end_position:} {:reverse_complement:}{:"
+    outs = []
+    for extra in ([], ["--host-fastq"]):
+        out = d / ("agree%d.fq" % len(extra))
+        subprocess.check_call([str(EXE), "--genome-file", str(d / "genomes.tsv"), "--output", str(out), "--num-reads", "2000",
+                               "--seed", "3", "--error-profile", "minimal-short", "--read-header-format", fmt] + extra)
+        outs.append(out.read_bytes())
+    assert len(outs[0]) > 600_000 and outs[0] == outs[1]

@@ -1,0 +1,87 @@
+"""Device FASTQ framing (simmr_fastq_plan / simmr_fastq_emit) against a restatement of
+fastq.rs:32-121 applied to the same SoA columns: byte-identical records, including the
+chained String::replace of the header template."""
+import numpy as np
+import pytest
+
+from simmr_amd import MinimalLongErrorProfile, MinimalShortErrorProfile, PerfectShortErrorProfile, SimmrError, _abi
+from tests import _synth
+from tests.test_gpu_cli import FMT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def genome_1m(engine):
+    from tests import _oracle
+    contig = _synth.synthetic_contigs([1_000_000], 1)[0]
+    engine.stage_genome(0, [contig])
+    return _oracle.HostGenome([contig])
+
+
+@pytest.fixture(scope="module")
+def genome_multi(engine):
+    from tests import _oracle
+    contigs = _synth.synthetic_contigs([300_000, 90_001, 30_017, 70_000, 123_457], 7)
+    engine.stage_genome(1, contigs)
+    return _oracle.HostGenome(contigs)
+
+
+def _check(engine, reads, names, fmt, paired):
+    got = engine.fastq(reads, fmt, names, paired).cpu().numpy().tobytes()
+    d = reads.to_host()
+    by_slot = {slot: (gid, sids) for slot, gid, sids in names}
+    want = bytearray()
+    for r in range(reads.n_reads):
+        gid, sids = by_slot[int(d["genome"][r])]
+        h = fmt  # fastq.rs:34-56: the replace calls in the reference's order
+        for k, v in (("{:genome_id:}", gid), ("{:read_id:}", str(int(d["read_id"][r]))),
+                     ("{:sequence_id:}", sids[int(d["contig"][r])]), ("{:start_position:}", str(int(d["start"][r]))),
+                     ("{:end_position:}", str(int(d["end"][r]))), ("{:reverse_complement:}", "t" if d["flags"][r] & 1 else "f"),
+                     ("{:pair:}", "2" if (paired and r & 1) else "1")):
+            h = h.replace(k, v)
+        a, b = int(d["seq_off"][r]), int(d["seq_off"][r + 1])
+        want += h.encode() + b"\n" + d["seq"][a:b].tobytes() + b"\n+\n" + d["qual"][a:b].tobytes() + b"\n"
+    assert len(got) == len(want)
+    if got != bytes(want):
+        g, w = np.frombuffer(got, np.uint8), np.frombuffer(bytes(want), np.uint8)
+        i = int(np.flatnonzero(g != w)[0])
+        raise AssertionError(f"first difference at byte {i}: {got[max(0, i - 60):i + 20]!r} vs {bytes(want)[max(0, i - 60):i + 20]!r}")
+
+
+@pytest.mark.parametrize("fmt", [
+    FMT,
+    "@{:read_id:}",
+    "{:pair:}{:pair:}x{:reverse_complement:}{:genome_id:}{:genome_id:} {:end_position:}-{:start_position:} {:sequence_id:}{:",
+    "@r{:read_id:}/{:pair:} {:s{:reverse_complement:}art_position:} {:unknown:} {{:pair:}:read_id:}",
+    "",
+])
+def test_fastq_pe(engine, genome_multi, fmt):
+    names = [(1, "genome-one", ["chrA something long", "b", "c c", "d" * 40][: len(genome_multi.contigs)] +
+              ["x%d" % i for i in range(max(0, len(genome_multi.contigs) - 4))])]
+    for prof, n in ((PerfectShortErrorProfile().pod(), 2001), (MinimalShortErrorProfile(read_length=37, insert_size=80).pod(), 1500),
+                    (MinimalShortErrorProfile(read_length=9, insert_size=5).pod(), 333)):
+        reads = engine.simulate_pe_reads_from_genome(1, prof, n, 11, read_id_base=4_294_000_000 if n == 333 else 0, qual_offset=33)
+        _check(engine, reads, names, fmt, True)
+
+
+def test_fastq_long_multi_genome(engine, genome_multi, genome_1m):
+    lp = MinimalLongErrorProfile(gamma_mean=2500.0, gamma_std=2000.0, length_mode=_abi.LEN_PER_READ).pod()
+    reads = engine.simulate_long_reads([1, 0], [70, 45], lp, 5, qual_offset=33)
+    names = [(1, "g1", ["ctg%d" % i for i in range(len(genome_multi.contigs))]), (0, "7700123", ["synth_1M"])]
+    _check(engine, reads, names, FMT, False)
+    _check(engine, reads, names, "@{:sequence_id:}", False)
+
+
+def test_fastq_left_to_the_host(engine, genome_multi):
+    reads = engine.simulate_pe_reads_from_genome(1, PerfectShortErrorProfile().pod(), 100, 1, qual_offset=33)
+    n = len(genome_multi.contigs)
+    for names, fmt in (([(1, "id{with}braces", ["c"] * n)], FMT), ([(1, "g", ["{:pair:}"] + ["c"] * (n - 1))], FMT),
+                       ([(1, "g", ["c" * 300] * n)], FMT), ([(1, "g", ["c"] * n)], "{:pair:}x" * 13),
+                       ([(0, "wrong slot", ["c"])], FMT)):
+        with pytest.raises(SimmrError) as ei:
+            engine.fastq(reads, fmt, names, True)
+        assert ei.value.code == _abi.ENOTSUP
+    # an empty shard is an empty file
+    empty = engine.simulate_pe_reads_from_genome(1, PerfectShortErrorProfile().pod(), 100, 1, first=50, count=0, qual_offset=33)
+    assert engine.fastq(empty, FMT, [(1, "g", ["c"] * n)], True).numel() == 0
