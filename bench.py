@@ -233,15 +233,18 @@ def main():
 
 def measured_traffic(args, reads_per_gpu):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1/f_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs of this very
+    (profiles/r1/g_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs of this very
     command); only reported for the workload it was measured on."""
     try:
-        t = json.load(open(ROOT / "profiles" / "r1" / "f_traffic.json"))
+        t = json.load(open(ROOT / "profiles" / "r1" / "g_traffic.json"))
     except OSError:
         return None
-    if args.profile == "minimal-short" and args.rng == "philox" and reads_per_gpu == 100_000_000 \
-            and args.genome_bases == 100_000_000:
+    if reads_per_gpu != 100_000_000 or args.genome_bases != 100_000_000:
+        return None
+    if args.profile == "minimal-short" and args.rng == "philox":
         return t["bytes_raw"]
+    if args.profile == "perfect-short":
+        return t["perfect_short"]["bytes_raw"]
     return None
 
 
