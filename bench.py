@@ -90,10 +90,16 @@ def main():
     first = rank * (2 * pairs_per_gpu if long_mode else pairs_per_gpu)
     counters_dev = torch.zeros(_abi.N_COUNTERS, dtype=torch.int64, device=eng.device)
 
+    # Each rank summarizes the outer-stream slots of its own pair range once per step and the ranks
+    # exchange 4 numbers, so that no rank re-walks the stream from slot 0 (simulate.seek_outer_stream).
+    from simmr_amd.simulate import seek_outer_stream
+    pieces = [(0, 1, j * pairs_per_gpu, (j + 1) * pairs_per_gpu) if j + 1 < world else None for j in range(world)]
+
     def plan():
         if long_mode:  # shard = range of global read indices
             return eng.long_plan([0], [total_reads], prof, args.seed, first, 2 * pairs_per_gpu)
-        return eng.pe_plan(0, prof, total_reads, args.seed, first, pairs_per_gpu)
+        start = seek_outer_stream(eng, pieces, (0, 1, first), args.seed) if world > 1 else (0, 0)
+        return eng.pe_plan(0, prof, total_reads, args.seed, first, pairs_per_gpu, start)
 
     # sizes are a deterministic function of (seed, shard): plan once to allocate
     info = plan()

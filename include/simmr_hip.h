@@ -202,6 +202,27 @@ int simmr_genome_info(const simmr_engine* e, uint32_t genome_idx, uint32_t* n_co
 int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profile* profile,
                   uint64_t genome_reads, int has_seed, uint64_t seed, simmr_range shard,
                   simmr_plan_info* info);
+/* Seeking in a genome's outer stream, so that N GPUs sharing one run do not each
+ * re-walk the stream from slot 0 to their shard (simulate.rs:172-184 draws, per
+ * pair, a contig index by rejection sampling and then pe_seed: the slot where
+ * pair p starts depends on every earlier rejection).  The loop is a two-state
+ * machine over u64 slots (0: about to draw a contig index, 1: about to draw
+ * pe_seed); simmr_outer_summarize walks slots [slot_first, slot_first +
+ * slot_count) (both multiples of 8) once and returns, for either state at
+ * slot_first, how many pairs complete inside the range and the state after it.
+ * Ranks summarize disjoint ranges, exchange the 4 numbers (the path's only other
+ * collective, 32 bytes per rank) and compose them; simmr_pe_plan_at then starts
+ * at a known position: pair `start_unit` begins at slot `start_slot`
+ * (start_unit <= shard.first; start_slot = start_unit = 0 is simmr_pe_plan). */
+typedef struct simmr_outer_summary {
+  uint64_t units[2];      /* pairs completed in the range, by state at slot_first */
+  uint32_t end_state[2];  /* state after the range */
+} simmr_outer_summary;
+int simmr_outer_summarize(simmr_engine* e, uint32_t genome_idx, uint64_t seed, uint64_t slot_first,
+                          uint64_t slot_count, simmr_outer_summary* out);
+int simmr_pe_plan_at(simmr_engine* e, uint32_t genome_idx, const simmr_error_profile* profile,
+                     uint64_t genome_reads, uint64_t seed, simmr_range shard, uint64_t start_slot,
+                     uint64_t start_unit, simmr_plan_info* info);
 /* Emits the planned pairs: bases, qualities, mutations, reverse complement,
  * metadata (simulate.rs:260-299).  read_id_base = id of pair 0 of this genome
  * (the reference's global AtomicU32, simulate.rs:85-89). */

@@ -89,6 +89,11 @@ class ReadsOut(C.Structure):
     ]
 
 
+class OuterSummary(C.Structure):
+    """struct simmr_outer_summary"""
+    _fields_ = [("units", C.c_uint64 * 2), ("end_state", C.c_uint32 * 2)]
+
+
 class FastqNames(C.Structure):
     """struct simmr_fastq_names"""
     _fields_ = [
@@ -117,6 +122,9 @@ SYMBOLS = {
     "simmr_genome_info": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_uint32), _P(C.c_uint64)]),
     "simmr_pe_plan": (C.c_int, [C.c_void_p, C.c_uint32, _P(ErrorProfilePOD), C.c_uint64, C.c_int,
                                 C.c_uint64, Range, _P(PlanInfo)]),
+    "simmr_outer_summarize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, _P(OuterSummary)]),
+    "simmr_pe_plan_at": (C.c_int, [C.c_void_p, C.c_uint32, _P(ErrorProfilePOD), C.c_uint64, C.c_uint64, Range,
+                                   C.c_uint64, C.c_uint64, _P(PlanInfo)]),
     "simmr_pe_emit": (C.c_int, [C.c_void_p, C.c_uint32, _P(ReadsOut)]),
     "simmr_long_plan": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_uint32), _P(C.c_uint64),
                                   _P(ErrorProfilePOD), C.c_int, C.c_uint64, Range, _P(PlanInfo)]),

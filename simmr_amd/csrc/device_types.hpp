@@ -92,11 +92,12 @@ struct OuterPrefix {
 };
 
 struct OuterScanResult {
-  uint64_t total_units;
+  uint64_t total_units;   // units in the scanned blocks when they start in NEED_IDX
   uint64_t wg_lo, wg_hi;
   uint64_t end_slot;
   uint32_t end_state;
-  uint32_t pad;
+  uint32_t end_state1;    // the same two numbers for a start in NEED_SEED
+  uint64_t total_units1;
 };
 
 // Per-unit plan columns (unit = pair or long read).

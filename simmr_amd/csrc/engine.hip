@@ -737,9 +737,61 @@ int simmr_genome_info(const simmr_engine* e, uint32_t genome_idx, uint32_t* n_co
 }
 
 // ---- paired-end -----------------------------------------------------------------
+int simmr_outer_summarize(simmr_engine* e, uint32_t genome_idx, uint64_t seed, uint64_t slot_first,
+                          uint64_t slot_count, simmr_outer_summary* out) {
+  if (!e) return SIMMR_EINVAL;
+  if (!out) return e->fail(SIMMR_EINVAL, "out is NULL");
+  if ((slot_first | slot_count) & 7u) return e->fail(SIMMR_EINVAL, "slot ranges are multiples of 8 (one ChaCha block)");
+  HIP_TRY(e, hipSetDevice(e->device));
+  int rc = check_genome(e, genome_idx);
+  if (rc) return rc;
+  out->units[0] = out->units[1] = 0;
+  out->end_state[0] = 0;
+  out->end_state[1] = 1;
+  if (slot_count == 0) return SIMMR_OK;
+  OuterParams P;
+  P.key = host_pcg32_expand(seed);
+  P.range = e->genomes[genome_idx].contigs.size();
+  P.zone = (P.range << __builtin_clzll(P.range)) - 1;
+  const uint64_t n_blocks = slot_count >> 3, n_wg = (n_blocks + 255) / 256;
+  if (n_wg > 0x7fffffffULL) return e->fail(SIMMR_ERANGE, "slot range too long for one launch");
+  if (!e->o_last_idx.ensure(n_blocks * 4) || !e->o_wg_sums.ensure(n_wg * 4) ||
+      !e->o_wg_prefix.ensure(n_wg * sizeof(OuterPrefix)) || !e->o_result.ensure(sizeof(OuterScanResult)))
+    return e->fail(SIMMR_ENOMEM, "outer stream scratch allocation failed");
+  HIP_TRY(e, hipMemsetAsync(e->o_result.p, 0, sizeof(OuterScanResult), e->stream));
+  hipLaunchKernelGGL(k_outer_classify, dim3((uint32_t)n_wg), dim3(256), 0, e->stream, P, slot_first >> 3, n_blocks, 0u,
+                     e->o_last_idx.as<uint32_t>(), e->o_wg_sums.as<uint32_t>());
+  hipLaunchKernelGGL(k_outer_scan, dim3(1), dim3(256), 0, e->stream, e->o_wg_sums.as<uint32_t>(), n_wg, (uint64_t)0,
+                     (uint64_t)0, e->o_wg_prefix.as<OuterPrefix>(), e->o_result.as<OuterScanResult>());
+  OuterScanResult res{};
+  HIP_TRY(e, hipMemcpyAsync(&res, e->o_result.p, sizeof res, hipMemcpyDeviceToHost, e->stream));
+  if ((rc = sync_check(e, "outer stream summary"))) return rc;
+  out->units[0] = res.total_units;
+  out->units[1] = res.total_units1;
+  out->end_state[0] = res.end_state;
+  out->end_state[1] = res.end_state1;
+  return SIMMR_OK;
+}
+
+static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_profile* profile, uint64_t genome_reads,
+                        int has_seed, uint64_t seed, simmr_range shard, uint64_t start_slot, uint64_t start_unit,
+                        simmr_plan_info* info);
+
 int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profile* profile,
                   uint64_t genome_reads, int has_seed, uint64_t seed, simmr_range shard,
                   simmr_plan_info* info) {
+  return pe_plan_impl(e, genome_idx, profile, genome_reads, has_seed, seed, shard, 0, 0, info);
+}
+
+int simmr_pe_plan_at(simmr_engine* e, uint32_t genome_idx, const simmr_error_profile* profile,
+                     uint64_t genome_reads, uint64_t seed, simmr_range shard, uint64_t start_slot,
+                     uint64_t start_unit, simmr_plan_info* info) {
+  return pe_plan_impl(e, genome_idx, profile, genome_reads, 1, seed, shard, start_slot, start_unit, info);
+}
+
+static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_profile* profile, uint64_t genome_reads,
+                        int has_seed, uint64_t seed, simmr_range shard, uint64_t start_slot, uint64_t start_unit,
+                        simmr_plan_info* info) {
   if (!e) return SIMMR_EINVAL;
   e->plan_kind = PLAN_NONE;
   HIP_TRY(e, hipSetDevice(e->device));
@@ -757,6 +809,9 @@ int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profil
   const uint64_t n_pairs = genome_reads / 2;  // simulate.rs:179
   uint64_t first = std::min(shard.first, n_pairs);
   uint64_t count = std::min(shard.count, n_pairs - first);
+  if (start_unit > first)
+    return e->fail(SIMMR_EINVAL, "start_unit %llu is past the first pair of the shard (%llu)", (unsigned long long)start_unit,
+                   (unsigned long long)first);
   if (!has_seed) seed = os_entropy_u64();  // simulate.rs:174 from_entropy()
   const bool seeds2 = prof.kind != SIMMR_K_PERFECT_SHORT;
   if ((rc = ensure_plan_arrays(e, count, seeds2, false))) return rc;
@@ -764,8 +819,9 @@ int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profil
   HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
   uint64_t end_slot = 0, total = 0;
   if (count > 0) {
-    rc = run_outer(e, seed, g.contigs.size(), 0, first + count, first, count, e->u_contig.as<uint32_t>(),
-                   e->u_seed.as<uint64_t>(), &end_slot);
+    // the stream is entered at pair start_unit (slot start_slot): units are counted from there
+    rc = run_outer(e, seed, g.contigs.size(), start_slot, first - start_unit + count, first - start_unit, count,
+                   e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(), &end_slot);
     if (rc) return rc;
     hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                        e->d_genomes.as<GenomeDev>(), genome_idx, count, e->u_contig.as<uint32_t>(),

@@ -207,6 +207,14 @@ k_outer_scan(const uint32_t* __restrict__ wg_sums, uint64_t n_wg, uint64_t first
     }
     res->total_units = base;
     res->end_state = st;
+    uint32_t st1 = 1;  // the same composition for a range entered in NEED_SEED (simmr_outer_summarize)
+    uint64_t base1 = 0;
+    for (int i = 0; i < 256; i++) {
+      base1 += st1 ? s_c1[i] : s_c0[i];
+      st1 = st1 ? s_e1[i] : s_e0[i];
+    }
+    res->total_units1 = base1;
+    res->end_state1 = st1;
   }
   __syncthreads();
   uint32_t st = s_state[t];

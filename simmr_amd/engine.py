@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Optional, Sequence
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -157,12 +157,28 @@ class Engine:
 
     # -- paired-end (simulate.rs:165-302) -------------------------------------
     def pe_plan(self, genome_idx: int, profile: ErrorProfilePOD, genome_reads: int,
-                seed: Optional[int], first: int = 0, count: int = U64_MAX) -> PlanInfo:
+                seed: Optional[int], first: int = 0, count: int = U64_MAX,
+                start: Tuple[int, int] = (0, 0)) -> PlanInfo:
+        """`start` = (slot, pair): a known position of the genome's outer stream at or before
+        `first` (see simulate.seek_outer_stream); (0, 0) walks the stream from its beginning."""
         info = PlanInfo()
-        self._check(self.lib.simmr_pe_plan(self._h, genome_idx, C.byref(profile), genome_reads,
-                                           0 if seed is None else 1, 0 if seed is None else seed,
-                                           Range(first, count), C.byref(info)))
+        if start == (0, 0):
+            self._check(self.lib.simmr_pe_plan(self._h, genome_idx, C.byref(profile), genome_reads,
+                                               0 if seed is None else 1, 0 if seed is None else seed,
+                                               Range(first, count), C.byref(info)))
+        else:
+            if seed is None:
+                raise ValueError("seeking needs a seed")
+            self._check(self.lib.simmr_pe_plan_at(self._h, genome_idx, C.byref(profile), genome_reads, seed,
+                                                  Range(first, count), start[0], start[1], C.byref(info)))
         return info
+
+    def outer_summarize(self, genome_idx: int, seed: int, slot_first: int, slot_count: int):
+        """(units0, units1, end0, end1) of slots [slot_first, slot_first + slot_count) of the genome's
+        outer stream (simulate.rs:172-184), see include/simmr_hip.h."""
+        s = _abi.OuterSummary()
+        self._check(self.lib.simmr_outer_summarize(self._h, genome_idx, seed, slot_first, slot_count, C.byref(s)))
+        return int(s.units[0]), int(s.units[1]), int(s.end_state[0]), int(s.end_state[1])
 
     def pe_emit(self, read_id_base: int, out: Reads):
         pod = out.pod()
@@ -170,8 +186,9 @@ class Engine:
 
     def simulate_pe_reads_from_genome(self, genome_idx: int, profile: ErrorProfilePOD, genome_reads: int,
                                       seed: Optional[int], first: int = 0, count: int = U64_MAX,
-                                      read_id_base: int = 0, qual_offset: int = 0) -> Reads:
-        info = self.pe_plan(genome_idx, profile, genome_reads, seed, first, count)
+                                      read_id_base: int = 0, qual_offset: int = 0,
+                                      start: Tuple[int, int] = (0, 0)) -> Reads:
+        info = self.pe_plan(genome_idx, profile, genome_reads, seed, first, count, start)
         out = Reads.allocate(info.n_reads, info.total_bases, self.device, qual_offset)
         self.pe_emit(read_id_base, out)
         return out

@@ -25,6 +25,7 @@ class GenomeRef:
     size: int           # Genome.size (sum of Seq.size)
     filepath: str = ""
     uuid: str = ""
+    n_contigs: int = 1  # Genome.num_seqs (the range of the contig draw, simulate.rs:181)
 
 
 def split_range(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -62,21 +63,110 @@ def pe_shards(genome_reads: Sequence[int], rank: int, world: int):
     return out
 
 
+def outer_slot_floor(n_contigs: int, unit: int) -> int:
+    """A block-aligned slot that lies at or before the slot where pair `unit` of a genome's outer
+    stream starts (simulate.rs:172-184: per pair, a contig index by rejection sampling —
+    gen_range(0..n_contigs), 1 / p_acc slots on average — and one slot for pe_seed).  Pure
+    arithmetic, identical on every rank; 2 % + 4096 slots below the expectation, which is more
+    than 20 standard deviations of the rejection count for any unit."""
+    if unit <= 0:
+        return 0
+    zone = ((n_contigs << (64 - n_contigs.bit_length())) - 1) & ((1 << 64) - 1)
+    p_acc = (zone + 1) / 2.0 ** 64
+    est = 0.98 * unit * (1.0 / p_acc + 1.0) - 4096.0
+    return max(0, int(est) // 8 * 8)
+
+
+def seek_outer_stream(backend, pieces, want, seed: int):
+    """Positions of the outer streams at the start of this rank's shard, without walking them
+    from slot 0 on every rank.
+
+    `pieces[j]` = (genome index, n_contigs, a, b) or None: the part [a, b) of a genome's pairs that
+    rank j covers and that ends before the genome does (only then a later rank starts inside the
+    same genome).  Rank j summarizes the slots [floor(a), floor(b)) of that genome's stream once
+    (`backend.outer_summarize`: pairs completed and end state for either entry state), the ranks
+    exchange the four numbers (all_gather), and each rank composes the summaries of the pieces in
+    front of its own start.  `want` = (genome index, n_contigs, first pair) of this rank.
+    Returns (slot, pair): pair `pair` (<= first pair) starts at slot `slot`."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    # RCCL moves device tensors; gloo (CPU tests, single-GPU rehearsal) host tensors
+    dev = torch.device("cuda", torch.cuda.current_device()) if world > 1 and dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.zeros(4, dtype=torch.int64)
+    if pieces[rank] is not None:
+        g, nc, a, b = pieces[rank]
+        lo, hi = outer_slot_floor(nc, a), outer_slot_floor(nc, b)
+        mine = torch.tensor(backend.outer_summarize(g, seed, lo, hi - lo), dtype=torch.int64)
+    if world > 1:
+        mine = mine.to(dev)
+        gathered = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        gathered = [t.cpu() for t in gathered]
+    else:
+        gathered = [mine]
+    return compose_outer_summaries(pieces, [tuple(int(x) for x in t) for t in gathered], want)
+
+
+def compose_outer_summaries(pieces, summaries, want):
+    """The pure part of seek_outer_stream: `summaries[j]` = (units0, units1, end0, end1) of piece j."""
+    g, nc, first = want
+    if first == 0:
+        return 0, 0
+    # the pieces of genome g in front of `first`, in order: [0, b1) [b1, b2) ... [.., first)
+    chain = sorted((p[2], p[3], j) for j, p in enumerate(pieces) if p is not None and p[0] == g and p[3] <= first)
+    units, state = 0, 0
+    best = (0, 0)
+    at = 0
+    for a, b, j in chain:
+        if a != at:
+            break  # a gap: what has been composed so far still stands
+        u0, u1, e0, e1 = summaries[j]
+        units += u1 if state else u0
+        state = e1 if state else e0
+        at = b
+        # in state 1 the pending pair gets its pe_seed from the next slot: the pair after it starts one slot later
+        if units + state <= first:
+            best = (outer_slot_floor(nc, b) + state, units + state)
+    return best
+
+
 def simulate_pe_reads(backend, num_reads: int, genomes: Sequence[GenomeRef], error_profile: ErrorProfile,
                       abundance_profile: AbundanceProfile, seed: Optional[int], rank: int = 0, world: int = 1,
                       qual_offset: int = 0):
     """Returns one tuple per genome, like simulate.rs:119:
     (filepath, uuid, genome_reads, abundance, reads-of-this-rank or None)."""
     ab = determine_reads(num_reads, genomes, error_profile, abundance_profile, True)
-    shards = pe_shards([r for r, _ in ab], rank, world)
+    reads_per_genome = [r for r, _ in ab]
+    shards = pe_shards(reads_per_genome, rank, world)
     pod = error_profile.pod()
+    # Only the first genome of a rank's range can start in the middle of that genome's outer stream.
+    start = {}
+    if world > 1 and seed is not None and hasattr(backend, "outer_summarize"):
+        pieces = []
+        for j in range(world):
+            mid = [(gi, sh) for gi, sh in enumerate(pe_shards(reads_per_genome, j, world))
+                   if sh[1] > 0 and sh[0] + sh[1] < reads_per_genome[gi] // 2]
+            gi, sh = mid[-1] if mid else (None, None)
+            pieces.append(None if gi is None else (genomes[gi].index, genomes[gi].n_contigs, sh[0], sh[0] + sh[1]))
+        firsts = [(gi, sh) for gi, sh in enumerate(shards) if sh[1] > 0]
+        if firsts:
+            gi, sh = firsts[0]
+            want = (genomes[gi].index, genomes[gi].n_contigs, sh[0])
+        else:
+            gi, want = None, (0, 1, 0)
+        pos = seek_outer_stream(backend, pieces, want, seed)  # collective: every rank calls it
+        if gi is not None:
+            start[gi] = pos
     out = []
-    for g, (reads, abund), (first, count, id_base) in zip(genomes, ab, shards):
+    for gi, (g, (reads, abund), (first, count, id_base)) in enumerate(zip(genomes, ab, shards)):
         res = None
         if count > 0:
             # the SAME seed for every genome (simulate.rs:137,172)
+            kw = {"start": start[gi]} if start.get(gi, (0, 0)) != (0, 0) else {}
             res = backend.simulate_pe_reads_from_genome(g.index, pod, reads, seed, first=first, count=count,
-                                                        read_id_base=id_base, qual_offset=qual_offset)
+                                                        read_id_base=id_base, qual_offset=qual_offset, **kw)
         out.append((g.filepath, g.uuid, reads, abund, res))
     return out
 

@@ -403,3 +403,45 @@ def test_error_paths(engine, genome_multi):
     assert engine.pe_plan(1, PerfectShortErrorProfile().pod(), 7, 1).n_reads == 6
     out = engine.simulate_pe_reads_from_genome(1, PerfectShortErrorProfile().pod(), 0, 1)
     assert out.n_reads == 0 and out.total_bases == 0
+
+
+# ---- multi-GPU seek in the outer stream (simmr_outer_summarize / simmr_pe_plan_at) ----
+def test_outer_stream_seek(engine, oracle, genome_multi, genome_1m):
+    from simmr_amd.simulate import compose_outer_summaries, outer_slot_floor
+    from tests.test_multi_rank_cpu import outer_accept_bits, replay_outer
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()
+    for gidx, g, seed, per_rank, world in ((0, genome_1m, 42, 20_000, 4), (1, genome_multi, 9, 15_000, 3)):
+        nc = len(g.contigs)
+        total = per_rank * world
+        acc = outer_accept_bits(oracle, nc, seed, outer_slot_floor(nc, total) + 64)
+        pieces = [(gidx, nc, j * per_rank, (j + 1) * per_rank) if j + 1 < world else None for j in range(world)]
+        summaries = []
+        for p in pieces:
+            if p is None:
+                summaries.append((0, 0, 0, 1))
+                continue
+            lo, hi = outer_slot_floor(nc, p[2]), outer_slot_floor(nc, p[3])
+            got = engine.outer_summarize(gidx, seed, lo, hi - lo)
+            (u0, e0), (u1, e1) = replay_outer(acc, lo, hi, 0), replay_outer(acc, lo, hi, 1)
+            assert got == (u0, u1, e0, e1)
+            summaries.append(got)
+        whole = engine.simulate_pe_reads_from_genome(gidx, prof, 2 * total, seed, qual_offset=33).to_host()
+        for r in range(1, world):
+            first = r * per_rank
+            start = compose_outer_summaries(pieces, summaries, (gidx, nc, first))
+            assert start != (0, 0) and start[1] <= first
+            part = engine.simulate_pe_reads_from_genome(gidx, prof, 2 * total, seed, first=first, count=per_rank,
+                                                        read_id_base=5, qual_offset=33, start=start).to_host()
+            a, b = 2 * first, 2 * (first + per_rank)
+            base = whole["seq_off"][a]
+            assert np.array_equal(part["seq_off"], whole["seq_off"][a:b + 1] - base)
+            for col in ("start", "end", "contig", "flags"):
+                assert np.array_equal(part[col], whole[col][a:b]), col
+            assert np.array_equal(part["read_id"], whole["read_id"][a:b] + 5)
+            assert np.array_equal(part["seq"], whole["seq"][base:whole["seq_off"][b]])
+            assert np.array_equal(part["qual"], whole["qual"][base:whole["seq_off"][b]])
+    from simmr_amd import SimmrError
+    with pytest.raises(SimmrError):  # a position past the shard's first pair
+        engine.pe_plan(0, prof, 1000, 42, 10, 20, start=(64, 11))
+    with pytest.raises(SimmrError):  # slot ranges are whole ChaCha blocks
+        engine.outer_summarize(0, 42, 4, 16)

@@ -28,9 +28,17 @@ class OracleBackend:
         self.genomes = [_oracle.HostGenome(_synth.synthetic_contigs(lens, seed)) for lens, seed in GENOMES]
 
     def simulate_pe_reads_from_genome(self, idx, pod, reads, seed, first=0, count=(1 << 64) - 1, read_id_base=0,
-                                      qual_offset=0):
+                                      qual_offset=0, start=(0, 0)):
+        if start != (0, 0):  # the oracle always walks from slot 0: only check the claimed position
+            acc = outer_accept_bits(self.lib, len(self.genomes[idx].contigs), seed, start[0])
+            assert replay_outer(acc, 0, start[0], 0) == (start[1], 0) and start[1] <= first
         return _oracle.simulate_pe(self.lib, self.genomes[idx], pod, reads, seed, first, count, read_id_base,
                                    qual_offset=qual_offset)
+
+    def outer_summarize(self, idx, seed, slot_first, slot_count):
+        acc = outer_accept_bits(self.lib, len(self.genomes[idx].contigs), seed, slot_first + slot_count)
+        (u0, e0), (u1, e1) = (replay_outer(acc, slot_first, slot_first + slot_count, s) for s in (0, 1))
+        return u0, u1, e0, e1
 
     def simulate_long_reads(self, idxs, reads, pod, seed, first=0, count=(1 << 64) - 1, read_id_base=0,
                             qual_offset=0):
@@ -38,8 +46,68 @@ class OracleBackend:
                                      read_id_base, qual_offset=qual_offset)
 
 
+def outer_accept_bits(lib, n_contigs, seed, n_slots):
+    """Per u64 slot of StdRng(seed): would gen_range(0..n_contigs) accept it (rand 0.8.5 sample_single)?
+    Drawn with the oracle's generator (tests only)."""
+    import ctypes as C
+    from tests._oracle import Rng
+    r = Rng()
+    lib.orc_rng_seed_from_u64(C.byref(r), seed)
+    zone = ((n_contigs << (64 - n_contigs.bit_length())) - 1) & ((1 << 64) - 1)
+    acc = np.zeros(n_slots, np.uint8)
+    for i in range(n_slots):
+        v = lib.orc_next_u64(C.byref(r))
+        acc[i] = ((v * n_contigs) & ((1 << 64) - 1)) <= zone
+    return acc
+
+
+def replay_outer(acc, lo, hi, state):
+    """simulate.rs:172-184 over slots [lo, hi) entered in `state` (0 = contig draw, 1 = pe_seed draw):
+    (pairs completed, state after)."""
+    units = 0
+    for i in range(lo, hi):
+        if state == 0:
+            state = 1 if acc[i] else 0
+        else:
+            state, units = 0, units + 1
+    return units, state
+
+
+def test_outer_stream_seek_composition():
+    """Host side of the multi-GPU seek: ranks summarize disjoint slot ranges, the summaries compose to a
+    position (slot, pair) at or before every rank's first pair, and that position is right."""
+    from simmr_amd.simulate import compose_outer_summaries, outer_slot_floor
+    lib = _oracle.load()
+    for n_contigs, seed, per_rank, world in ((1, 42, 9000, 4), (3, 7, 12000, 3), (2, 5, 7000, 5)):
+        total = per_rank * world
+        n_slots = outer_slot_floor(n_contigs, total) + 8
+        acc = outer_accept_bits(lib, n_contigs, seed, n_slots)
+        pieces = [(0, n_contigs, j * per_rank, (j + 1) * per_rank) if j + 1 < world else None for j in range(world)]
+        summaries = []
+        for p in pieces:
+            if p is None:
+                summaries.append((0, 0, 0, 1))
+                continue
+            lo, hi = outer_slot_floor(n_contigs, p[2]), outer_slot_floor(n_contigs, p[3])
+            assert lo % 8 == 0 and hi % 8 == 0 and lo <= hi
+            (u0, e0), (u1, e1) = replay_outer(acc, lo, hi, 0), replay_outer(acc, lo, hi, 1)
+            summaries.append((u0, u1, e0, e1))
+        for r in range(world):
+            first = r * per_rank
+            slot, unit = compose_outer_summaries(pieces, summaries, (0, n_contigs, first))
+            assert unit <= first and (r == 0) == ((slot, unit) == (0, 0))
+            assert replay_outer(acc, 0, slot, 0) == (unit, 0)  # pair `unit` starts at `slot`
+            if r > 0:
+                assert first - unit < 0.03 * first + 3000  # and it is close to the shard
+        # a piece missing from the chain: composition stops there, the position stays valid
+        holes = list(pieces)
+        holes[1] = None
+        slot, unit = compose_outer_summaries(holes, summaries, (0, n_contigs, (world - 1) * per_rank))
+        assert replay_outer(acc, 0, slot, 0) == (unit, 0) and unit <= per_rank
+
+
 def _refs():
-    return [GenomeRef(i, sum(l), f"g{i}.fna", f"id{i}") for i, (l, _) in enumerate(GENOMES)]
+    return [GenomeRef(i, sum(l), f"g{i}.fna", f"id{i}", len(l)) for i, (l, _) in enumerate(GENOMES)]
 
 
 def test_split_and_shards_cover_everything():
