@@ -223,6 +223,19 @@ int simmr_outer_summarize(simmr_engine* e, uint32_t genome_idx, uint64_t seed, u
 int simmr_pe_plan_at(simmr_engine* e, uint32_t genome_idx, const simmr_error_profile* profile,
                      uint64_t genome_reads, uint64_t seed, simmr_range shard, uint64_t start_slot,
                      uint64_t start_unit, simmr_plan_info* info);
+/* simulate_pe_reads (simulate.rs:110-150) over several genomes in ONE plan.  The
+ * reference loops over the genomes and re-creates the outer StdRng with the same
+ * seed for each (simulate.rs:137,172), so genomes with the same number of
+ * sequences draw the same (contig, pe_seed) list: it is generated once per
+ * distinct count and shared.  genome_reads[g] are the per-genome read counts of
+ * the abundance profile; shard is a range of the global pair index (genomes
+ * concatenated in the given order — the order in which the reference's global id
+ * counter, simulate.rs:85-89, numbers the pairs).  simmr_pe_emit then emits the
+ * shard with read_id_base = 0 and fills the `genome` column per read.
+ * SIMMR_ENOTSUP for custom profiles (plan those one genome at a time). */
+int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_idx,
+                        const uint64_t* genome_reads, const simmr_error_profile* profile, int has_seed,
+                        uint64_t seed, simmr_range shard, simmr_plan_info* info);
 /* Emits the planned pairs: bases, qualities, mutations, reverse complement,
  * metadata (simulate.rs:260-299).  read_id_base = id of pair 0 of this genome
  * (the reference's global AtomicU32, simulate.rs:85-89). */

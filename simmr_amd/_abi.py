@@ -125,6 +125,8 @@ SYMBOLS = {
     "simmr_outer_summarize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, _P(OuterSummary)]),
     "simmr_pe_plan_at": (C.c_int, [C.c_void_p, C.c_uint32, _P(ErrorProfilePOD), C.c_uint64, C.c_uint64, Range,
                                    C.c_uint64, C.c_uint64, _P(PlanInfo)]),
+    "simmr_pe_plan_multi": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_uint32), _P(C.c_uint64), _P(ErrorProfilePOD),
+                                      C.c_int, C.c_uint64, Range, _P(PlanInfo)]),
     "simmr_pe_emit": (C.c_int, [C.c_void_p, C.c_uint32, _P(ReadsOut)]),
     "simmr_long_plan": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_uint32), _P(C.c_uint64),
                                   _P(ErrorProfilePOD), C.c_int, C.c_uint64, Range, _P(PlanInfo)]),

@@ -77,6 +77,9 @@ struct simmr_engine {
   uint32_t plan_genome = 0;
   uint64_t plan_first = 0, plan_units = 0, plan_total_bases = 0;
   bool plan_paired = false;
+  bool plan_multi = false;    // paired-end plan over several genomes (u_genome per pair)
+  bool plan_any_exc = false;  // some genome of the plan has an exception plane
+  DevBuf m_genomes, m_contig, m_seed;
   DevBuf u_contig, u_genome, u_seed, u_len, u_a, u_b, u_bytes, u_qs2, u_ms2, u_flags, u_off;
   DevBuf scan_tmp, u_order, len_hist;
   bool plan_sorted = false;
@@ -630,7 +633,7 @@ void simmr_engine_destroy(simmr_engine* e) {
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
                     &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->ph_table,
                     &e->fq_blob, &e->fq_gid_off, &e->fq_gid_len, &e->fq_cbase, &e->fq_ncontig, &e->fq_coff, &e->fq_clen,
-                    &e->fq_len, &e->fq_off};
+                    &e->fq_len, &e->fq_off, &e->m_genomes, &e->m_contig, &e->m_seed};
   for (DevBuf* b : bufs) b->release();
   if (e->ev_a) (void)hipEventDestroy(e->ev_a);
   if (e->ev_b) (void)hipEventDestroy(e->ev_b);
@@ -825,8 +828,8 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     if (rc) return rc;
     hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                        e->d_genomes.as<GenomeDev>(), genome_idx, count, e->u_contig.as<uint32_t>(),
-                       e->u_seed.as<uint64_t>(), plan_arrays(e, seeds2), e->d_tables.as<Tables>(),
-                       e->d_err.as<uint32_t>());
+                       e->u_seed.as<uint64_t>(), (const uint32_t*)nullptr, plan_arrays(e, seeds2),
+                       e->d_tables.as<Tables>(), e->d_err.as<uint32_t>());
   }
   e->plan_sorted = false;
   if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0 &&
@@ -853,6 +856,115 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   e->plan_units = count;
   e->plan_total_bases = total;
   e->plan_paired = true;
+  e->plan_multi = false;
+  e->plan_any_exc = g.has_exc;
+  if (info) {
+    memset(info, 0, sizeof *info);
+    info->n_units = count;
+    info->n_reads = 2 * count;
+    info->total_bases = total;
+    info->seed_used = seed;
+    info->outer_slots = end_slot;
+  }
+  return SIMMR_OK;
+}
+
+// simulate_pe_reads (simulate.rs:110-150) for several genomes in one plan: the shard is a range of the
+// global pair index (genomes concatenated in the given order, ids as the reference's global counter).
+int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_idx, const uint64_t* genome_reads,
+                        const simmr_error_profile* profile, int has_seed, uint64_t seed, simmr_range shard,
+                        simmr_plan_info* info) {
+  if (!e) return SIMMR_EINVAL;
+  e->plan_kind = PLAN_NONE;
+  if (n_genomes == 0 || !genome_idx || !genome_reads) return e->fail(SIMMR_EINVAL, "simmr_pe_plan_multi: no genomes");
+  HIP_TRY(e, hipSetDevice(e->device));
+  int rc;
+  ProfileDev prof;
+  if ((rc = make_profile(e, profile, false, &prof))) return rc;
+  if (prof.kind == SIMMR_K_CUSTOM || (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant != 0))
+    return e->fail(SIMMR_ENOTSUP, "this profile / emit variant is planned one genome at a time (simmr_pe_plan)");
+  // global pair ranges of the genomes (simulate.rs:179: num_reads / 2 pairs each)
+  std::vector<uint64_t> base(n_genomes + 1, 0);
+  for (uint32_t g = 0; g < n_genomes; g++) {
+    if ((rc = check_genome(e, genome_idx[g]))) return rc;
+    base[g + 1] = base[g] + genome_reads[g] / 2;
+  }
+  const uint64_t n_pairs = base[n_genomes];
+  const uint64_t first = std::min(shard.first, n_pairs);
+  const uint64_t count = std::min(shard.count, n_pairs - first);
+  if (!has_seed) seed = os_entropy_u64();  // one draw for the call; the reference draws one per genome (simulate.rs:174)
+  // genomes that overlap the shard; one outer list per distinct number of sequences
+  struct Cls { uint64_t range, need, off; };
+  std::vector<Cls> classes;
+  std::vector<MultiGenome> mg(n_genomes);
+  bool any_exc = false;
+  for (uint32_t g = 0; g < n_genomes; g++) {
+    const GenomeHost& G = e->genomes[genome_idx[g]];
+    mg[g] = MultiGenome{base[g], 0, genome_idx[g], 0};
+    const uint64_t lo = std::max(first, base[g]), hi = std::min(first + count, base[g + 1]);
+    if (hi <= lo) continue;
+    // simulate.rs:220-225: any sequence not larger than minimum_genome_size() can be drawn and is an error
+    for (size_t c = 0; c < G.contigs.size(); c++)
+      if (G.contigs[c].size <= prof.required)
+        return e->fail(SIMMR_EGENOME, "Genome size (%llunt) is smaller than the required length (%u)",
+                       (unsigned long long)G.contigs[c].size, prof.required);
+    any_exc = any_exc || G.has_exc;
+    const uint64_t range = G.contigs.size(), need = hi - base[g];  // local pairs [0, need)
+    size_t ci = 0;
+    while (ci < classes.size() && classes[ci].range != range) ci++;
+    if (ci == classes.size()) classes.push_back(Cls{range, 0, 0});
+    classes[ci].need = std::max(classes[ci].need, need);
+    mg[g].pad = (uint32_t)ci;
+  }
+  uint64_t list_total = 0;
+  for (Cls& c : classes) { c.off = list_total; list_total += c.need; }
+  for (uint32_t g = 0; g < n_genomes; g++) mg[g].cls_off = classes.empty() ? 0 : classes[mg[g].pad].off;
+  const bool seeds2 = prof.kind != SIMMR_K_PERFECT_SHORT;
+  if ((rc = ensure_plan_arrays(e, count, seeds2, true))) return rc;
+  if (!e->m_contig.ensure(std::max<uint64_t>(list_total, 1) * 4) || !e->m_seed.ensure(std::max<uint64_t>(list_total, 1) * 8))
+    return e->fail(SIMMR_ENOMEM, "outer list allocation failed");
+  if ((rc = upload_vec(e, e->m_genomes, mg))) return rc;
+  HIP_TRY(e, hipEventRecord(e->ev_a, e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
+  uint64_t end_slot = 0, total = 0;
+  for (const Cls& c : classes) {  // run_outer synchronises, so `mg` has been uploaded when it returns
+    if ((rc = run_outer(e, seed, c.range, 0, c.need, 0, c.need, e->m_contig.as<uint32_t>() + c.off,
+                        e->m_seed.as<uint64_t>() + c.off, &end_slot)))
+      return rc;
+  }
+  if (count > 0) {
+    hipLaunchKernelGGL(k_multi_units, dim3(grid_for(count, 256)), dim3(256), 0, e->stream, e->m_genomes.as<MultiGenome>(),
+                       n_genomes, first, count, e->m_contig.as<uint32_t>(), e->m_seed.as<uint64_t>(),
+                       e->u_genome.as<uint32_t>(), e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>());
+    hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
+                       e->d_genomes.as<GenomeDev>(), 0u, count, e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(),
+                       e->u_genome.as<uint32_t>(), plan_arrays(e, seeds2), e->d_tables.as<Tables>(),
+                       e->d_err.as<uint32_t>());
+  }
+  e->plan_sorted = false;
+  if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && (rc = sort_by_length(e, count, 0)))
+    return rc;
+  if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
+    total = count * 2ull * prof.read_length;
+  } else if ((rc = scan_offsets(e, count, &total))) {
+    return rc;
+  }
+  HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
+  uint32_t errw = 0;
+  if ((rc = read_err_word(e, &errw))) return rc;  // also: the host vector `mg` may go out of scope now
+  if (errw & SIMMR_ERRBIT_GENOME) return e->fail(SIMMR_EGENOME, "a sequence is smaller than the required length");
+  if (errw & SIMMR_ERRBIT_SLICE)
+    return e->fail(SIMMR_ERANGE, "a read would extend past its sequence (the reference panics on this slice)");
+  (void)hipEventElapsedTime(&e->last_plan_ms, e->ev_a, e->ev_b);
+  e->plan_kind = PLAN_PE;
+  e->prof = prof;
+  e->plan_genome = genome_idx[0];
+  e->plan_first = first;
+  e->plan_units = count;
+  e->plan_total_bases = total;
+  e->plan_paired = true;
+  e->plan_multi = true;
+  e->plan_any_exc = any_exc;
   if (info) {
     memset(info, 0, sizeof *info);
     info->n_units = count;
@@ -872,7 +984,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
   if (rc) return rc;
   const bool seeds2 = paired && e->prof.kind != SIMMR_K_PERFECT_SHORT;
   PlanArrays pl = plan_arrays(e, seeds2);
-  const uint32_t* u_genome = paired ? nullptr : e->u_genome.as<uint32_t>();
+  const uint32_t* u_genome = (paired && !e->plan_multi) ? nullptr : e->u_genome.as<uint32_t>();
   // the Philox and perfect-short emit kernels write the metadata columns and the plan counters themselves
   const bool fused = n_units > 0 && (e->prof.kind == SIMMR_K_PERFECT_SHORT ||
                                      (e->prof.kind != SIMMR_K_CUSTOM && e->prof.rng_mode == SIMMR_RNG_PHILOX));
@@ -886,14 +998,16 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
     if (e->prof.kind == SIMMR_K_PERFECT_SHORT) {
       const uint64_t groups = (n_reads + PERFECT_GROUP - 1) / PERFECT_GROUP;
       const uint32_t grid = (uint32_t)std::min<uint64_t>(groups, (uint64_t)e->n_cu * 8);
-      hipLaunchKernelGGL(k_emit_perfect_pe, dim3(grid), dim3(256), 0, e->stream, e->d_genomes.as<GenomeDev>(),
-                         e->plan_genome, n_units, e->prof.read_length, pl, e->u_contig.as<uint32_t>(), out->seq,
+      auto kern = e->plan_multi ? k_emit_perfect_pe<true> : k_emit_perfect_pe<false>;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->d_genomes.as<GenomeDev>(),
+                         e->plan_genome, u_genome, e->plan_any_exc ? 1u : 0u, n_units, e->prof.read_length, pl,
+                         e->u_contig.as<uint32_t>(), out->seq,
                          out->qual, 60u + out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
     } else if (e->prof.rng_mode == SIMMR_RNG_PHILOX) {
       const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
       const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
       bool exc = false;
-      if (paired) exc = e->genomes[e->plan_genome].has_exc;
+      if (paired) exc = e->plan_any_exc;
       else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
       auto kern = exc ? k_emit_philox<true> : k_emit_philox<false>;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
@@ -910,7 +1024,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
     } else if (e->emit_variant == 0) {
       // lane-per-read kernel: template on (exception plane present, paired, perfect-long Phred)
       bool exc = false;
-      if (paired) exc = e->genomes[e->plan_genome].has_exc;
+      if (paired) exc = e->plan_any_exc;
       else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
       const bool pl_kind = e->prof.kind == SIMMR_K_PERFECT_LONG;
       using KernT = void (*)(ProfileDev, const GenomeDev*, uint32_t, uint64_t, const uint32_t*, PlanArrays,
@@ -940,7 +1054,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
   if (n_units > 0 && !fused) {
     const bool perfect = e->prof.kind == SIMMR_K_PERFECT_SHORT;
-    const bool acgt_all = perfect && !e->genomes[e->plan_genome].has_exc;
+    const bool acgt_all = perfect && !e->plan_any_exc;
     hipLaunchKernelGGL(k_count_plan, dim3(std::min<uint32_t>(grid_for(n_units, 256), (uint32_t)e->n_cu * 4)), dim3(256), 0, e->stream, paired ? 1u : 0u,
                        n_units, pl, perfect ? 60u : 0u, acgt_all ? 1u : 0u, counters);
   }

@@ -335,14 +335,41 @@ SIMMR_DEV uint32_t pdf_sample_words(const uint32_t* __restrict__ W, uint32_t nw,
 
 #define PLAN_THREADS 256
 
+// simulate_pe_reads over several genomes in one plan (simulate.rs:110-150): every genome re-creates
+// the outer StdRng with the same seed (simulate.rs:137,172), so genomes with the same number of
+// sequences draw the same (contig, pe_seed) list; it is generated once per class and looked up here.
+struct MultiGenome {
+  uint64_t base;     // global index of the genome's first pair
+  uint64_t cls_off;  // start of its class's list in cls_contig / cls_seed
+  uint32_t slot;     // engine genome slot
+  uint32_t pad;
+};
+
+extern "C" __global__ void __launch_bounds__(256)
+k_multi_units(const MultiGenome* __restrict__ mg, uint32_t n_genomes, uint64_t first, uint64_t n_units,
+              const uint32_t* __restrict__ cls_contig, const uint64_t* __restrict__ cls_seed,
+              uint32_t* __restrict__ u_genome, uint32_t* __restrict__ u_contig, uint64_t* __restrict__ u_seed) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_units) return;
+  const uint64_t gp = first + k;  // global pair index
+  uint32_t lo = 0, hi = n_genomes;  // last genome with base <= gp (genomes without pairs share a base: take the last)
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (mg[mid].base <= gp) lo = mid; else hi = mid; }
+  const MultiGenome g = mg[lo];
+  const uint64_t p = gp - g.base;
+  u_genome[k] = g.slot;
+  u_contig[k] = cls_contig[g.cls_off + p];
+  u_seed[k] = cls_seed[g.cls_off + p];
+}
+
 extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
 k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
           const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
-          PlanArrays pl, const Tables* __restrict__ T, uint32_t* __restrict__ err) {
+          const uint32_t* __restrict__ u_genome, PlanArrays pl, const Tables* __restrict__ T,
+          uint32_t* __restrict__ err) {
   __shared__ uint32_t rows[PLAN_THREADS * 17];
   uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
   if (k >= n_units) return;
-  const GenomeDev G = genomes[genome];
+  const GenomeDev G = genomes[u_genome ? u_genome[k] : genome];  // u_genome: several genomes in one plan
   const uint64_t size = G.contigs[u_contig[k]].size;
   const uint64_t pe_seed = u_seed[k];
   LaneRng rng;
@@ -693,13 +720,25 @@ SIMMR_DEV void gather_piece(const GenomeDev& G, const PieceSrc& s, uint32_t k, u
 // Each thread first writes the source position of one read to LDS (one coalesced pass over the plan
 // columns, one contig-table lookup per read instead of one per chunk); the chunk loop then needs
 // only LDS and the packed plane.  Chunk -> (read, offset) advances incrementally (no division).
-extern "C" __global__ void __launch_bounds__(256)
-k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
+// MULTI: the plan spans several genomes (u_genome[] per pair); the planes of a read then come from LDS.
+template <bool MULTI>
+__global__ void __launch_bounds__(256)
+k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, const uint32_t* __restrict__ u_genome,
+                  uint32_t any_exc, uint64_t n_units,
                   uint32_t L, PlanArrays pl, const uint32_t* __restrict__ u_contig,
                   uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_byte,
                   uint64_t first_unit, uint32_t read_id_base, OutCols o, unsigned long long* __restrict__ counters) {
   __shared__ int64_t r_pos[PERFECT_GROUP];  // absolute base position of output byte 0's source
-  const GenomeDev G = genomes[genome];
+  __shared__ const uint32_t* r_packed[MULTI ? PERFECT_GROUP : 1];
+  __shared__ const uint32_t* r_mask[MULTI ? PERFECT_GROUP : 1];
+  GenomeDev G = genomes[genome];
+  if (MULTI) G.has_exc = any_exc;  // uniform: does any genome of the plan have an exception plane
+  // the planes of read rr of the current group
+  auto planes = [&](uint32_t rr) {
+    GenomeDev R = G;
+    if (MULTI) { R.packed = r_packed[rr]; R.mask = r_mask[rr]; R.has_exc = r_mask[rr] != nullptr; }
+    return R;
+  };
   const uint64_t n_reads = 2 * n_units;
   const uint64_t n_groups = (n_reads + PERFECT_GROUP - 1) / PERFECT_GROUP;
   const uint32_t q4 = qual_byte * 0x01010101u;
@@ -720,14 +759,17 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64
       const uint32_t contig = u_contig[u];
       const uint32_t rev = (uint32_t)(r & 1u);
       const uint64_t pos = rev ? pl.b[u] : pl.a[u];
-      r_pos[threadIdx.x] = (int64_t)(G.contigs[contig].base + (rev ? pos + L - 1 : pos));  // mate 2: byte k comes from pos - k
+      const uint32_t gslot = MULTI ? u_genome[u] : genome;
+      const GenomeDev Gr = MULTI ? genomes[gslot] : G;
+      if (MULTI) { r_packed[threadIdx.x] = Gr.packed; r_mask[threadIdx.x] = Gr.has_exc ? Gr.mask : nullptr; }
+      r_pos[threadIdx.x] = (int64_t)(Gr.contigs[contig].base + (rev ? pos + L - 1 : pos));  // mate 2: byte k comes from pos - k
       // metadata columns of this read (k_write_meta is not launched for this kernel)
       o.seq_off[r] = r * L;
       if (r + 1 == n_reads) o.seq_off[n_reads] = n_reads * L;  // closing CSR offset
       if (o.start) o.start[r] = rev ? pos + L : pos;  // simulate.rs:289,295
       if (o.end) o.end[r] = rev ? pos : pos + L;      // simulate.rs:290,296
       if (o.contig) o.contig[r] = contig;
-      if (o.genome) o.genome[r] = genome;
+      if (o.genome) o.genome[r] = gslot;
       if (o.read_id) o.read_id[r] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
       if (o.flags) o.flags[r] = rev ? (uint8_t)pl.flags[u] : 0;
     }
@@ -753,10 +795,11 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64
               if (pc == 1 && !(cna[j] < 16u && r < n_in)) continue;
               const int64_t pos = r_pos[r];
               const int64_t p = (r & 1u) ? pos - (int64_t)(pc ? 0u : k0) - 15 : pos + (int64_t)(pc ? 0u : k0);
-              raw[j][pc] = load_plane_u64(G.packed, p >> 4);
+              raw[j][pc] = load_plane_u64(MULTI ? r_packed[r] : G.packed, p >> 4);
               sh[j][pc] = (uint32_t)(p & 15) * 2u;
               if (G.has_exc) {
-                rawm[j][pc] = load_plane_u64(G.mask, p >> 5);
+                const uint32_t* mk = MULTI ? r_mask[r] : G.mask;
+                if (mk) rawm[j][pc] = load_plane_u64(mk, p >> 5);
                 shm[j][pc] = (uint32_t)(p & 31);
               }
             }
@@ -812,14 +855,14 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, uint64
       const uint32_t lb = cl << 4;
       const uint32_t na = (L - k0) < 16u ? (L - k0) : 16u;  // bytes taken from read r_base + rl
       uint32_t codes, exc;
-      gather_piece(G, PieceSrc{r_pos[rl], rl & 1u}, k0, codes, exc);
+      gather_piece(planes(rl), PieceSrc{r_pos[rl], rl & 1u}, k0, codes, exc);
       if (na < 16u) {
         uint32_t filled = na, r = rl + 1;
         codes &= (1u << (2 * filled)) - 1u;
         exc &= (1u << filled) - 1u;
         while (filled < 16u && r < n_in) {
           uint32_t c2, e2;
-          gather_piece(G, PieceSrc{r_pos[r], r & 1u}, 0, c2, e2);
+          gather_piece(planes(r), PieceSrc{r_pos[r], r & 1u}, 0, c2, e2);
           const uint32_t take = (16u - filled) < L ? (16u - filled) : L;
           if (take < 16u) { c2 &= (1u << (2 * take)) - 1u; e2 &= (1u << take) - 1u; }
           codes |= c2 << (2 * filled);
@@ -1618,7 +1661,7 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
       rev = PAIRED ? (uint32_t)(task & 1u) : 0u;
       L = pl.len[u];
       off = u_off[u] + (rev ? L : 0u);
-      const GenomeDev G = genomes[PAIRED ? genome : u_genome[u]];
+      const GenomeDev G = genomes[u_genome ? u_genome[u] : genome];
       packed = G.packed;
       mask = G.mask;
       src = G.contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]);

@@ -180,6 +180,25 @@ class Engine:
         self._check(self.lib.simmr_outer_summarize(self._h, genome_idx, seed, slot_first, slot_count, C.byref(s)))
         return int(s.units[0]), int(s.units[1]), int(s.end_state[0]), int(s.end_state[1])
 
+    def pe_plan_multi(self, genome_idx: Sequence[int], genome_reads: Sequence[int], profile: ErrorProfilePOD,
+                      seed: Optional[int], first: int = 0, count: int = U64_MAX) -> PlanInfo:
+        """simulate_pe_reads over several genomes in one plan; [first, first + count) is a range of the
+        global pair index (genomes concatenated in order)."""
+        n = len(genome_idx)
+        gi = (C.c_uint32 * n)(*[int(x) for x in genome_idx])
+        gr = (C.c_uint64 * n)(*[int(x) for x in genome_reads])
+        info = PlanInfo()
+        self._check(self.lib.simmr_pe_plan_multi(self._h, n, gi, gr, C.byref(profile), 0 if seed is None else 1,
+                                                 0 if seed is None else seed, Range(first, count), C.byref(info)))
+        return info
+
+    def simulate_pe_reads_multi(self, genome_idx, genome_reads, profile, seed, first=0, count=U64_MAX,
+                                qual_offset=0) -> Reads:
+        info = self.pe_plan_multi(genome_idx, genome_reads, profile, seed, first, count)
+        out = Reads.allocate(info.n_reads, info.total_bases, self.device, qual_offset)
+        self.pe_emit(0, out)
+        return out
+
     def pe_emit(self, read_id_base: int, out: Reads):
         pod = out.pod()
         self._check(self.lib.simmr_pe_emit(self._h, read_id_base, C.byref(pod)))

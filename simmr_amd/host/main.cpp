@@ -181,8 +181,35 @@ static int run_main(int argc, char** argv) {
 
   if (!is_long) {
     info("Simulating short reads");
+    // all genomes in one device plan (simulate_pe_reads, simulate.rs:110-150); the library leaves
+    // custom profiles to the genome-by-genome loop below
+    std::vector<uint32_t> all_idx(genomes.size());
+    std::vector<uint64_t> all_reads(genomes.size());
+    for (size_t gi = 0; gi < genomes.size(); gi++) { all_idx[gi] = (uint32_t)gi; all_reads[gi] = ab[gi].first; }
+    simmr_plan_info mpi{};
+    const int mrc = simmr_pe_plan_multi(eng, (uint32_t)genomes.size(), all_idx.data(), all_reads.data(), &pod, has_seed, seed, all, &mpi);
+    if (mrc != SIMMR_OK && mrc != SIMMR_ENOTSUP) return die(simmr_last_error(eng));
+    if (mrc == SIMMR_OK) {
+      DeviceOut d;
+      if (!d.init(mpi.n_reads, mpi.total_bases)) return die("device allocation failed");
+      if (simmr_pe_emit(eng, 0, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
+      int fq = args.host_fastq ? 1 : write_fastq_device(eng, args.read_header_format, genomes, 0, genomes.size(), d.o, mpi.n_reads,
+                                                      true, args.output, &err);
+      if (fq < 0) fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+      if (fq > 0) {  // host writer (fastq.rs restated in host.cpp), genome by genome
+        HostReads h;
+        if (!d.to_host(mpi.n_reads, mpi.total_bases, true, &h)) return die("copy back failed");
+        uint64_t first_read = 0;
+        for (size_t gi = 0; gi < genomes.size(); gi++) {
+          const uint64_t n = ab[gi].first / 2 * 2;
+          if (!write_to_fastq(genomes[gi].uuid, genomes[gi], h, first_read, n, args.output, args.read_header_format, true, &err))
+            fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+          first_read += n;
+        }
+      }
+    }
     uint32_t id_base = 0;  // the global AtomicU32 of simulate.rs:85-89
-    for (size_t gi = 0; gi < genomes.size(); gi++) {
+    for (size_t gi = 0; mrc == SIMMR_ENOTSUP && gi < genomes.size(); gi++) {
       simmr_plan_info pi{};
       if (simmr_pe_plan(eng, (uint32_t)gi, &pod, ab[gi].first, has_seed, seed, all, &pi) != SIMMR_OK)
         return die(simmr_last_error(eng));  // the reference unwrap()s this Err (simulate.rs:137)

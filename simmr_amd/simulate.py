@@ -171,6 +171,23 @@ def simulate_pe_reads(backend, num_reads: int, genomes: Sequence[GenomeRef], err
     return out
 
 
+def simulate_pe_reads_batched(backend, num_reads: int, genomes: Sequence[GenomeRef], error_profile: ErrorProfile,
+                              abundance_profile: AbundanceProfile, seed: Optional[int], rank: int = 0,
+                              world: int = 1, qual_offset: int = 0):
+    """simulate_pe_reads (simulate.rs:110-150) with all genomes in ONE device plan
+    (`simmr_pe_plan_multi`): same reads, ids and order as the per-genome loop, returned like
+    simulate_long_reads as (per-genome metadata, reads of this rank's range of the global pair
+    index).  For runs over many genomes (BASELINE config 4) this removes the per-genome launch
+    and synchronisation cost."""
+    ab = determine_reads(num_reads, genomes, error_profile, abundance_profile, True)
+    reads_per_genome = [r for r, _ in ab]
+    first, count = split_range(sum(r // 2 for r in reads_per_genome), rank, world)
+    reads = backend.simulate_pe_reads_multi([g.index for g in genomes], reads_per_genome, error_profile.pod(), seed,
+                                            first=first, count=count, qual_offset=qual_offset)
+    meta = [(g.filepath, g.uuid, r, a) for g, (r, a) in zip(genomes, ab)]
+    return meta, reads
+
+
 def simulate_long_reads(backend, num_reads: int, genomes: Sequence[GenomeRef], error_profile: ErrorProfile,
                         abundance_profile: AbundanceProfile, seed: Optional[int], rank: int = 0, world: int = 1,
                         qual_offset: int = 0):

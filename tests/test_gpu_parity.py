@@ -445,3 +445,54 @@ def test_outer_stream_seek(engine, oracle, genome_multi, genome_1m):
         engine.pe_plan(0, prof, 1000, 42, 10, 20, start=(64, 11))
     with pytest.raises(SimmrError):  # slot ranges are whole ChaCha blocks
         engine.outer_summarize(0, 42, 4, 16)
+
+
+# ---- simulate_pe_reads over several genomes in one plan (simmr_pe_plan_multi) ----
+@pytest.mark.parametrize("kind", ["perfect", "minimal", "philox", "perfect17"])
+def test_pe_plan_multi_equals_per_genome_calls(engine, oracle, genome_multi, genome_1m, kind):
+    """Same reads, ids and order as the reference's loop over genomes (simulate.rs:121-150), checked against
+    the oracle genome by genome; genomes 0 and 4 have one sequence and share one outer list, a genome
+    without reads and one with an exception plane are in the middle."""
+    rng = np.random.default_rng(5)
+    exc = _synth.synthetic_contigs([50_000], 33)[0].copy()
+    exc[rng.integers(0, 50_000, 4000)] = ord("N")
+    engine.stage_genome(4, [exc])
+    hosts = {0: genome_1m, 1: genome_multi, 4: _oracle.HostGenome([exc])}
+    order, reads = [0, 1, 4, 1], [3000, 2501, 0, 1801]
+    if kind != "perfect17":
+        order, reads = order + [4], reads + [2200]
+    prof = {"perfect": PerfectShortErrorProfile(), "minimal": MinimalShortErrorProfile(),
+            "philox": MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX, mean_phred_score=25),
+            "perfect17": PerfectShortErrorProfile(read_length=17, insert_size=40)}[kind].pod()
+    seed = 77
+    parts, base = [], 0
+    for gi, n in zip(order, reads):
+        o = _oracle.simulate_pe(oracle, hosts[gi], prof, n, seed, read_id_base=base, qual_offset=33).trimmed()
+        o["genome"] = np.full(o["read_id"].size, gi, np.uint32)
+        parts.append(o)
+        base += n // 2
+    lens = np.concatenate([np.diff(p["seq_off"].astype(np.int64)) for p in parts])
+    whole = {c: np.concatenate([p[c] for p in parts]) for c in ("seq", "qual", "start", "end", "contig", "genome", "read_id", "flags")}
+    whole["seq_off"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n_pairs = base
+    engine.counters_reset()
+    dev = engine.simulate_pe_reads_multi(order, reads, prof, seed, qual_offset=33)
+    assert_same(dev.to_host(), whole, cols=COLS + ("genome",))
+    c = engine.counters()
+    assert c[_abi.CNT_READS] == 2 * n_pairs and c[_abi.CNT_BASES] == lens.sum()
+    for first, count in ((0, 10), (1400, 300), (2700, 1500), (n_pairs - 7, 50)):  # ranges across genome borders
+        d = engine.simulate_pe_reads_multi(order, reads, prof, seed, first=first, count=count, qual_offset=33).to_host()
+        a, b = 2 * first, 2 * min(first + count, n_pairs)
+        o0 = whole["seq_off"][a]
+        assert np.array_equal(d["seq_off"], whole["seq_off"][a:b + 1] - o0)
+        for col in ("start", "end", "contig", "genome", "read_id", "flags"):
+            assert np.array_equal(d[col], whole[col][a:b]), (col, first)
+        assert np.array_equal(d["seq"], whole["seq"][o0:whole["seq_off"][b]])
+        assert np.array_equal(d["qual"], whole["qual"][o0:whole["seq_off"][b]])
+    engine.stage_genome(4, [exc[:400]])  # too small for 2 * 150 + 150
+    if kind != "perfect17":
+        from simmr_amd import SimmrError
+        with pytest.raises(SimmrError) as ei:
+            engine.pe_plan_multi(order, reads, prof, seed)
+        assert ei.value.code == _abi.EGENOME
+        engine.pe_plan_multi(order, reads, prof, seed, first=0, count=100)  # that genome is outside the shard
