@@ -94,7 +94,7 @@ struct simmr_engine {
   DevBuf fq_blob, fq_gid_off, fq_gid_len, fq_cbase, fq_ncontig, fq_coff, fq_clen, fq_len, fq_off;
   FqTemplate fq_tpl{};
   uint64_t fq_reads = 0, fq_total = 0;
-  uint32_t fq_slots = 0, fq_lit_bytes = 0;
+  uint32_t fq_slots = 0, fq_lit_bytes = 0, fq_hpitch = 272;
   bool fq_paired = false, fq_ready = false;
 
   int fail(int code, const char* fmt, ...) {
@@ -1319,10 +1319,12 @@ int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fas
                        e->fq_len.as<uint64_t>(), e->d_err.as<uint32_t>());
   uint64_t total = 0;
   if ((rc = scan_u64(e, e->fq_len, n_reads, e->fq_off, &total))) return rc;  // also waits for the uploads
-  uint32_t errw = 0;
-  if ((rc = read_err_word(e, &errw))) return rc;
-  if (errw & SIMMR_ERRBIT_FASTQ)
+  uint32_t errw2[2] = {0, 0};  // error bits, longest header
+  HIP_TRY(e, hipMemcpyAsync(errw2, e->d_err.p, 8, hipMemcpyDeviceToHost, e->stream));
+  if ((rc = sync_check(e, "fastq size readback"))) return rc;
+  if (errw2[0] & SIMMR_ERRBIT_FASTQ)
     return e->fail(SIMMR_ENOTSUP, "a FASTQ header is longer than %u bytes, or a read names a genome / contig without an id", FQ_HMAX - 1);
+  e->fq_hpitch = (errw2[1] + 1u + 8u + 15u) & ~15u;  // header, '\n', slack of the 8-byte id copies and 16-byte window reads
   e->fq_reads = n_reads;
   e->fq_total = total;
   e->fq_slots = n_slots;
@@ -1350,10 +1352,10 @@ int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst
   const FqReads rd{reads->seq, reads->qual, reads->seq_off, reads->start, reads->end, reads->contig, reads->genome,
                    reads->read_id, reads->flags};
   const uint64_t n_batches = (e->fq_reads + FQ_BATCH - 1) / FQ_BATCH;
-  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 4);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 8);
   HIP_TRY(e, hipEventRecord(e->ev_c, e->stream));
-  hipLaunchKernelGGL(k_fastq_write, dim3(grid), dim3(256), 0, e->stream, e->fq_tpl, tb, rd, e->fq_reads,
-                     e->fq_paired ? 1u : 0u, e->fq_lit_bytes, e->fq_off.as<uint64_t>(), dst);
+  hipLaunchKernelGGL(k_fastq_write, dim3(grid), dim3(256), 4 * FQ_BATCH * e->fq_hpitch, e->stream, e->fq_tpl, tb, rd,
+                     e->fq_reads, e->fq_paired ? 1u : 0u, e->fq_lit_bytes, e->fq_hpitch, e->fq_off.as<uint64_t>(), dst);
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
   hipError_t s = hipGetLastError();
   if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "fastq launch failed: %s", hipGetErrorString(s));

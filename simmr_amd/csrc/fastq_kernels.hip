@@ -13,8 +13,9 @@
 // pieces, decimals in 32-bit arithmetic when they fit).  A record is three byte
 // runs — header+'\n' (from LDS), bases+"\n+\n", qualities+'\n' (from the SoA
 // columns) — cut into unaligned 16-byte windows; the windows of all 32 records are
-// dealt to the 64 lanes (prefix of window counts in LDS, branch-free search), so
-// every lane has an independent load -> store in flight.  The last window of a run
+// dealt to the 64 lanes (prefix of window counts in LDS, branch-free search);
+// a lane resolves several windows without a branch (one LDS and one global load
+// each, the unused one at a harmless address) so their loads are in flight together.  The last window of a run
 // ends exactly at the run's end (it overlaps its neighbour with identical bytes),
 // so there are no partial stores; the constant trailer bytes are shifted into it.
 #pragma once
@@ -23,7 +24,6 @@ namespace simmr {
 
 #define FQ_MAX_SEGS 24
 #define FQ_HMAX 256u  /* longest header, including the '\n' */
-#define FQ_HPITCH 264u /* LDS bytes per header slot: 8-byte copies may run past the end */
 #define FQ_LIT_MAX 256u /* template literals kept in LDS (they are part of a header, so < FQ_HMAX) */
 #define FQ_BATCH 32u  /* reads per wave iteration */
 
@@ -115,6 +115,7 @@ k_fastq_size(FqTemplate tp, FqTables tb, FqReads rd, uint64_t n_reads, uint64_t*
   if (r >= n_reads) return;
   const uint32_t h = fq_header_len(tp, tb, rd, r);
   if (h >= FQ_HMAX) { atomicOr(err, SIMMR_ERRBIT_FASTQ); rec_len[r] = 0; return; }  // header + '\n' must fit the LDS slot
+  atomicMax(err + 1, h);  // the longest header sizes the LDS slots of k_fastq_write
   const uint64_t L = rd.seq_off[r + 1] - rd.seq_off[r];
   rec_len[r] = (uint64_t)h + 1u + L + 3u + L + 1u;
 }
@@ -123,33 +124,16 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
 typedef const __attribute__((address_space(1))) u32x4_unaligned* global_u128_unaligned_ptr;
 
-// the 16 bytes x >> (8 * t) with the low t bytes of `fill` in the t vacated top bytes, 1 <= t <= 3
+// the 16 bytes x >> (8 * t) with the low t bytes of `fill` in the t vacated top bytes, 0 <= t <= 3
 SIMMR_DEV u32x4 fq_shift_in(u32x4 x, uint32_t t, uint32_t fill) {
   const uint32_t sh = 8u * t;
   u32x4 y;
   y.x = __builtin_amdgcn_alignbit(x.y, x.x, sh);
   y.y = __builtin_amdgcn_alignbit(x.z, x.y, sh);
   y.z = __builtin_amdgcn_alignbit(x.w, x.z, sh);
-  y.w = (x.w >> sh) | (fill << (32u - sh));
+  // (fill << (32 - sh)) without a shift by 32 when t == 0
+  y.w = (x.w >> sh) | (uint32_t)(((uint64_t)(fill & ((1u << sh) - 1u)) << 32) >> sh);
   return y;
-}
-
-// One unaligned 16-byte window of the run src[0, n_src) + k trailer bytes (`fill`, first byte lowest; k <= 3),
-// written to dst.  Window `piece` of `n_pieces` starts at 16 * piece, except the last one, which ends at the
-// end of the run (so it overlaps its neighbour — with identical bytes: every window is exact, including the
-// trailer bytes it covers).  Needs n_src >= 16; source loads never leave src[0, n_src).
-SIMMR_DEV void fq_copy_window(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n_src, uint32_t k,
-                              uint32_t fill, uint32_t piece, uint32_t n_pieces) {
-  const uint32_t n = n_src + k;
-  const uint32_t w = piece + 1 < n_pieces ? piece * 16u : n - 16u;
-  u32x4 v;
-  if (w + 16u <= n_src) {
-    v = *(global_u128_unaligned_ptr)(src + w);
-  } else {
-    const uint32_t t = w + 16u - n_src;  // trailer bytes inside this window
-    v = fq_shift_in(*(global_u128_unaligned_ptr)(src + n_src - 16u), t, fill & (0xffffffffu >> (32u - 8u * t)));
-  }
-  *reinterpret_cast<u32x4_unaligned*>(dst + w) = v;
 }
 
 struct FqRead {  // what the copy phase needs to know about a record
@@ -158,14 +142,17 @@ struct FqRead {  // what the copy phase needs to know about a record
   uint32_t H, L;   // header length including the '\n'; read length
 };
 
+#define FQ_UNROLL 4 /* windows per lane in flight */
+
 extern "C" __global__ void __launch_bounds__(256)
 k_fastq_write(FqTemplate tp, FqTables tb, FqReads rd, uint64_t n_reads, uint32_t paired, uint32_t lit_bytes,
-              const uint64_t* __restrict__ rec_off, uint8_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint8_t hdr[4][FQ_BATCH][FQ_HPITCH];
+              uint32_t hpitch, const uint64_t* __restrict__ rec_off, uint8_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t hdr_all[];  // [4 waves][FQ_BATCH][hpitch], hpitch % 16 == 0
   __shared__ __attribute__((aligned(16))) uint8_t lit[FQ_LIT_MAX + 8];
   __shared__ FqRead recs[4][FQ_BATCH];
   __shared__ uint32_t wpre[4][FQ_BATCH + 1];  // first window of each record of the batch
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint8_t* hdr = hdr_all + (size_t)wave * FQ_BATCH * hpitch;
   for (uint32_t i = threadIdx.x; i < lit_bytes; i += 256) lit[i] = tb.blob[i];
   __syncthreads();
   const uint64_t n_batches = (n_reads + FQ_BATCH - 1) / FQ_BATCH;
@@ -177,7 +164,7 @@ k_fastq_write(FqTemplate tp, FqTables tb, FqReads rd, uint64_t n_reads, uint32_t
     uint32_t nwin = 0;
     if (lane < nb) {
       const uint64_t r = r0 + lane;
-      uint8_t* h = hdr[wave][lane];
+      uint8_t* h = hdr + lane * hpitch;
       const uint32_t g = rd.genome[r];
       const uint32_t row = tb.g_cbase[g] + rd.contig[r];
       const uint32_t gid_off = tb.g_id_off[g], gid_len = tb.g_id_len[g], sid_off = tb.c_off[row], sid_len = tb.c_len[row];
@@ -214,39 +201,68 @@ k_fastq_write(FqTemplate tp, FqTables tb, FqReads rd, uint64_t n_reads, uint32_t
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     const uint32_t total = wpre[wave][FQ_BATCH];
-    // ---- phase 2: every lane moves one window of one record
-    for (uint32_t win = lane; win < total; win += 64) {
-      uint32_t i = 0;  // record of this window: last i with wpre[i] <= win (lanes past nb hold the total)
+    // ---- phase 2: every lane moves windows of the batch's records.  A window of a run of n_src source
+    // bytes + k trailer bytes starts at 16 * piece, except the last one, which ends at the end of the run (it
+    // overlaps its neighbour with identical bytes: every window is exact, trailer bytes included); source
+    // loads never leave the run.  Runs shorter than 16 bytes are one "window" copied bytewise afterwards.
+    for (uint32_t win0 = lane; win0 < total; win0 += 64 * FQ_UNROLL) {
+      u32x4 v[FQ_UNROLL];
+      uint8_t* dst[FQ_UNROLL];
+      uint32_t slow[FQ_UNROLL];
 #pragma unroll
-      for (uint32_t step = FQ_BATCH / 2; step; step >>= 1)
-        if (wpre[wave][i + step] <= win) i += step;
-      const FqRead R = recs[wave][i];
-      uint32_t k = win - wpre[wave][i];
-      uint8_t* rec = out + R.rec;
-      const uint32_t wA = R.H >= 16u ? (R.H + 15u) >> 4 : 1u;
-      if (k < wA) {  // run A: header + '\n' from LDS
-        const uint8_t* h = hdr[wave][i];
-        if (R.H >= 16u) {
-          const uint32_t w = k + 1 < wA ? k * 16u : R.H - 16u;
-          *reinterpret_cast<u32x4_unaligned*>(rec + w) = *reinterpret_cast<const u32x4_unaligned*>(h + w);
-        } else {
-          for (uint32_t j = 0; j < R.H; j++) rec[j] = h[j];
-        }
-        continue;
+      for (int u = 0; u < FQ_UNROLL; u++) {
+        const uint32_t win = win0 + 64u * u;
+        const bool on = win < total;
+        uint32_t i = 0;  // record of this window: last i with wpre[i] <= win (lanes past nb hold the total)
+#pragma unroll
+        for (uint32_t step = FQ_BATCH / 2; step; step >>= 1)
+          if (wpre[wave][i + step] <= win) i += step;
+        if (!on) i = 0;
+        const FqRead R = recs[wave][i];
+        const uint32_t k0 = win - wpre[wave][i];
+        const uint32_t wA = R.H >= 16u ? (R.H + 15u) >> 4 : 1u;
+        const uint32_t npB = R.L >= 16u ? (R.L + 3u + 15u) >> 4 : 1u;
+        const bool isA = k0 < wA, isB = !isA && k0 - wA < npB;
+        // the run: n_src source bytes, kt trailer bytes, `piece` of `np` windows, destination offset in the record
+        const uint32_t n_src = isA ? R.H : R.L, kt = isA ? 0u : (isB ? 3u : 1u);
+        const uint32_t fill = isB ? 0x0a2b0au : 0x0au;
+        const uint32_t piece = isA ? k0 : (isB ? k0 - wA : k0 - wA - npB);
+        const uint32_t np = isA ? wA : (isB ? npB : (R.L >= 16u ? (R.L + 1u + 15u) >> 4 : 1u));
+        const uint32_t run_off = isA ? 0u : (isB ? R.H : R.H + R.L + 3u);
+        const bool fast = on && n_src >= 16u;
+        const uint32_t n = n_src + kt;
+        const uint32_t w = fast ? (piece + 1 < np ? piece * 16u : n - 16u) : 0u;
+        const bool shifted = fast && w + 16u > n_src;  // the window reaches into the trailer
+        const uint32_t t = shifted ? w + 16u - n_src : 0u;
+        const uint32_t ld = shifted ? n_src - 16u : w;
+        // both loads are always issued (no branch): the one that is not needed reads a harmless address
+        const uint8_t* gsrc = (isB ? rd.seq : rd.qual) + R.so + ((fast && !isA) ? ld : 0u);
+        const u32x4 vg = *(global_u128_unaligned_ptr)(fast && !isA ? gsrc : rd.seq);
+        const u32x4 vl = *reinterpret_cast<const u32x4_unaligned*>(hdr + i * hpitch + ((fast && isA) ? w : 0u));
+        v[u] = isA ? vl : fq_shift_in(vg, t, fill);
+        dst[u] = fast ? out + R.rec + run_off + w : nullptr;
+        slow[u] = (on && !fast) ? (i | (isA ? 0x100u : isB ? 0x200u : 0x400u)) : 0u;
       }
-      k -= wA;
-      uint8_t* recB = rec + R.H;
-      uint8_t* recC = recB + R.L + 3u;
-      if (R.L >= 16u) {  // runs B and C: bases + "\n+\n", qualities + '\n'
-        const uint32_t npB = (R.L + 3u + 15u) >> 4, npC = (R.L + 1u + 15u) >> 4;
-        if (k < npB) fq_copy_window(recB, rd.seq + R.so, R.L, 3u, 0x0a2b0au, k, npB);
-        else fq_copy_window(recC, rd.qual + R.so, R.L, 1u, 0x0au, k - npB, npC);
-      } else if (k == 0) {
-        for (uint32_t j = 0; j < R.L; j++) recB[j] = rd.seq[R.so + j];
-        recB[R.L] = '\n'; recB[R.L + 1] = '+'; recB[R.L + 2] = '\n';
-      } else {
-        for (uint32_t j = 0; j < R.L; j++) recC[j] = rd.qual[R.so + j];
-        recC[R.L] = '\n';
+#pragma unroll
+      for (int u = 0; u < FQ_UNROLL; u++)
+        if (dst[u]) *reinterpret_cast<u32x4_unaligned*>(dst[u]) = v[u];
+#pragma unroll
+      for (int u = 0; u < FQ_UNROLL; u++) {
+        if (!slow[u]) continue;  // a run shorter than 16 bytes
+        const uint32_t i = slow[u] & 0xffu;
+        const FqRead R = recs[wave][i];
+        uint8_t* rec = out + R.rec;
+        if (slow[u] & 0x100u) {
+          for (uint32_t j = 0; j < R.H; j++) rec[j] = hdr[i * hpitch + j];
+        } else if (slow[u] & 0x200u) {
+          uint8_t* recB = rec + R.H;
+          for (uint32_t j = 0; j < R.L; j++) recB[j] = rd.seq[R.so + j];
+          recB[R.L] = '\n'; recB[R.L + 1] = '+'; recB[R.L + 2] = '\n';
+        } else {
+          uint8_t* recC = rec + R.H + R.L + 3u;
+          for (uint32_t j = 0; j < R.L; j++) recC[j] = rd.qual[R.so + j];
+          recC[R.L] = '\n';
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();  // the next batch overwrites the LDS slots
