@@ -1764,6 +1764,7 @@ SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t k0, uint32_t k1, uint32_t out
 
 #define PHILOX_UNITS 64u
 #define PHILOX_READS 128u  /* 64 pairs x 2 mates */
+#define PHILOX_MAP_ITEMS 2048u
 
 // bytes a + b with per-byte wrap-around (u8 add of util.rs:46-50)
 SIMMR_DEV uint32_t add_bytes(uint32_t a, uint32_t b) {
@@ -1818,6 +1819,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ const uint32_t* r_mask[PHILOX_READS];
   __shared__ uint32_t r_len[PHILOX_READS];     // L | rev << 31
   __shared__ uint32_t r_gs[PHILOX_READS + 1];  // first item of each read, ~0 past the last read
+  __shared__ uint8_t owner[PHILOX_MAP_ITEMS];   // item -> read, when the block has few enough items
   __shared__ uint32_t lds4[4];
   {
     const uint32_t t = threadIdx.x;
@@ -1888,12 +1890,20 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     uint32_t n_items;
     const uint32_t ex = wg_exclusive_scan_u32(g, lds4, &n_items);
     if (threadIdx.x <= PHILOX_READS) r_gs[threadIdx.x] = threadIdx.x < nr ? ex : 0xffffffffu;
+    // short reads: every read writes its index over its items, so an item finds its read with one LDS load
+    const bool use_map = n_items <= PHILOX_MAP_ITEMS;
+    if (use_map && threadIdx.x < nr)
+      for (uint32_t j = 0; j < g; j++) owner[ex + j] = (uint8_t)threadIdx.x;
     __syncthreads();
     for (uint32_t item = threadIdx.x; item < n_items; item += 256) {
       uint32_t r = 0;  // read of this item: last r with r_gs[r] <= item
+      if (use_map) {
+        r = owner[item];
+      } else {
 #pragma unroll
-      for (uint32_t step = PHILOX_READS / 2; step; step >>= 1)
-        if (r_gs[r + step] <= item) r += step;
+        for (uint32_t step = PHILOX_READS / 2; step; step >>= 1)
+          if (r_gs[r + step] <= item) r += step;
+      }
       const uint32_t Lr = r_len[r];
       const uint32_t L = Lr & 0x7fffffffu, rev = Lr >> 31;
       const uint32_t b0 = (item - r_gs[r]) << 4;
