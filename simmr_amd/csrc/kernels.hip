@@ -1820,6 +1820,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ uint32_t r_len[PHILOX_READS];     // L | rev << 31
   __shared__ uint32_t r_gs[PHILOX_READS + 1];  // first item of each read, ~0 past the last read
   __shared__ uint8_t owner[PHILOX_MAP_ITEMS];   // item -> read, when the block has few enough items
+  __shared__ uint4 nmask[17];    // byte masks of the first n bytes of 16
+  __shared__ uint32_t nmask2[17]; // the low 2n bits
   __shared__ uint32_t lds4[4];
   {
     const uint32_t t = threadIdx.x;
@@ -1829,6 +1831,11 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint32_t al = e >> 22;
       jtab[i] = make_uint4((e & 0x3fffffu) << 10, (((i + qual_offset) & 0xffu) << 8) | (i >> 8),
                            (((al + qual_offset) & 0xffu) << 8) | (al >> 8), 0u);
+    }
+    if (t <= 16u) {
+      auto bytes = [](int k) { return k >= 4 ? 0xffffffffu : (k <= 0 ? 0u : ((1u << (8 * k)) - 1u)); };
+      nmask[t] = make_uint4(bytes((int)t), bytes((int)t - 4), bytes((int)t - 8), bytes((int)t - 12));
+      nmask2[t] = t >= 16u ? 0xffffffffu : ((1u << (2u * t)) - 1u);
     }
     const uint32_t acgt = 0x54474341u;  // "ACGT"
     asc[t] = ((acgt >> (8 * (t & 3u))) & 0xffu) | (((acgt >> (8 * ((t >> 2) & 3u))) & 0xffu) << 8) |
@@ -1932,14 +1939,17 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         }
       }
       // only live ACGT bases mutate (minimal_short.rs:120-128)
-      const uint32_t live = n >= 16u ? 0xffffu : ((1u << n) - 1u);
+      // masks of the n live bases of the item: byte masks for the four quality words, 2-bit-field mask
+      const uint4 bm = nmask[n];
+      const uint32_t live2 = nmask2[n];
       if (HAS_EXC) ss &= ~spread16(exc);
-      if (n < 16u) ss &= (1u << (2u * n)) - 1u;
+      ss &= live2;
       n_subst += __builtin_popcount((ss | (ss >> 1)) & 0x55555555u);
-      n_acgt += __builtin_popcount(~exc & live);
-      uint32_t qs = 0;
-#pragma unroll
-      for (int d = 0; d < 4; d++) qs = __builtin_amdgcn_sad_u8(low_bytes(qr[d], (int)n - 4 * d), 0u, qs);
+      n_acgt += HAS_EXC ? __builtin_popcount(~spread16(exc) & live2 & 0x55555555u) : n;
+      uint32_t qs = __builtin_amdgcn_sad_u8(qr[0] & bm.x, 0u, 0u);
+      qs = __builtin_amdgcn_sad_u8(qr[1] & bm.y, 0u, qs);
+      qs = __builtin_amdgcn_sad_u8(qr[2] & bm.z, 0u, qs);
+      qs = __builtin_amdgcn_sad_u8(qr[3] & bm.w, 0u, qs);
       qsum += qs;
       n_live += n;
       if (!q_nowrap) {
