@@ -1762,9 +1762,9 @@ SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t k0, uint32_t k1, uint32_t out
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-#define PHILOX_UNITS 64u
-#define PHILOX_READS 128u  /* 64 pairs x 2 mates */
-#define PHILOX_MAP_ITEMS 2048u
+#define PHILOX_UNITS 128u
+#define PHILOX_READS 256u  /* 128 pairs x 2 mates */
+#define PHILOX_MAP_ITEMS 4096u
 
 // bytes a + b with per-byte wrap-around (u8 add of util.rs:46-50)
 SIMMR_DEV uint32_t add_bytes(uint32_t a, uint32_t b) {
