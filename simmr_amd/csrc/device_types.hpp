@@ -48,6 +48,7 @@ struct PdfDev {
   uint32_t pad;
   double w_scale;      // Uniform<f64>::new(0, weight_sum).scale
 };
+struct alignas(16) Rec16 { uint32_t x, y, z, w; };
 struct CustomDev {
   const PdfDev* pdfs;  // [0] read length, [1] insert size (n == 0 if absent), [2 + p] quality of position p
   const double* odds;
@@ -55,6 +56,8 @@ struct CustomDev {
   const uint32_t* bin_low;
   const uint32_t* bin_range;  // 0 = full u32 range
   const uint32_t* bin_zone;
+  const Rec16* col_rec;  // the same tables packed for one load per lookup: {odds lo, odds hi, alias, -}
+  const Rec16* bin_rec;  // {range, zone, low, -}
   uint32_t n_quality;
   uint32_t pad;
 };

@@ -89,7 +89,7 @@ struct simmr_engine {
   // long-read runs
   DevBuf d_runs, d_usable;
   // custom profile tables
-  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, ph_table;
+  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, c_colrec, c_binrec, ph_table;
   // FASTQ framing
   DevBuf fq_blob, fq_gid_off, fq_gid_len, fq_cbase, fq_ncontig, fq_coff, fq_clen, fq_len, fq_off;
   FqTemplate fq_tpl{};
@@ -268,6 +268,15 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
       (rc = upload_vec(e, e->c_alias, t.alias)) || (rc = upload_vec(e, e->c_low, t.bin_low)) ||
       (rc = upload_vec(e, e->c_range, t.bin_range)) || (rc = upload_vec(e, e->c_zone, t.bin_zone)))
     return rc;
+  // the emit kernel's copies: one 16-byte record per alias column / per bin
+  std::vector<Rec16> colrec(t.odds.size()), binrec(t.bin_low.size());
+  for (size_t i = 0; i < t.odds.size(); i++) {
+    uint64_t bits;
+    memcpy(&bits, &t.odds[i], 8);
+    colrec[i] = Rec16{(uint32_t)bits, (uint32_t)(bits >> 32), t.alias[i], 0u};
+  }
+  for (size_t i = 0; i < t.bin_low.size(); i++) binrec[i] = Rec16{t.bin_range[i], t.bin_zone[i], t.bin_low[i], 0u};
+  if ((rc = upload_vec(e, e->c_colrec, colrec)) || (rc = upload_vec(e, e->c_binrec, binrec))) return rc;
   if ((rc = sync_check(e, "custom table upload"))) return rc;  // the host vectors go out of scope
   ProfileDev d{};
   d.kind = SIMMR_K_CUSTOM;
@@ -281,6 +290,8 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
   d.custom.bin_low = e->c_low.as<uint32_t>();
   d.custom.bin_range = e->c_range.as<uint32_t>();
   d.custom.bin_zone = e->c_zone.as<uint32_t>();
+  d.custom.col_rec = e->c_colrec.as<Rec16>();
+  d.custom.bin_rec = e->c_binrec.as<Rec16>();
   d.custom.n_quality = (uint32_t)m.quality.size();
   *out = d;
   return SIMMR_OK;
@@ -631,7 +642,7 @@ void simmr_engine_destroy(simmr_engine* e) {
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_bytes, &e->u_qs2,
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
-                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->ph_table,
+                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->ph_table,
                     &e->fq_blob, &e->fq_gid_off, &e->fq_gid_len, &e->fq_cbase, &e->fq_ncontig, &e->fq_coff, &e->fq_clen,
                     &e->fq_len, &e->fq_off, &e->m_genomes, &e->m_contig, &e->m_seed};
   for (DevBuf* b : bufs) b->release();
@@ -1016,8 +1027,10 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
     } else if (e->prof.kind == SIMMR_K_CUSTOM) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
-      const uint32_t grid = (uint32_t)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 16);
-      hipLaunchKernelGGL(k_emit_custom_pe, dim3(grid), dim3(64), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
+      const uint64_t blocks = (n_reads + 255) / 256;
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
+      auto kern = e->plan_any_exc ? k_emit_custom_pe<true> : k_emit_custom_pe<false>;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
                          e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset, counters,
                          e->d_err.as<uint32_t>());

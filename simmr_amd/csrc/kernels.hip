@@ -328,6 +328,41 @@ SIMMR_DEV uint32_t pdf_sample_words(const uint32_t* __restrict__ W, uint32_t nw,
   }
 }
 
+// The same draws from the stream itself, for the sample that runs past the staged window (a dozen
+// consecutive rejections; kept for exactness, not for speed): blocks are generated on demand.
+__device__ __attribute__((noinline)) uint32_t pdf_sample_stream(uint64_t seed, const CustomDev& C, const PdfDev pdf,
+                                                                bool* bad) {
+  const Key key = pcg32_expand(seed);
+  uint32_t blk[16];
+  uint32_t cur = 0xffffffffu, k = 0;
+  auto word = [&](uint32_t i) {
+    if ((i >> 4) != cur) { cur = i >> 4; chacha12_block(key, cur, blk); }
+    return blk[i & 15u];
+  };
+  const uint32_t cap = 1u << 16;  // words; a stream that rejects this often is a broken model
+  uint32_t c = 0;
+  for (;;) {
+    if (k >= cap) { *bad = true; return 0; }
+    const uint64_t m = (uint64_t)word(k++) * pdf.n;
+    if ((uint32_t)m <= pdf.idx_zone) { c = (uint32_t)(m >> 32); break; }
+  }
+  const uint32_t lo = word(k), hi = word(k + 1);
+  k += 2;
+  const uint64_t bits = ((uint64_t)hi << 32) | lo;
+  const double v01 = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ULL)) - 1.0;
+  const double x = __dmul_rn(v01, pdf.w_scale);
+  const uint32_t bin = (x < C.odds[pdf.off + c]) ? c : C.alias[pdf.off + c];
+  if (bin >= pdf.n_bins) { *bad = true; return 0; }
+  const uint32_t range = C.bin_range[pdf.off_bins + bin], low = C.bin_low[pdf.off_bins + bin];
+  if (range == 0) return word(k);
+  const uint32_t zone = C.bin_zone[pdf.off_bins + bin];
+  for (;;) {
+    if (k >= cap) { *bad = true; return 0; }
+    const uint64_t m = (uint64_t)word(k++) * range;
+    if ((uint32_t)m <= zone) return low + (uint32_t)(m >> 32);
+  }
+}
+
 // ===========================================================================
 // 3. Per-unit planning (simulate.rs:211-258 for pairs, :478-491 for long reads)
 //    One lane per unit; each lane owns a LaneRng (one ChaCha block in LDS).
@@ -1226,80 +1261,6 @@ k_emit_stream(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 }
 
 // ===========================================================================
-// 7b. Emit: custom-short pairs (custom_short.rs:332-353, :522-529).
-// simulate_phred_scores re-seeds the SAME StdRng at every position, so a read's
-// qualities are functions of the first few words of one stream and of the
-// position's PDF: one wave per pair stages those words once in LDS, then every
-// lane samples its positions independently.  Bases are a plain copy (mate 2
-// reverse-complemented); simulate_errors is not on the paired-end path.
-// ===========================================================================
-#define CUSTOM_MAX_WORDS 1024u
-extern "C" __global__ void __launch_bounds__(64)
-k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
-                 PlanArrays pl, const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
-                 const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
-                 uint32_t qual_offset, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
-  __shared__ uint32_t W[2][CUSTOM_MAX_WORDS];
-  const uint32_t lane = threadIdx.x & 63u;
-  const GenomeDev G = genomes[genome];
-  const CustomDev C = prof.custom;
-  uint64_t qsum = 0;
-  uint32_t n_acgt = 0;
-  for (uint64_t k = blockIdx.x; k < n_units; k += gridDim.x) {
-    const uint32_t L = pl.len[k];
-    if (L == 0) continue;
-    const uint64_t cbase = G.contigs[u_contig[k]].base;
-    const uint64_t o1 = u_off[k], o2 = o1 + L;
-    const uint64_t seedA = u_seed[k], seedB = pl.qs2[k];
-    for (uint32_t nw = 64;; nw *= 4) {
-      __syncthreads();
-      const uint32_t nb = nw / 16;
-      for (uint32_t j = lane; j < 2 * nb; j += 64) {
-        const uint32_t st = j / nb, blk = j - st * nb;
-        const Key key = pcg32_expand(st ? seedB : seedA);
-        uint32_t o[16];
-        chacha12_block(key, blk, o);
-#pragma unroll
-        for (int i = 0; i < 16; i++) W[st][blk * 16 + i] = o[i];
-      }
-      __syncthreads();
-      bool ovf = false, bad = false;
-      for (uint32_t p = lane; p < L; p += 64) {
-        const PdfDev pdf = C.pdfs[2 + (p < C.n_quality ? p : C.n_quality - 1)];
-        const uint32_t q1 = pdf_sample_words(W[0], nw, C, pdf, &bad, &ovf) & 0xffu;  // `as u8`
-        const uint32_t q2 = pdf_sample_words(W[1], nw, C, pdf, &bad, &ovf) & 0xffu;
-        qual[o1 + p] = (uint8_t)(q1 + qual_offset);
-        qual[o2 + p] = (uint8_t)(q2 + qual_offset);
-      }
-      if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
-      if (!__any(ovf)) break;
-      if (nw * 4 > CUSTOM_MAX_WORDS) { if (lane == 0) atomicOr(err, SIMMR_ERRBIT_PDF); break; }
-    }
-    for (uint32_t p = lane; p < L; p += 64) {
-      qsum += (uint32_t)((qual[o1 + p] - qual_offset) & 0xffu) + (uint32_t)((qual[o2 + p] - qual_offset) & 0xffu);
-      const uint64_t p1 = cbase + pl.a[k] + p;           // forward mate, byte p
-      const uint64_t p2 = cbase + pl.b[k] + (L - 1 - p);  // mate 2, byte p <- slice base L-1-p (simulate.rs:283)
-      uint32_t c1 = (G.packed[p1 >> 4] >> ((p1 & 15u) * 2u)) & 3u, c2 = (G.packed[p2 >> 4] >> ((p2 & 15u) * 2u)) & 3u;
-      if (G.has_exc) {
-        c1 |= ((G.mask[p1 >> 5] >> (p1 & 31u)) & 1u) << 2;
-        c2 |= ((G.mask[p2 >> 5] >> (p2 & 31u)) & 1u) << 2;
-      }
-      n_acgt += (c1 < 4u ? 1u : 0u) + (c2 < 4u ? 1u : 0u);
-      seq[o1 + p] = (uint8_t)"ACGTN-N-"[c1];
-      seq[o2 + p] = (uint8_t)"TGCAN-N-"[c2];
-    }
-  }
-  for (int d = 32; d > 0; d >>= 1) {
-    n_acgt += __shfl_down(n_acgt, d, 64);
-    qsum += __shfl_down(qsum, d, 64);
-  }
-  if (lane == 0 && counters) {
-    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
-    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
-  }
-}
-
-// ===========================================================================
 // 8. Emit, lane-per-read form (the fast path for short reads)
 //
 // Every LANE owns one read (mate) and walks its own StdRng streams exactly as
@@ -2007,6 +1968,153 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     if (p_redrawn) atomicAdd(&counters[SIMMR_CNT_REDRAWN], (unsigned long long)p_redrawn);
     if (p_seedsubst) atomicAdd(&counters[SIMMR_CNT_SEED_SUBST], (unsigned long long)p_seedsubst);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[SIMMR_CNT_READS], (unsigned long long)n_reads);
+  }
+}
+
+// ===========================================================================
+// 9b. Emit: custom-short pairs (custom_short.rs:332-353, :522-529).
+//
+// simulate_phred_scores re-seeds the SAME StdRng at every position, so every
+// quality of a read is a function of the first few words of one stream (w0 picks
+// the alias column, (w1, w2) the f64 against the column's odds, w3 the score
+// inside the bin) and of the position's PDF.  One lane per read (mate): it
+// generates the first ChaCha12 block of its stream once and then walks its read
+// in groups of 16 positions.  All lanes of a wave are at the same group, i.e.
+// at the same 16 PDFs: the PDF headers are wave-uniform loads and the alias /
+// bin tables of one PDF are a few cache lines, instead of 64 different lines
+// per load (the item form dealt "16 positions of one read" to lanes like
+// k_emit_philox and was bound by exactly those scattered table loads: 26 ms
+// per 20 M reads).  Bases are copied in the code domain (mate 2 complement-
+// reversed) and both streams leave as 16-byte stores.  A sample whose words
+// are rejected (rare) goes through the general routine, and one that would run
+// past the 16 staged words is drawn again from the stream itself, so the
+// result is exact in every case.
+// ===========================================================================
+#define CUSTOM2_WORDS 16u
+
+template <bool HAS_EXC>
+__global__ void __launch_bounds__(256)
+k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
+                 PlanArrays pl, const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
+                 const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
+                 uint32_t qual_offset, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
+  __shared__ uint32_t asc[256];  // four 2-bit codes -> four ASCII bytes
+  __shared__ uint32_t words[256][CUSTOM2_WORDS + 1];  // per lane: first block of its stream (general routine only)
+  const GenomeDev G = genomes[genome];
+  const CustomDev C = prof.custom;
+  {
+    const uint32_t t = threadIdx.x;
+    const uint32_t acgt = 0x54474341u;  // "ACGT"
+    asc[t] = ((acgt >> (8 * (t & 3u))) & 0xffu) | (((acgt >> (8 * ((t >> 2) & 3u))) & 0xffu) << 8) |
+             (((acgt >> (8 * ((t >> 4) & 3u))) & 0xffu) << 16) | (((acgt >> (8 * (t >> 6))) & 0xffu) << 24);
+  }
+  __syncthreads();
+  uint64_t qsum = 0;
+  uint32_t n_acgt = 0;
+  bool bad = false;
+  const uint32_t qoff = qual_offset & 0xffu;
+  const uint64_t n_reads = 2 * n_units;
+  uint32_t* const row = words[threadIdx.x];
+  for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n_reads; r0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t r = r0 + threadIdx.x;
+    const bool live_read = r < n_reads;
+    uint32_t L = 0, rev = 0;
+    uint64_t off = 0, src0 = 0, key = 0;
+    if (live_read) {
+      const uint64_t u = r >> 1;
+      rev = (uint32_t)(r & 1u);
+      L = pl.len[u];
+      off = u_off[u] + (rev ? L : 0u);
+      src0 = G.contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]);
+      key = rev ? pl.qs2[u] : u_seed[u];  // simulate.rs:262,266: StdRng(pe_seed) / StdRng(drawn seed)
+    }
+    uint32_t o[16];
+    chacha12_block(pcg32_expand(key), 0, o);
+#pragma unroll
+    for (int i = 0; i < 16; i++) row[i] = o[i];
+    const uint32_t w0 = o[0], w3 = o[3];
+    const double v01 = __longlong_as_double((long long)(((((uint64_t)o[2] << 32) | o[1]) >> 12) | 0x3FF0000000000000ULL)) - 1.0;
+    for (uint32_t b0 = 0; __any(b0 < L); b0 += 16) {
+      if (b0 >= L) continue;
+      const uint32_t n = (L - b0) < 16u ? (L - b0) : 16u;
+      uint64_t q_lo = 0, q_hi = 0;
+#pragma unroll 4
+      for (uint32_t j = 0; j < 16; j++) {
+        // wave-uniform: position b0 + j samples PDF min(position, n_quality - 1) (custom_short.rs:339-350)
+        const uint32_t p = b0 + j;
+        const PdfDev pdf = C.pdfs[2 + (p < C.n_quality ? p : C.n_quality - 1)];
+        if (j >= n) continue;
+        const uint64_t m = (uint64_t)w0 * pdf.n;
+        uint32_t q = 0;
+        bool fast = (uint32_t)m <= pdf.idx_zone;
+        if (fast) {
+          const uint32_t col = (uint32_t)(m >> 32);
+          const Rec16 cr = C.col_rec[pdf.off + col];  // {odds, alias}
+          const double odds = __longlong_as_double((long long)(((uint64_t)cr.y << 32) | cr.x));
+          const uint32_t bin = (__dmul_rn(v01, pdf.w_scale) < odds) ? col : cr.z;
+          fast = bin < pdf.n_bins;
+          if (fast) {
+            const Rec16 br = C.bin_rec[pdf.off_bins + bin];  // {range, zone, low}
+            const uint64_t m2 = (uint64_t)w3 * br.x;
+            if (br.x == 0) q = w3;
+            else if ((uint32_t)m2 <= br.y) q = br.z + (uint32_t)(m2 >> 32);
+            else fast = false;
+          }
+        }
+        if (!fast) {  // a rejected word or a bin without a range: the general routine (and its error reporting)
+          bool ovf = false;
+          q = pdf_sample_words(row, CUSTOM2_WORDS, C, pdf, &bad, &ovf);
+          if (ovf) q = pdf_sample_stream(key, C, pdf, &bad);
+        }
+        q &= 0xffu;  // `as u8`
+        qsum += q;
+        const uint64_t enc = (q + qoff) & 0xffu;
+        if (j < 8u) q_lo |= enc << (8u * j); else q_hi |= enc << (8u * (j - 8u));
+      }
+      // bases: a plain copy (simulate_point_mutations is the identity, custom_short.rs:522-529), mate 2
+      // reverse-complemented (simulate.rs:283)
+      const uint64_t src = src0 + b0;
+      uint32_t codes = fetch_codes16(G.packed, (int64_t)src);
+      uint32_t exc = 0u;
+      if (HAS_EXC) exc = fetch_mask16(G.mask, (int64_t)src);
+      const uint32_t live = n >= 16u ? 0xffffu : ((1u << n) - 1u);
+      n_acgt += __builtin_popcount(~exc & live);
+      uint8_t* qd = qual + off + b0;
+      uint8_t* sd = seq + off + b0;
+      if (rev) {
+        codes = ~reverse_groups16(codes);
+        if (HAS_EXC) { exc = __builtin_bitreverse32(exc) >> 16; codes ^= spread16(exc); }
+        const uint32_t dead = 16u - n;
+        if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
+        sd = seq + off + (L - b0 - n);
+      }
+      uint32_t s0, s1, s2, s3;
+      if (HAS_EXC) {
+        s0 = expand4(codes & 0xffu, exc & 0xfu); s1 = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
+        s2 = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu); s3 = expand4(codes >> 24, (exc >> 12) & 0xfu);
+      } else {
+        s0 = asc[codes & 0xffu]; s1 = asc[(codes >> 8) & 0xffu]; s2 = asc[(codes >> 16) & 0xffu]; s3 = asc[codes >> 24];
+      }
+      const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
+      if (n == 16u) {
+        *reinterpret_cast<u64_unaligned*>(qd) = q_lo;
+        *reinterpret_cast<u64_unaligned*>(qd + 8) = q_hi;
+        *reinterpret_cast<u64_unaligned*>(sd) = s_lo;
+        *reinterpret_cast<u64_unaligned*>(sd + 8) = s_hi;
+      } else {
+        store_tail(qd, q_lo, q_hi, n);
+        store_tail(sd, s_lo, s_hi, n);
+      }
+    }
+  }
+  if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
+  for (int d = 32; d > 0; d >>= 1) {
+    n_acgt += __shfl_down(n_acgt, d, 64);
+    qsum += __shfl_down(qsum, d, 64);
+  }
+  if ((threadIdx.x & 63u) == 0 && counters) {
+    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
+    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
   }
 }
 

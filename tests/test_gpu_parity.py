@@ -364,6 +364,24 @@ def test_custom_short_bit_exact(engine, oracle, genome_multi, n_positions, seed)
     assert c[_abi.CNT_SUBSTITUTIONS] == 0 and c[_abi.CNT_BASES] == dev.total_bases
 
 
+def test_custom_short_rejection_heavy_model(engine, oracle, genome_multi):
+    """Bin ranges of about 2^31 + 1 scores make Uniform<u32>::new_inclusive reject every second word, so some
+    samples run past the 16 staged words of their stream and take the exact on-demand path."""
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    wide = [(0, 2 ** 31 + 5), (7, 2 ** 31 + 900), (40, 40)]
+    quality = [([0.45, 0.45, 0.10], wide)] * 90
+    blob = _model.serialize_model(quality, ([0.5, 0.5], [(70, 79), (80, 89)]), ([1.0], [(60, 160)]),
+                                  read_length_mean=80.0, insert_size_mean=110.0)
+    pod = CustomShortErrorProfile(blob).pod()
+    engine.counters_reset()
+    dev = engine.simulate_pe_reads_from_genome(1, pod, 6000, 3, qual_offset=33)
+    ora = _oracle.simulate_pe(oracle, genome_multi, pod, 6000, 3, qual_offset=33)
+    assert_same(dev.to_host(), ora.trimmed())
+    raw = (dev.to_host()["qual"].astype(np.int64) - 33) % 256
+    assert engine.counters()[_abi.CNT_QUAL_SUM] == raw.sum()
+
+
 def test_custom_short_rejects_bad_models(engine, genome_multi):
     from simmr_amd import CustomShortErrorProfile, SimmrError
     from tests import _model
