@@ -183,17 +183,26 @@ k_outer_scan(const uint32_t* __restrict__ wg_sums, uint64_t n_wg, uint64_t first
   __shared__ uint64_t s_base[256];
   __shared__ uint32_t s_state[256];
   const uint32_t t = threadIdx.x;
-  const uint64_t chunk = (n_wg + 255) / 256;
-  const uint64_t lo = (uint64_t)t * chunk, hi = (lo + chunk < n_wg) ? lo + chunk : n_wg;
+  // chunks are multiples of 4 entries so that they can be read 16 bytes at a time: the loop is a chain of
+  // dependent-latency loads, and four entries per load make it four times shorter
+  const uint64_t chunk = (((n_wg + 255) / 256) + 3) & ~(uint64_t)3;
+  const uint64_t lo = (uint64_t)t * chunk < n_wg ? (uint64_t)t * chunk : n_wg, hi = (lo + chunk < n_wg) ? lo + chunk : n_wg;
   // compose my chunk with 64-bit counts
   uint32_t e0 = 0, e1 = 1;
   uint64_t c0 = 0, c1 = 0;
-  for (uint64_t w = lo; w < hi; w++) {
-    uint32_t g = wg_sums[w];
+  auto compose = [&](uint32_t g) {
     uint32_t ge0 = g & 1u, ge1 = (g >> 1) & 1u;
     uint64_t gc0 = (g >> 2) & 0x7fffu, gc1 = g >> 17;
     c0 += e0 ? gc1 : gc0; e0 = e0 ? ge1 : ge0;
     c1 += e1 ? gc1 : gc0; e1 = e1 ? ge1 : ge0;
+  };
+  {
+    uint64_t w = lo;
+    for (; w + 4 <= hi; w += 4) {
+      const uint4 g4 = *reinterpret_cast<const uint4*>(wg_sums + w);
+      compose(g4.x); compose(g4.y); compose(g4.z); compose(g4.w);
+    }
+    for (; w < hi; w++) compose(wg_sums[w]);
   }
   s_e0[t] = e0; s_e1[t] = e1; s_c0[t] = c0; s_c1[t] = c1;
   __syncthreads();
@@ -220,10 +229,9 @@ k_outer_scan(const uint32_t* __restrict__ wg_sums, uint64_t n_wg, uint64_t first
   uint32_t st = s_state[t];
   uint64_t base = s_base[t];
   const uint64_t last = first + count;  // exclusive
-  for (uint64_t w = lo; w < hi; w++) {
+  auto emit = [&](uint64_t w, uint32_t g) {
     OuterPrefix p; p.base = base; p.state = st; p.pad = 0;
     wg_prefix[w] = p;
-    uint32_t g = wg_sums[w];
     uint64_t gc = st ? (uint64_t)(g >> 17) : (uint64_t)((g >> 2) & 0x7fffu);
     uint32_t ge = st ? ((g >> 1) & 1u) : (g & 1u);
     uint64_t nb = base + gc;
@@ -232,6 +240,14 @@ k_outer_scan(const uint32_t* __restrict__ wg_sums, uint64_t n_wg, uint64_t first
       if (base < last && last <= nb) res->wg_hi = w;
     }
     base = nb; st = ge;
+  };
+  {
+    uint64_t w = lo;
+    for (; w + 4 <= hi; w += 4) {
+      const uint4 g4 = *reinterpret_cast<const uint4*>(wg_sums + w);
+      emit(w, g4.x); emit(w + 1, g4.y); emit(w + 2, g4.z); emit(w + 3, g4.w);
+    }
+    for (; w < hi; w++) emit(w, wg_sums[w]);
   }
 }
 
