@@ -514,3 +514,24 @@ def test_pe_plan_multi_equals_per_genome_calls(engine, oracle, genome_multi, gen
             engine.pe_plan_multi(order, reads, prof, seed)
         assert ei.value.code == _abi.EGENOME
         engine.pe_plan_multi(order, reads, prof, seed, first=0, count=100)  # that genome is outside the shard
+
+
+def test_pe_plan_multi_edges(engine, genome_multi, genome_1m):
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()
+    # nothing to do: no reads at all, an empty shard, a shard past the end
+    for reads, first, count in (([0, 0], 0, _abi.U64_MAX), ([1, 1], 0, _abi.U64_MAX), ([100, 60], 20, 0), ([100, 60], 500, 10)):
+        info = engine.pe_plan_multi([0, 1], reads, prof, 5, first, count)
+        assert info.n_units == 0 and info.n_reads == 0 and info.total_bases == 0
+        out = engine.simulate_pe_reads_multi([0, 1], reads, prof, 5, first=first, count=count, qual_offset=33)
+        assert out.n_reads == 0 and int(out.seq_off[0].item()) == 0
+    # one genome through the multi plan == the single-genome plan (ids start at 0 in both)
+    a = engine.simulate_pe_reads_multi([1], [3001], prof, 8, qual_offset=33).to_host()
+    b = engine.simulate_pe_reads_from_genome(1, prof, 3001, 8, qual_offset=33).to_host()
+    for col in COLS:
+        assert np.array_equal(a[col], b[col]), col
+    assert (a["genome"] == 1).all()
+    from simmr_amd import CustomShortErrorProfile, SimmrError
+    from tests import _model
+    with pytest.raises(SimmrError) as ei:  # custom profiles are planned genome by genome
+        engine.pe_plan_multi([1], [100], CustomShortErrorProfile(_model.synthetic_short_model()).pod(), 1)
+    assert ei.value.code == _abi.ENOTSUP
