@@ -1789,7 +1789,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   // per outcome column i = q | s << 8: x = alias threshold << 10 (compared with W << 10),
   // y = result i, z = result alias(i), both as enc(q) << 8 | s with enc(q) = (q + qual_offset) as u8
   // (util.rs:46-50)
-  __shared__ uint4 jtab[1024];
+  __shared__ uint2 jtab[1024];
   __shared__ uint32_t asc[256];  // four 2-bit codes -> four ASCII bytes
   __shared__ uint64_t r_key[PHILOX_READS], r_dst[PHILOX_READS], r_src[PHILOX_READS];
   __shared__ const uint32_t* r_packed[PHILOX_READS];
@@ -1806,8 +1806,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     for (uint32_t i = t; i < 1024u; i += 256u) {
       const uint32_t e = prof.philox_phred[i];
       const uint32_t al = e >> 22;
-      jtab[i] = make_uint4((e & 0x3fffffu) << 10, (((i + qual_offset) & 0xffu) << 8) | (i >> 8),
-                           (((al + qual_offset) & 0xffu) << 8) | (al >> 8), 0u);
+      jtab[i] = make_uint2((e & 0x3fffffu) << 10, ((((i + qual_offset) & 0xffu) << 8) | (i >> 8)) |
+                                                      (((((al + qual_offset) & 0xffu) << 8) | (al >> 8)) << 16));
     }
     if (t <= 16u) {
       auto bytes = [](int k) { return k >= 4 ? 0xffffffffu : (k <= 0 ? 0u : ((1u << (8 * k)) - 1u)); };
@@ -1908,8 +1908,12 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         for (int h = 0; h < 4; h++) {
           const int j = 4 * c + h;  // base b0 + j; ascending, so base j ends at bits 2j of ss
           const uint32_t W = w[h];
-          const uint4 e = jtab[W >> 22];
-          const uint32_t x = ((W << 10) < e.x) ? e.y : e.z;  // enc(q) << 8 | s
+          const uint2 e = jtab[W >> 22];
+          // x = frac < thr ? low half : high half (enc(q) << 8 | s); the select reads the halves in place
+          uint32_t x;
+          asm("v_cmp_lt_u32_e32 vcc, %1, %2\n\t"
+              "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
+              : "=v"(x) : "v"(W << 10), "v"(e.x), "v"(e.y) : "vcc");
           ss = __builtin_amdgcn_alignbit(x, ss, 2);
           // byte (j & 3) of qr[j >> 2] = enc(q) = byte 1 of x
           qr[j >> 2] = __builtin_amdgcn_perm(x, qr[j >> 2], 0x03020100u ^ ((uint32_t)((j & 3) ^ 5) << (8 * (j & 3))));
