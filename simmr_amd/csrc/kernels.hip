@@ -1717,12 +1717,14 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
 // minimise the instruction count per base:
 //   * v_mad_u64_u32 gives both halves of a Philox product, v_bitop3_b32 the
 //     three-way xor of a round (4 instructions per round, 10 per word);
-//   * one 16-byte LDS entry per outcome column holds the alias threshold and,
-//     for either result, (enc(q) << 8 | s): one ds_read_b96, one compare, one
-//     select; v_alignbit_b32 shifts s into the packed substitution word and
+//   * one 8-byte LDS entry per outcome column holds the alias threshold and the
+//     two results (enc(q) << 8 | s) as 16-bit halves: one ds_read_b64, one
+//     compare, one select that reads the halves in place (SDWA);
+//     v_alignbit_b32 shifts s into the packed substitution word and
 //     v_perm_b32 drops the quality byte into place;
 //   * the substitutions are one SWAR add modulo 4 on the packed 2-bit codes;
-//   * a branch-free binary search over the item prefix finds the read.
+//   * blocks of short reads keep an item -> read map in LDS (one byte load);
+//     otherwise a branch-free binary search over the item prefix finds the read.
 // ===========================================================================
 SIMMR_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
