@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -71,17 +72,32 @@ static int write_fastq_device(simmr_engine* eng, const std::string& fmt, const s
   if (rc != SIMMR_OK) { *err = simmr_last_error(eng); return -1; }
   void* dev = nullptr;
   if (hipMalloc(&dev, total ? total : 1) != hipSuccess) { *err = "device allocation failed"; return -1; }
-  std::vector<char> host(total);
   rc = simmr_fastq_emit(eng, &reads, (uint8_t*)dev, total);
-  const bool ok = rc == SIMMR_OK && (total == 0 || hipMemcpy(host.data(), dev, total, hipMemcpyDeviceToHost) == hipSuccess);
-  (void)hipFree(dev);
-  if (!ok) { *err = rc != SIMMR_OK ? simmr_last_error(eng) : "copy back failed"; return -1; }
+  if (rc != SIMMR_OK) { *err = simmr_last_error(eng); (void)hipFree(dev); return -1; }
   FILE* f = fopen(output.c_str(), "ab");
-  if (!f) { *err = "cannot open " + output; return -1; }
-  const bool wrote = total == 0 || fwrite(host.data(), 1, total, f) == total;
+  if (!f) { *err = "cannot open " + output; (void)hipFree(dev); return -1; }
+  // drain through two pinned buffers: the copy of chunk i + 1 runs while chunk i is written to the file
+  const size_t chunk = 256u << 20;
+  void* pin[2] = {nullptr, nullptr};
+  hipStream_t cs = nullptr;
+  bool ok = hipHostMalloc(&pin[0], chunk, hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc(&pin[1], chunk, hipHostMallocDefault) == hipSuccess && hipStreamCreate(&cs) == hipSuccess &&
+            hipDeviceSynchronize() == hipSuccess;
+  const uint64_t n_chunks = (total + chunk - 1) / chunk;
+  auto len_of = [&](uint64_t i) { return (size_t)std::min<uint64_t>(chunk, total - i * chunk); };
+  if (ok && n_chunks > 0) ok = hipMemcpyAsync(pin[0], (const char*)dev, len_of(0), hipMemcpyDeviceToHost, cs) == hipSuccess;
+  for (uint64_t i = 0; ok && i < n_chunks; i++) {
+    ok = hipStreamSynchronize(cs) == hipSuccess;  // chunk i is in pin[i & 1]
+    if (ok && i + 1 < n_chunks)
+      ok = hipMemcpyAsync(pin[(i + 1) & 1], (const char*)dev + (i + 1) * chunk, len_of(i + 1), hipMemcpyDeviceToHost, cs) == hipSuccess;
+    if (ok && fwrite(pin[i & 1], 1, len_of(i), f) != len_of(i)) { *err = "short write to " + output; ok = false; }
+  }
+  if (!ok && err->empty()) *err = "copy back failed";
   fclose(f);
-  if (!wrote) { *err = "short write to " + output; return -1; }
-  return 0;
+  if (cs) (void)hipStreamDestroy(cs);
+  for (void* q : pin) if (q) (void)hipHostFree(q);
+  (void)hipFree(dev);
+  return ok ? 0 : -1;
 }
 
 static int run_main(int argc, char** argv) {
