@@ -79,6 +79,15 @@ enum simmr_rng_mode { SIMMR_RNG_REFERENCE = 0, SIMMR_RNG_PHILOX = 1 };
  *   Selected automatically when has_seed == 0. */
 enum simmr_length_mode { SIMMR_LEN_REFERENCE = 0, SIMMR_LEN_PER_READ = 1 };
 
+/* Where a long read starts on its sequence (Appendix A Q6 of SURVEY.md).
+ * REFERENCE: simulate.rs:484 draws read_start in [0, read_length) — not in
+ *   [0, size - read_length) — so every long read starts within the first
+ *   read_length bases of its sequence; reproduced exactly.
+ * UNIFORM: read_start = gen_range(0..size - read_length) from the same
+ *   StdRng(read_seed), read_end = read_start + read_length (no re-draw is needed):
+ *   what simulate_long_read evidently means to do.  An extension; off by default. */
+enum simmr_long_start_mode { SIMMR_START_REFERENCE = 0, SIMMR_START_UNIFORM = 1 };
+
 /* Flattened ErrorProfile (trait: error_profiles/base.rs:6-32; construction:
  * cli.rs:229-301).  Plain data, copied by the callee. */
 typedef struct simmr_error_profile {
@@ -88,7 +97,8 @@ typedef struct simmr_error_profile {
   uint16_t read_length; /* --read-length   (cli.rs:126)                      */
   uint16_t insert_size; /* --insert-size   (cli.rs:143)                      */
   uint8_t mean_phred;   /* --mean-phred-score (cli.rs:152)                   */
-  uint8_t reserved0[3];
+  uint8_t long_start_mode; /* enum simmr_long_start_mode (long reads only) */
+  uint8_t reserved0[2];
   double read_length_std; /* minimal-short: 15.0 (cli.rs:240)               */
   double insert_size_std; /* minimal-short: 75.0 (cli.rs:239)               */
   float gamma_shape;      /* (mean/std)^2, minimal_long.rs:68                */

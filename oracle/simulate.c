@@ -485,12 +485,14 @@ typedef struct long_unit {
 } long_unit;
 
 /* simulate.rs:478-491 */
-static int long_window(uint64_t size, uint32_t read_length, uint64_t read_seed, uint64_t* start,
+static int long_window(uint64_t size, uint32_t read_length, uint64_t read_seed, int uniform_start, uint64_t* start,
                        uint64_t* end) {
   if (size <= read_length) FAIL(SIMMR_EGENOME, "Genome size is smaller than the read length"); /* :471-476 */
   orc_rng r; orc_rng_seed_from_u64(&r, read_seed);
   uint64_t s, e;
-  if (orc_gen_range_u64(&r, 0, read_length, &s)) FAIL(SIMMR_ERANGE, "read_length == 0 (Rust panic)"); /* :484 */
+  /* :484 draws in [0, read_length); SIMMR_START_UNIFORM (an extension) in [0, size - read_length) */
+  if (orc_gen_range_u64(&r, 0, uniform_start ? size - read_length : (uint64_t)read_length, &s))
+    FAIL(SIMMR_ERANGE, "read_length == 0 (Rust panic)");
   e = s + read_length;                                                                    /* :485 */
   if (e >= size) orc_gen_range_u64(&r, s, size, &e);                                      /* :488-491 */
   *start = s; *end = e;
@@ -587,7 +589,8 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
 #pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1) if (threads > 1)
     for (int64_t k = 0; k < (int64_t)count; k++) {
       long_unit* u = &units[k];
-      int r2 = long_window(genomes[u->genome].size[u->contig], u->read_length, u->read_seed, &u->start, &u->end);
+      int r2 = long_window(genomes[u->genome].size[u->contig], u->read_length, u->read_seed,
+                           p->long_start_mode == SIMMR_START_UNIFORM, &u->start, &u->end);
       if (r2) {
 #pragma omp critical
         { if (!err) err = r2; }

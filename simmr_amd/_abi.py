@@ -22,6 +22,8 @@ PERFECT_SHORT, MINIMAL_SHORT, PERFECT_LONG, MINIMAL_LONG, CUSTOM = range(5)
 RNG_REFERENCE, RNG_PHILOX = 0, 1
 # enum simmr_length_mode
 LEN_REFERENCE, LEN_PER_READ = 0, 1
+# enum simmr_long_start_mode
+START_REFERENCE, START_UNIFORM = 0, 1
 
 FLAG_REVCOMP, FLAG_QSEED_SUBST, FLAG_MSEED_SUBST, FLAG_REDRAWN = 1, 2, 4, 8
 
@@ -41,7 +43,8 @@ class ErrorProfilePOD(C.Structure):
         ("read_length", C.c_uint16),
         ("insert_size", C.c_uint16),
         ("mean_phred", C.c_uint8),
-        ("reserved0", C.c_uint8 * 3),
+        ("long_start_mode", C.c_uint8),
+        ("reserved0", C.c_uint8 * 2),
         ("read_length_std", C.c_double),
         ("insert_size_std", C.c_double),
         ("gamma_shape", C.c_float),

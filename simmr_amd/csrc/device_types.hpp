@@ -74,6 +74,7 @@ struct ProfileDev {
   float gamma_shape, gamma_scale;
   double read_length_std, insert_size_std;
   CustomDev custom;
+  uint32_t long_start_uniform;   // SIMMR_START_UNIFORM
   const uint32_t* philox_phred;  // SIMMR_RNG_PHILOX: 1024 joint alias entries (thr22 | alias << 22)
   uint32_t philox_qmax;          // largest Phred the alias table can return
 };

@@ -318,6 +318,8 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
   d.insert_size = p->insert_size;
   d.mean_phred_f = (float)p->mean_phred;
   d.pl_mean = 1.0f - powf(10.0f, -((float)20 / 10.0f));  // convert_phred_to_accuracy(20)
+  if (p->long_start_mode > SIMMR_START_UNIFORM) return e->fail(SIMMR_EINVAL, "unknown long_start_mode %u", p->long_start_mode);
+  d.long_start_uniform = p->long_start_mode == SIMMR_START_UNIFORM ? 1u : 0u;
   d.gamma_shape = p->gamma_shape;
   d.gamma_scale = p->gamma_scale;
   d.read_length_std = p->read_length_std;
@@ -1184,7 +1186,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
     if (!per_read) {
       hipLaunchKernelGGL(k_plan_long_ref, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream,
                          e->d_genomes.as<GenomeDev>(), e->d_runs.as<LongGenomeRun>(), (uint32_t)runs.size(), first,
-                         count, L0, e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
+                         count, L0, prof.long_start_uniform, e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
                          e->u_seed.as<uint64_t>(), plan_arrays(e, false), e->d_err.as<uint32_t>());
     } else {
       hipLaunchKernelGGL(k_plan_long_per_read, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0,

@@ -479,7 +479,7 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
 // the length is the run-wide constant (simulate.rs:358 with Some(seed)).
 extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
 k_plan_long_ref(const GenomeDev* __restrict__ genomes, const LongGenomeRun* __restrict__ runs,
-                uint32_t n_runs, uint64_t first_unit, uint64_t n_units, uint32_t L0,
+                uint32_t n_runs, uint64_t first_unit, uint64_t n_units, uint32_t L0, uint32_t uniform_start,
                 uint32_t* __restrict__ u_contig, uint32_t* __restrict__ u_genome,
                 const uint64_t* __restrict__ u_seed, PlanArrays pl, uint32_t* __restrict__ err) {
   __shared__ uint32_t rows[PLAN_THREADS * 17];
@@ -494,9 +494,10 @@ k_plan_long_ref(const GenomeDev* __restrict__ genomes, const LongGenomeRun* __re
   const uint64_t size = G.contigs[contig].size;
   LaneRng rng;
   rng.seed_from_u64(u_seed[k], rows + threadIdx.x * 17);
-  uint64_t s = rng.gen_range_u64(0, L0);          // simulate.rs:484
+  // simulate.rs:484 draws the start in [0, L0); SIMMR_START_UNIFORM in [0, size - L0) (usable: size > L0)
+  uint64_t s = rng.gen_range_u64(0, uniform_start ? size - L0 : (uint64_t)L0);
   uint64_t e = s + L0;                            // :485
-  if (e >= size) e = rng.gen_range_u64(s, size);  // :488-491
+  if (e >= size) e = rng.gen_range_u64(s, size);  // :488-491 (never taken with a uniform start)
   if (e > G.contigs[contig].len) { atomicOr(err, SIMMR_ERRBIT_SLICE); e = s; }
   u_contig[k] = contig;
   u_genome[k] = run.genome;
@@ -546,7 +547,7 @@ k_plan_long_per_read(ProfileDev prof, const GenomeDev* __restrict__ genomes,
   if (L) {
     const uint64_t size = G.contigs[contig].size;
     rng.seed_from_u64(read_seed, rows + threadIdx.x * 17);
-    s = rng.gen_range_u64(0, L);
+    s = rng.gen_range_u64(0, prof.long_start_uniform ? size - L : (uint64_t)L);
     e = s + L;
     if (e >= size) e = rng.gen_range_u64(s, size);
     if (e > G.contigs[contig].len) { atomicOr(err, SIMMR_ERRBIT_SLICE); e = s; }

@@ -284,6 +284,7 @@ simmr_error_profile MinimalShortErrorProfile::pod() const {
 simmr_error_profile MinimalLongErrorProfile::pod() const {
   simmr_error_profile p = zero_pod();
   p.kind = SIMMR_MINIMAL_LONG; p.mean_phred = mean_phred_score; p.length_mode = length_mode;
+  p.long_start_mode = long_start_mode;
   // minimal_long.rs:64-69: shape = (mean / std_dev).powf(2.0); scale = std_dev.powf(2.0) / mean (f32)
   p.gamma_shape = powf(gamma_mean / gamma_std, 2.0f);
   p.gamma_scale = powf(gamma_std, 2.0f) / gamma_mean;
@@ -371,7 +372,7 @@ std::string usage() {
          "  --seed <N>                    Random seed\n"
          "  --size-adjusted               Adjust by genome size\n"
          "  --contiguous                  Treat separate sequences in a genome as one contiguous sequence\n"
-         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths  --host-fastq\n";
+         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths  --uniform-start  --host-fastq\n";
 }
 
 static bool parse_u64(const std::string& s, uint64_t max, uint64_t* out) {
@@ -437,6 +438,7 @@ bool parse_cli_args(int argc, const char* const* argv, CliArgs* a, std::string* 
       a->gamma = std::make_pair(m, s);
     }
     else if (arg == "--per-read-lengths") a->per_read_lengths = true;
+    else if (arg == "--uniform-start") a->uniform_start = true;
     else { *err = "Found argument '" + arg + "' which wasn't expected"; return false; }
   }
   // cli.rs:88-92: ArgGroup "genomes" is required, and --output has no default
@@ -463,6 +465,7 @@ std::unique_ptr<ErrorProfile> determine_error_profile(const CliArgs& args, std::
       auto p = std::make_unique<PerfectLongErrorProfile>();
       if (args.gamma) { p->gamma_mean = args.gamma->first; p->gamma_std = args.gamma->second; }
       if (args.per_read_lengths) p->length_mode = SIMMR_LEN_PER_READ;
+      if (args.uniform_start) p->long_start_mode = SIMMR_START_UNIFORM;
       return p;
     }
     case ErrorProfileKind::MinimalLong: {  // cli.rs:284-297
@@ -472,6 +475,7 @@ std::unique_ptr<ErrorProfile> determine_error_profile(const CliArgs& args, std::
       p->read_length_std = args.read_length < 400 ? args.read_length_std : 5000.0;
       if (args.gamma) { p->gamma_mean = args.gamma->first; p->gamma_std = args.gamma->second; }
       if (args.per_read_lengths) p->length_mode = SIMMR_LEN_PER_READ;
+      if (args.uniform_start) p->long_start_mode = SIMMR_START_UNIFORM;
       return p;
     }
     case ErrorProfileKind::CustomShort: {  // cli.rs:255-272

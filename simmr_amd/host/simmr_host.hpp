@@ -108,6 +108,7 @@ struct MinimalLongErrorProfile : ErrorProfile {  // minimal_long.rs
   double read_length_std = 5000.0;
   float gamma_mean = 20000.0f, gamma_std = 15000.0f;
   uint32_t length_mode = SIMMR_LEN_REFERENCE;
+  uint8_t long_start_mode = SIMMR_START_REFERENCE;
   simmr_error_profile pod() const override;
   uint16_t minimum_genome_size() const override { return 20000; }
   bool is_long_read() const override { return true; }
@@ -179,6 +180,7 @@ struct CliArgs {  // cli.rs:93-220, same flags and defaults
   int device = 0;
   bool host_fastq = false;  // --host-fastq: frame the FASTQ on the host instead of the device
   std::optional<std::pair<float, float>> gamma;  // --gamma mean,std
+  bool uniform_start = false;                    // --uniform-start (SIMMR_START_UNIFORM)
   bool per_read_lengths = false;                 // --per-read-lengths (SIMMR_LEN_PER_READ)
 };
 // returns false and fills err on a usage error (clap would exit(2)); help=true for --help

@@ -106,6 +106,7 @@ class MinimalLongErrorProfile(ErrorProfile):
     gamma_std: float = 15000.0
     length_mode: int = _abi.LEN_REFERENCE
     rng_mode: int = _abi.RNG_REFERENCE
+    uniform_start: bool = False  # SIMMR_START_UNIFORM: starts over the whole sequence (extension)
     kind = _abi.MINIMAL_LONG
 
     def pod(self):
@@ -113,6 +114,7 @@ class MinimalLongErrorProfile(ErrorProfile):
         p.kind = self.kind
         p.rng_mode = self.rng_mode
         p.length_mode = self.length_mode
+        p.long_start_mode = _abi.START_UNIFORM if self.uniform_start else _abi.START_REFERENCE
         p.mean_phred = self.mean_phred_score
         p.gamma_shape, p.gamma_scale = gamma_params(self.gamma_mean, self.gamma_std)
         return p

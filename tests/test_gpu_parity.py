@@ -535,3 +535,22 @@ def test_pe_plan_multi_edges(engine, genome_multi, genome_1m):
     with pytest.raises(SimmrError) as ei:  # custom profiles are planned genome by genome
         engine.pe_plan_multi([1], [100], CustomShortErrorProfile(_model.synthetic_short_model()).pod(), 1)
     assert ei.value.code == _abi.ENOTSUP
+
+
+def test_long_reads_uniform_start(engine, oracle, genome_multi, genome_1m):
+    """SIMMR_START_UNIFORM: the start is drawn over the whole sequence instead of the
+    reference's [0, read_length); same streams otherwise, bit-exact against the oracle in both length modes."""
+    for kw in ({}, {"length_mode": _abi.LEN_PER_READ, "gamma_mean": 9000.0, "gamma_std": 5000.0}):
+        for rng_mode in (_abi.RNG_REFERENCE, _abi.RNG_PHILOX):
+            prof = MinimalLongErrorProfile(uniform_start=True, rng_mode=rng_mode, **kw).pod()
+            dev = engine.simulate_long_reads([1, 0], [60, 40], prof, 11).to_host()
+            ora = _oracle.simulate_long(oracle, [genome_multi, genome_1m], [60, 40], prof, 11).trimmed()
+            assert_same(dev, ora)
+            lens = (dev["end"] - dev["start"]).astype(np.int64)
+            assert (dev["start"] > lens).any()  # impossible with the reference's start < read_length
+            sizes = np.array([c.size for c in genome_multi.contigs])
+            g1 = dev["genome"] == 1
+            assert (dev["end"][g1] <= sizes[dev["contig"][g1]]).all()
+    # the reference's quirk for comparison: with the constant 20 000-base length every start is below it
+    ref = engine.simulate_long_reads([1, 0], [60, 40], MinimalLongErrorProfile().pod(), 11).to_host()
+    assert (ref["start"] < 65536).all()
