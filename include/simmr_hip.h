@@ -192,6 +192,21 @@ int simmr_engine_set_stream(simmr_engine* e, void* hip_stream);
 int simmr_stage_genome(simmr_engine* e, uint32_t genome_idx, uint32_t n_contigs,
                        const uint8_t* const* contig_ascii, const uint64_t* contig_len,
                        const uint64_t* contig_size);
+/* Genome::from_fasta's sequence handling on the device (genome.rs:93-137): the
+ * host splits the file into records (header lines, body ranges); the device
+ * applies needletail's normalize(false) (genome.rs:114: whitespace and line ends
+ * dropped, acgt -> ACGT, u/U -> T, . ~ -> -, A C G T N - kept, everything else ->
+ * N) and packs in the same pass, so no normalised copy is ever built on the host.
+ * body[c] / body_len[c]: the raw bytes between record c's header line and the
+ * next header (HOST memory).  base_count[c] receives the record's number of bases.
+ * contiguous == 0: records with more than min_size bases become the genome's
+ *   sequences, in order (the size filter of main.rs:117-162; pass 0 to keep all);
+ *   *n_staged = how many.  With none left the slot is left unstaged.
+ * contiguous != 0: one sequence, every record followed by an 'N' (genome.rs:
+ *   121-137); its Seq.size counts the bases without the separators. */
+int simmr_stage_fasta(simmr_engine* e, uint32_t genome_idx, uint32_t n_records,
+                      const uint8_t* const* body, const uint64_t* body_len, int contiguous,
+                      uint64_t min_size, uint64_t* base_count, uint32_t* n_staged);
 /* Synthetic genome generated on the device: word k of the packed array (32
  * bases) is SplitMix64 output k of `splitmix_seed` (BASELINE.md / SURVEY §8d). */
 int simmr_stage_synthetic(simmr_engine* e, uint32_t genome_idx, uint32_t n_contigs,

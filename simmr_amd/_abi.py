@@ -118,6 +118,8 @@ SYMBOLS = {
     "simmr_engine_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "simmr_stage_genome": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_void_p),
                                      _P(C.c_uint64), _P(C.c_uint64)]),
+    "simmr_stage_fasta": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_void_p), _P(C.c_uint64), C.c_int,
+                                    C.c_uint64, _P(C.c_uint64), _P(C.c_uint32)]),
     "simmr_stage_synthetic": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_uint64),
                                         C.c_uint64]),
     "simmr_unstage_contig": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64,

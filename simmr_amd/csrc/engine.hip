@@ -702,6 +702,87 @@ int simmr_stage_genome(simmr_engine* e, uint32_t genome_idx, uint32_t n_contigs,
   return refresh_genome_table(e);
 }
 
+int simmr_stage_fasta(simmr_engine* e, uint32_t genome_idx, uint32_t n_records, const uint8_t* const* body,
+                      const uint64_t* body_len, int contiguous, uint64_t min_size, uint64_t* base_count,
+                      uint32_t* n_staged) {
+  if (!e) return SIMMR_EINVAL;
+  if (!body || !body_len || !base_count || n_records == 0) return e->fail(SIMMR_EINVAL, "empty FASTA");
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (genome_idx >= e->genomes.size()) e->genomes.resize(genome_idx + 1);
+  GenomeHost& g = e->genomes[genome_idx];
+  g.staged = false;
+  if (n_staged) *n_staged = 0;
+  // raw bodies on the device, every record at a multiple of FASTA_TILE, the gaps filled with '\n'
+  std::vector<uint64_t> tile0(n_records + 1, 0);
+  for (uint32_t c = 0; c < n_records; c++) tile0[c + 1] = tile0[c] + (body_len[c] + FASTA_TILE - 1) / FASTA_TILE;
+  const uint64_t n_tiles = tile0[n_records];
+  DevBuf raw, kept, prefix, d_tile0, d_gather, d_recs, d_sep;
+  auto release = [&]() { raw.release(); kept.release(); prefix.release(); d_tile0.release(); d_gather.release(); d_recs.release(); d_sep.release(); };
+  int rc = SIMMR_OK;
+  if (!raw.ensure(std::max<uint64_t>(n_tiles, 1) * FASTA_TILE) || !kept.ensure(std::max<uint64_t>(n_tiles, 1) * 8) ||
+      !d_tile0.ensure((n_records + 1) * 8) || !d_gather.ensure((n_records + 1) * 8) ||
+      !d_recs.ensure(n_records * sizeof(FastaRecord)) || !d_sep.ensure(n_records * 8)) {
+    release();
+    return e->fail(SIMMR_ENOMEM, "FASTA staging allocation failed (%llu bytes)", (unsigned long long)(n_tiles * FASTA_TILE));
+  }
+#define FASTA_TRY(call) do { hipError_t _s = (call); if (_s != hipSuccess) { release(); return e->fail(SIMMR_ENODEV, "%s failed: %s", #call, hipGetErrorString(_s)); } } while (0)
+  FASTA_TRY(hipMemsetAsync(raw.p, '\n', std::max<uint64_t>(n_tiles, 1) * FASTA_TILE, e->stream));
+  for (uint32_t c = 0; c < n_records; c++)
+    if (body_len[c])
+      FASTA_TRY(hipMemcpyAsync(raw.as<uint8_t>() + tile0[c] * FASTA_TILE, body[c], body_len[c], hipMemcpyHostToDevice, e->stream));
+  FASTA_TRY(hipMemcpyAsync(d_tile0.p, tile0.data(), (n_records + 1) * 8, hipMemcpyHostToDevice, e->stream));
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_tiles, 1), (uint64_t)e->n_cu * 16);
+  if (n_tiles) hipLaunchKernelGGL(k_fasta_count, dim3(grid), dim3(256), 0, e->stream, raw.as<uint8_t>(), n_tiles, kept.as<uint64_t>());
+  uint64_t total = 0;
+  if ((rc = scan_u64(e, kept, n_tiles, prefix, &total))) { release(); return rc; }  // prefix has n_tiles + 1 entries
+  std::vector<uint64_t> pre(n_records + 1, 0);
+  hipLaunchKernelGGL(k_fasta_gather, dim3(grid_for(n_records + 1, 256)), dim3(256), 0, e->stream, prefix.as<uint64_t>(),
+                     d_tile0.as<uint64_t>(), n_records + 1, d_gather.as<uint64_t>());
+  FASTA_TRY(hipMemcpyAsync(pre.data(), d_gather.p, (n_records + 1) * 8, hipMemcpyDeviceToHost, e->stream));
+  if ((rc = sync_check(e, "FASTA base counts"))) { release(); return rc; }
+  for (uint32_t c = 0; c < n_records; c++) base_count[c] = pre[c + 1] - pre[c];
+  // layout: the staged sequences and where every record's bases go
+  std::vector<FastaRecord> recs(n_records);
+  std::vector<uint64_t> lens, sizes, seps;
+  if (contiguous) {  // genome.rs:121-137
+    uint64_t at = 0;
+    for (uint32_t c = 0; c < n_records; c++) { recs[c] = FastaRecord{tile0[c], at}; at += base_count[c]; seps.push_back(at); at += 1; }
+    lens.push_back(at);
+    sizes.push_back(total);
+  } else {
+    for (uint32_t c = 0; c < n_records; c++)
+      if (base_count[c] > min_size) { lens.push_back(base_count[c]); sizes.push_back(base_count[c]); }
+  }
+  if (lens.empty()) { release(); return SIMMR_OK; }
+  if ((rc = layout_genome(e, g, (uint32_t)lens.size(), lens.data(), sizes.data()))) { release(); return rc; }
+  if (!contiguous) {
+    uint32_t k = 0;
+    for (uint32_t c = 0; c < n_records; c++) recs[c] = FastaRecord{tile0[c], base_count[c] > min_size ? g.contigs[k++].base : ~0ull};
+  }
+  FASTA_TRY(hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
+  uint32_t* d_any = e->d_err.as<uint32_t>() + 1;
+  FASTA_TRY(hipMemcpyAsync(d_recs.p, recs.data(), n_records * sizeof(FastaRecord), hipMemcpyHostToDevice, e->stream));
+  if (n_tiles)
+    hipLaunchKernelGGL(k_fasta_pack, dim3(grid), dim3(256), 0, e->stream, raw.as<uint8_t>(), n_tiles, prefix.as<uint64_t>(),
+                       d_recs.as<FastaRecord>(), n_records, g.packed.as<uint32_t>() + FRONT_PAD_WORDS,
+                       g.mask.as<uint32_t>() + FRONT_PAD_WORDS, d_any);
+  if (!seps.empty()) {
+    FASTA_TRY(hipMemcpyAsync(d_sep.p, seps.data(), seps.size() * 8, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_fasta_separators, dim3(grid_for(seps.size(), 256)), dim3(256), 0, e->stream, d_sep.as<uint64_t>(),
+                       (uint32_t)seps.size(), g.mask.as<uint32_t>() + FRONT_PAD_WORDS, d_any);
+  }
+  uint32_t any = 0;
+  FASTA_TRY(hipMemcpyAsync(&any, d_any, 4, hipMemcpyDeviceToHost, e->stream));
+#undef FASTA_TRY
+  rc = sync_check(e, "FASTA staging");  // the host vectors and the raw copy may go now
+  release();
+  if (rc) return rc;
+  g.has_exc = any != 0;
+  g.staged = true;
+  if (n_staged) *n_staged = (uint32_t)lens.size();
+  return refresh_genome_table(e);
+}
+
 int simmr_stage_synthetic(simmr_engine* e, uint32_t genome_idx, uint32_t n_contigs,
                           const uint64_t* contig_len, uint64_t splitmix_seed) {
   if (!e) return SIMMR_EINVAL;

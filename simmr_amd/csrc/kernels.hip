@@ -55,6 +55,134 @@ k_pack_ascii(const uint8_t* __restrict__ ascii, uint64_t n, uint64_t dst_base,
   if (m) atomicOr(any_exc, 1u);
 }
 
+// exclusive scan of one u32 per thread over a 256-thread workgroup
+SIMMR_DEV uint32_t wg_exclusive_scan_u32(uint32_t v, uint32_t* lds4, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc += o;
+  }
+  if (lane == 63) lds4[wave] = inc;
+  __syncthreads();
+  const uint32_t t0 = lds4[0], t1 = lds4[1], t2 = lds4[2], t3 = lds4[3];
+  const uint32_t pre = (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
+  *total = t0 + t1 + t2 + t3;
+  return pre + inc - v;
+}
+
+// ---------------------------------------------------------------------------
+// FASTA bodies -> planes on the device (simmr_stage_fasta): needletail 0.4.1
+// sequence::normalize(seq, iupac = false) as genome.rs:114 applies it, fused with
+// the packing.  Raw record bodies sit in `raw` at offsets that are multiples of
+// FASTA_TILE, padded with '\n'; a workgroup owns one tile of FASTA_TILE raw bytes.
+//   class of a raw byte: 0..3 = A C G T (also a c g t, and u / U -> T), 4 = N
+//   (N itself and every byte that is none of the others), 5 = '-' (also . ~),
+//   0xff = dropped (space, tab, CR, LF).
+// ---------------------------------------------------------------------------
+#define FASTA_TILE 1024u
+
+SIMMR_DEV uint32_t fasta_class(uint32_t c) {
+  switch (c) {
+    case 'A': case 'a': return 0u;
+    case 'C': case 'c': return 1u;
+    case 'G': case 'g': return 2u;
+    case 'T': case 't': case 'U': case 'u': return 3u;
+    case '-': case '.': case '~': return 5u;
+    case ' ': case '\t': case '\r': case '\n': return 0xffu;
+    default: return 4u;
+  }
+}
+
+// bases kept per tile
+extern "C" __global__ void __launch_bounds__(256)
+k_fasta_count(const uint8_t* __restrict__ raw, uint64_t n_tiles, uint64_t* __restrict__ kept) {
+  __shared__ uint32_t lds4[4];
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint32_t w = reinterpret_cast<const uint32_t*>(raw + t * FASTA_TILE)[threadIdx.x];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) c += fasta_class((w >> (8 * i)) & 0xffu) != 0xffu ? 1u : 0u;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) lds4[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) kept[t] = (uint64_t)lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  }
+}
+
+struct FastaRecord {
+  uint64_t tile0;  // first tile of the record
+  uint64_t dst;    // plane position (bases) of the record's first base; ~0 = record not staged
+};
+
+// prefix[t] = bases kept in tiles before t (all records); the tile's bases go to
+// rec.dst + (prefix[t] - prefix[rec.tile0]) ...
+extern "C" __global__ void __launch_bounds__(256)
+k_fasta_pack(const uint8_t* __restrict__ raw, uint64_t n_tiles, const uint64_t* __restrict__ prefix,
+             const FastaRecord* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ packed,
+             uint32_t* __restrict__ mask, uint32_t* __restrict__ any_exc) {
+  __shared__ uint8_t codes[FASTA_TILE + 64];
+  __shared__ uint32_t lds4[4];
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    uint32_t lo = 0, hi = n_recs;  // record of this tile: last one with tile0 <= t
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (recs[mid].tile0 <= t) lo = mid; else hi = mid; }
+    const FastaRecord rec = recs[lo];
+    if (rec.dst == ~0ull) continue;  // below the minimum size: not staged (main.rs:117-162)
+    const uint64_t dst0 = rec.dst + (prefix[t] - prefix[rec.tile0]);
+    const uint32_t w = reinterpret_cast<const uint32_t*>(raw + t * FASTA_TILE)[threadIdx.x];
+    uint32_t cls[4], c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { cls[i] = fasta_class((w >> (8 * i)) & 0xffu); c += cls[i] != 0xffu ? 1u : 0u; }
+    __syncthreads();  // the previous tile's words have been built
+    uint32_t n_kept;
+    uint32_t at = wg_exclusive_scan_u32(c, lds4, &n_kept);
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (cls[i] != 0xffu) codes[at++] = (uint8_t)cls[i];
+    __syncthreads();
+    if (n_kept == 0) continue;
+    // plane words touched by bases [dst0, dst0 + n_kept): the first and the last may be shared with a neighbour
+    const uint64_t cw0 = dst0 >> 4, cw1 = (dst0 + n_kept - 1) >> 4;
+    for (uint64_t wd = cw0 + threadIdx.x; wd <= cw1; wd += 256) {
+      uint32_t v = 0;
+      for (uint32_t i = 0; i < 16; i++) {
+        const uint64_t b = wd * 16 + i;
+        if (b >= dst0 && b < dst0 + n_kept) {
+          const uint32_t cl = codes[b - dst0];
+          v |= (cl < 4u ? cl : cl - 4u) << (2 * i);  // exception bases keep 0 ('N') / 1 ('-') in the code plane
+        }
+      }
+      if (wd == cw0 || wd == cw1) atomicOr(&packed[wd], v); else packed[wd] = v;
+    }
+    const uint64_t mw0 = dst0 >> 5, mw1 = (dst0 + n_kept - 1) >> 5;
+    for (uint64_t wd = mw0 + threadIdx.x; wd <= mw1; wd += 256) {
+      uint32_t v = 0;
+      for (uint32_t i = 0; i < 32; i++) {
+        const uint64_t b = wd * 32 + i;
+        if (b >= dst0 && b < dst0 + n_kept) v |= (codes[b - dst0] >= 4u ? 1u : 0u) << i;
+      }
+      if (v) { atomicOr(&mask[wd], v); atomicOr(any_exc, 1u); }
+    }
+  }
+}
+
+// genome.rs:121-137 (--contiguous): an 'N' after every record
+extern "C" __global__ void __launch_bounds__(256)
+k_fasta_separators(const uint64_t* __restrict__ pos, uint32_t n, uint32_t* __restrict__ mask, uint32_t* __restrict__ any_exc) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  atomicOr(&mask[pos[i] >> 5], 1u << (pos[i] & 31u));  // code plane stays 0 = 'N'
+  atomicOr(any_exc, 1u);
+}
+
+// prefix values at the records' first tiles (and the grand total) for the host
+extern "C" __global__ void __launch_bounds__(256)
+k_fasta_gather(const uint64_t* __restrict__ prefix, const uint64_t* __restrict__ tile0, uint32_t n, uint64_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = prefix[tile0[i]];
+}
+
 // Synthetic reference: u64 word k of the packed plane = SplitMix64 output k.
 extern "C" __global__ void __launch_bounds__(256)
 k_synth(uint64_t* __restrict__ packed64, uint64_t n_words64, uint64_t seed) {
@@ -1762,23 +1890,6 @@ SIMMR_DEV void store_tail(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi, uin
   if (n & 4u) { *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(d + p) = (uint32_t)v; v >>= 32; p += 4; }
   if (n & 2u) { *reinterpret_cast<uint16_t __attribute__((aligned(1)))*>(d + p) = (uint16_t)v; v >>= 16; p += 2; }
   if (n & 1u) d[p] = (uint8_t)v;
-}
-
-// exclusive scan of one u32 per thread over a 256-thread workgroup
-SIMMR_DEV uint32_t wg_exclusive_scan_u32(uint32_t v, uint32_t* lds4, uint32_t* total) {
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(inc, d, 64);
-    if (lane >= (uint32_t)d) inc += o;
-  }
-  if (lane == 63) lds4[wave] = inc;
-  __syncthreads();
-  const uint32_t t0 = lds4[0], t1 = lds4[1], t2 = lds4[2], t3 = lds4[3];
-  const uint32_t pre = (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
-  *total = t0 + t1 + t2 + t3;
-  return pre + inc - v;
 }
 
 template <bool HAS_EXC>

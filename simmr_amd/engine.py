@@ -138,6 +138,20 @@ class Engine:
         szs = (C.c_uint64 * n)(*[int(s) for s in sizes]) if sizes is not None else None
         self._check(self.lib.simmr_stage_genome(self._h, genome_idx, n, ptrs, lens, szs))
 
+    def stage_fasta(self, genome_idx: int, bodies: Sequence[bytes], contiguous: bool = False, min_size: int = 0):
+        """Raw FASTA record bodies (the bytes between a header line and the next header) -> staged genome;
+        normalisation (needletail normalize(false), genome.rs:114) and packing happen on the device.
+        Returns (bases per record, number of sequences staged)."""
+        arrs = [np.frombuffer(bytes(b), dtype=np.uint8) for b in bodies]
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = (C.c_uint64 * n)(*[a.size for a in arrs])
+        counts = (C.c_uint64 * n)()
+        staged = C.c_uint32(0)
+        self._check(self.lib.simmr_stage_fasta(self._h, genome_idx, n, ptrs, lens, 1 if contiguous else 0, int(min_size),
+                                               counts, C.byref(staged)))
+        return [int(x) for x in counts], int(staged.value)
+
     def stage_synthetic(self, genome_idx: int, contig_lens: Sequence[int], splitmix_seed: int):
         n = len(contig_lens)
         lens = (C.c_uint64 * n)(*[int(x) for x in contig_lens])

@@ -50,19 +50,19 @@ std::string uuid_from_u64(uint64_t u) {
   return buf;
 }
 
-bool Genome::from_fasta(const std::string& filepath, bool contiguous, Genome* out, std::string* err) {
+bool scan_fasta(const std::string& filepath, FastaRecords* out, std::string* err) {
   std::ifstream f(filepath, std::ios::binary);
   if (!f) { *err = "No such file or directory (os error 2)"; return false; }
   std::stringstream ss;
   ss << f.rdbuf();
-  const std::string data = ss.str();
+  out->data = ss.str();
+  const std::string& data = out->data;
   if (data.empty()) { *err = "Failed to read the first two bytes. Is the file empty?"; return false; }
   if (data.size() >= 2 && (unsigned char)data[0] == 0x1f && (unsigned char)data[1] == 0x8b) {
     *err = "compressed FASTA is not supported by this host layer";
     return false;
   }
   if (data[0] != '>') { *err = "Bad starting byte found, expected '>' (FASTA records only)"; return false; }
-  std::vector<Seq> sequences;
   size_t pos = 0;
   while (pos < data.size()) {
     // header line
@@ -80,13 +80,24 @@ bool Genome::from_fasta(const std::string& filepath, bool contiguous, Genome* ou
       if (e == std::string::npos) { next = data.size(); break; }
       next = e + 1;
     }
+    out->ids.push_back(header);                          // genome.rs:112 record.id()
+    out->body.emplace_back(p, next - p);
+    pos = next;
+  }
+  return true;
+}
+
+bool Genome::from_fasta(const std::string& filepath, bool contiguous, Genome* out, std::string* err) {
+  FastaRecords recs;
+  if (!scan_fasta(filepath, &recs, err)) return false;
+  std::vector<Seq> sequences;
+  for (size_t c = 0; c < recs.ids.size(); c++) {
     Seq s;
-    s.id = header;                                       // genome.rs:112 record.id()
+    s.id = recs.ids[c];
     s.uuid = generate_id();                              // genome.rs:118
-    s.seq = normalize(data.substr(p, next - p));         // genome.rs:114 normalize(false)
+    s.seq = normalize(recs.data.substr(recs.body[c].first, recs.body[c].second));  // genome.rs:114 normalize(false)
     s.size = s.seq.size();
     sequences.push_back(std::move(s));
-    pos = next;
   }
   Genome g;
   g.uuid = uuid_from_u64(generate_id());                 // genome.rs:124,140
@@ -372,7 +383,7 @@ std::string usage() {
          "  --seed <N>                    Random seed\n"
          "  --size-adjusted               Adjust by genome size\n"
          "  --contiguous                  Treat separate sequences in a genome as one contiguous sequence\n"
-         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths  --uniform-start  --host-fastq\n";
+         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths  --uniform-start  --host-fastq  --host-normalize\n";
 }
 
 static bool parse_u64(const std::string& s, uint64_t max, uint64_t* out) {
@@ -430,6 +441,7 @@ bool parse_cli_args(int argc, const char* const* argv, CliArgs* a, std::string* 
     else if (arg == "--size-adjusted") a->size_adjusted = true;
     else if (arg == "--contiguous") a->contiguous = true;
     else if (arg == "--host-fastq") a->host_fastq = true;
+    else if (arg == "--host-normalize") a->host_normalize = true;
     else if (arg == "--device") { if (!need(&v) || !parse_u64(v, 1023, &u)) { *err = "invalid value for --device"; return false; } a->device = (int)u; }
     else if (arg == "--gamma") {
       if (!need(&v)) return false;

@@ -100,6 +100,54 @@ static int write_fastq_device(simmr_engine* eng, const std::string& fmt, const s
   return ok ? 0 : -1;
 }
 
+// Genome::from_fasta (genome.rs:89-162) with the sequences going straight to the device: the host only finds
+// the records; simmr_stage_fasta normalises (needletail normalize(false), genome.rs:114), applies the size filter
+// of main.rs:117-162 and packs.  Returns 1 if the genome has no usable sequence (it is left out), -1 on error.
+static int load_genome_device(simmr_engine* eng, uint32_t slot, const std::string& path, bool contiguous, uint64_t min_size,
+                              Genome* g, std::string* err) {
+  FastaRecords recs;
+  if (!scan_fasta(path, &recs, err)) return -1;
+  const uint32_t n = (uint32_t)recs.ids.size();
+  std::vector<const uint8_t*> body(n);
+  std::vector<uint64_t> len(n), count(n);
+  for (uint32_t c = 0; c < n; c++) { body[c] = (const uint8_t*)recs.data.data() + recs.body[c].first; len[c] = recs.body[c].second; }
+  uint32_t n_staged = 0;
+  if (simmr_stage_fasta(eng, slot, n, body.data(), len.data(), contiguous ? 1 : 0, contiguous ? 0 : min_size, count.data(),
+                        &n_staged) != SIMMR_OK) {
+    *err = simmr_last_error(eng);
+    return -1;
+  }
+  g->uuid = uuid_from_u64(generate_id());  // genome.rs:124,140
+  g->filepath = path;
+  g->contiguous = contiguous;
+  g->size = 0;
+  for (uint32_t c = 0; c < n; c++) g->size += count[c];
+  g->sequence.clear();
+  if (contiguous) {  // genome.rs:121-137
+    Seq whole;
+    whole.id = "whole genome";
+    whole.uuid = generate_id();
+    whole.size = g->size;
+    g->sequence.push_back(std::move(whole));
+  } else {
+    for (uint32_t c = 0; c < n; c++) {
+      if (count[c] <= min_size) {
+        warn("(" + path + ") Sequence " + recs.ids[c] + " doesn't meet size requirements, size = " + std::to_string(count[c]) +
+             ", min size = " + std::to_string(min_size));
+        continue;
+      }
+      Seq q;
+      q.id = recs.ids[c];
+      q.uuid = generate_id();
+      q.size = count[c];
+      g->sequence.push_back(std::move(q));
+    }
+  }
+  g->num_seqs = g->sequence.size();
+  if (n_staged == 0) { warn("Removing " + path + " from simulation, it doesn't have usable sequences"); return 1; }
+  return 0;
+}
+
 static int run_main(int argc, char** argv) {
   CliArgs args;
   std::string err;
@@ -113,9 +161,33 @@ static int run_main(int argc, char** argv) {
   if (args.error_profile == ErrorProfileKind::CustomShort && eprofile->is_long_read())
     return die("You specified a custom short-read error profile but the provided error profile is for long reads");
 
+  simmr_engine* eng = nullptr;
+  if (simmr_engine_create(args.device, &eng) != SIMMR_OK) return die(std::string("cannot create engine: ") + simmr_last_error(nullptr));
+
   info("Loading genomes");
   std::vector<Genome> genomes;
-  if (args.genome_file) {  // main.rs:38-100
+  const uint64_t device_min_size = eprofile->minimum_genome_size();
+  if (!args.host_normalize) {
+    // main.rs:38-162 with the sequences normalised, filtered and packed on the device
+    std::vector<GenomeRecord> records;
+    if (args.genome_file) {
+      if (!parse_genome_file(*args.genome_file, &records, &err)) return die("Failed to read genome file: " + err);
+      for (const auto& rec : records)
+        if (!exists(rec.filepath)) return die("Genome (" + rec.filepath + ") does not exist");
+    } else {
+      for (const auto& path : args.genome) { GenomeRecord r; r.filepath = path; records.push_back(r); }
+    }
+    for (const auto& rec : records) {
+      Genome g;
+      const int rc = load_genome_device(eng, (uint32_t)genomes.size(), rec.filepath, args.contiguous, device_min_size, &g, &err);
+      if (rc < 0) return die("Failed to parse " + rec.filepath + ": " + err);
+      if (rec.uuid) g.uuid = *rec.uuid;
+      if (args.genome_file && args.abundance_profile == AbundanceProfileKind::Custom && !rec.abundance)
+        return die("You used a custom abundance profile but didn't provide abundances for genome " + g.filepath);
+      g.abundance = rec.abundance;
+      if (rc == 0) genomes.push_back(std::move(g));
+    }
+  } else if (args.genome_file) {  // main.rs:38-100
     std::vector<GenomeRecord> records;
     if (!parse_genome_file(*args.genome_file, &records, &err)) return die("Failed to read genome file: " + err);
     for (const auto& rec : records)
@@ -140,7 +212,7 @@ static int run_main(int argc, char** argv) {
     return die("a custom abundance profile needs a --genome-file with abundances");
 
   info("Ensuring genomes meet minimum sequence length requirements for simulation");
-  if (!args.contiguous) {  // main.rs:117-162
+  if (!args.contiguous && args.host_normalize) {  // main.rs:117-162
     const uint64_t min_size = eprofile->minimum_genome_size();
     std::vector<Genome> kept;
     for (Genome& g : genomes) {
@@ -169,9 +241,7 @@ static int run_main(int argc, char** argv) {
   std::unique_ptr<AbundanceProfile> aprofile = determine_abundance_profile(args, custom_ab);
 
   // ---- stage the references once (replaces keeping Vec<Seq> in RAM for the loop)
-  simmr_engine* eng = nullptr;
-  if (simmr_engine_create(args.device, &eng) != SIMMR_OK) return die(std::string("cannot create engine: ") + simmr_last_error(nullptr));
-  for (size_t gi = 0; gi < genomes.size(); gi++) {
+  for (size_t gi = 0; args.host_normalize && gi < genomes.size(); gi++) {
     const Genome& g = genomes[gi];
     std::vector<const uint8_t*> ptrs;
     std::vector<uint64_t> lens, sizes;

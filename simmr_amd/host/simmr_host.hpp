@@ -39,6 +39,17 @@ struct Genome {  // genome.rs:26-41
   static bool from_fasta(const std::string& filepath, bool contiguous, Genome* out, std::string* err);
 };
 
+// The record structure of a FASTA file without its sequences: what Genome::from_fasta does before it
+// normalises (genome.rs:93-112).  `data` is the file; record c has header ids[c] and the raw body
+// data[body[c].first, body[c].first + body[c].second) — the input of simmr_stage_fasta, which normalises
+// and packs on the device.
+struct FastaRecords {
+  std::string data;
+  std::vector<std::string> ids;
+  std::vector<std::pair<size_t, size_t>> body;
+};
+bool scan_fasta(const std::string& filepath, FastaRecords* out, std::string* err);
+
 // needletail 0.4.1 Sequence::normalize(iupac = false) as used at genome.rs:114
 std::string normalize(const std::string& raw);
 // util.rs:124-129: first 64 bits of a random UUID v4
@@ -178,6 +189,7 @@ struct CliArgs {  // cli.rs:93-220, same flags and defaults
   bool contiguous = false;
   // extensions of this implementation (not reference flags)
   int device = 0;
+  bool host_normalize = false;  // --host-normalize: normalise FASTA on the host instead of the device
   bool host_fastq = false;  // --host-fastq: frame the FASTQ on the host instead of the device
   std::optional<std::pair<float, float>> gamma;  // --gamma mean,std
   bool uniform_start = false;                    // --uniform-start (SIMMR_START_UNIFORM)

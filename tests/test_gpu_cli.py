@@ -134,3 +134,28 @@ def test_cli_device_and_host_fastq_agree(workdir):
                                "--seed", "3", "--error-profile", "minimal-short", "--read-header-format", fmt] + extra)
         outs.append(out.read_bytes())
     assert len(outs[0]) > 600_000 and outs[0] == outs[1]
+
+
+def test_cli_device_and_host_normalize_agree(workdir, tmp_path):
+    """FASTA bodies are normalised, size-filtered and packed on the device by default; --host-normalize keeps the
+    C++ restatement of genome.rs:89-162 + needletail normalize.  Same output, also for a messy FASTA."""
+    d, _ = workdir
+    rng = np.random.default_rng(4)
+    letters = np.frombuffer(b"ACGTacgtNnRYuU.-", dtype=np.uint8)
+    seq = letters[rng.choice(letters.size, 61_000, p=np.r_[np.full(4, 0.22), np.full(12, 0.01)])].tobytes()
+    messy = tmp_path / "messy.fna"
+    with open(messy, "wb") as f:
+        f.write(b">first record with spaces\r\n")
+        for i in range(0, 60_000, 70):
+            f.write(seq[i:i + 70] + b"\r\n")
+        f.write(b">short one\n" + seq[60_000:60_200] + b"\n\n>third\n" + seq[200:40_200] + b"\n")
+    tsv = tmp_path / "g.tsv"
+    tsv.write_text(f"path\tid\n{messy}\tmessy\n{d}/g1.fna\tgenome1\n")
+    for extra_common in ([], ["--contiguous"]):
+        outs = []
+        for extra in ([], ["--host-normalize"]):
+            out = tmp_path / ("norm%d%d.fq" % (len(extra_common), len(extra)))
+            subprocess.check_call([str(EXE), "--genome-file", str(tsv), "--output", str(out), "--num-reads", "3000", "--seed", "9",
+                                   "--error-profile", "minimal-short"] + extra_common + extra)
+            outs.append(out.read_bytes())
+        assert len(outs[0]) > 900_000 and outs[0] == outs[1]
