@@ -42,21 +42,21 @@ def test_stage_fasta_equals_host_normalize(engine, contiguous):
     raw = bodies()
     want = [host_normalize(b) for b in raw]
     min_size = 0 if contiguous else 14
-    counts, n_staged = engine.stage_fasta(9, raw, contiguous=contiguous, min_size=min_size)
+    counts, n_staged = engine.stage_fasta(20, raw, contiguous=contiguous, min_size=min_size)
     assert counts == [len(w) for w in want]
     if contiguous:
         assert n_staged == 1
         whole = b"".join(w + b"N" for w in want)  # genome.rs:121-137
-        n_contigs, size = engine.genome_info(9)
+        n_contigs, size = engine.genome_info(20)
         assert n_contigs == 1 and size == sum(len(w) for w in want)  # Seq.size does not count the separators
-        assert engine.unstage(9, 0, 0, len(whole)).tobytes() == whole
+        assert engine.unstage(20, 0, 0, len(whole)).tobytes() == whole
     else:
         kept = [w for w in want if len(w) > min_size]  # main.rs:117-162
         assert n_staged == len(kept) and len(kept) < len(want)
-        n_contigs, size = engine.genome_info(9)
+        n_contigs, size = engine.genome_info(20)
         assert n_contigs == len(kept) and size == sum(len(w) for w in kept)
         for c, w in enumerate(kept):
-            assert engine.unstage(9, c, 0, len(w)).tobytes() == w, c
+            assert engine.unstage(20, c, 0, len(w)).tobytes() == w, c
 
 
 def test_stage_fasta_then_simulate(engine, oracle):
@@ -65,11 +65,11 @@ def test_stage_fasta_then_simulate(engine, oracle):
     from tests import _oracle
     raw = bodies()[:1] + bodies()[5:6]
     norm = [np.frombuffer(host_normalize(b), dtype=np.uint8) for b in raw]
-    engine.stage_fasta(9, raw)
-    engine.stage_genome(10, norm)
+    engine.stage_fasta(20, raw)
+    engine.stage_genome(21, norm)
     prof = MinimalShortErrorProfile().pod()
-    a = engine.simulate_pe_reads_from_genome(9, prof, 3000, 5, qual_offset=33).to_host()
-    b = engine.simulate_pe_reads_from_genome(10, prof, 3000, 5, qual_offset=33).to_host()
+    a = engine.simulate_pe_reads_from_genome(20, prof, 3000, 5, qual_offset=33).to_host()
+    b = engine.simulate_pe_reads_from_genome(21, prof, 3000, 5, qual_offset=33).to_host()
     for col in ("seq", "qual", "seq_off", "start", "end", "contig", "flags"):
         assert np.array_equal(a[col], b[col]), col
     o = _oracle.simulate_pe(oracle, _oracle.HostGenome(norm), prof, 3000, 5, qual_offset=33).trimmed()
@@ -78,7 +78,7 @@ def test_stage_fasta_then_simulate(engine, oracle):
 
 def test_stage_fasta_nothing_left(engine):
     from simmr_amd import SimmrError, PerfectShortErrorProfile
-    counts, n_staged = engine.stage_fasta(11, [b"ACGT\nAC\n", b"\n"], min_size=100)
+    counts, n_staged = engine.stage_fasta(22, [b"ACGT\nAC\n", b"\n"], min_size=100)
     assert counts == [6, 0] and n_staged == 0
     with pytest.raises(SimmrError):  # the slot is not staged
-        engine.pe_plan(11, PerfectShortErrorProfile().pod(), 10, 1)
+        engine.pe_plan(22, PerfectShortErrorProfile().pod(), 10, 1)

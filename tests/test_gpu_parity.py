@@ -411,7 +411,7 @@ def test_error_paths(engine, genome_multi):
         engine.pe_plan(1, PerfectShortErrorProfile(30000, 30000).pod(), 10, 1)
     assert ei.value.code == _abi.ERANGE  # u16 overflow of minimum_genome_size
     with pytest.raises(SimmrError) as ei:
-        engine.pe_plan(9, PerfectShortErrorProfile().pod(), 10, 1)
+        engine.pe_plan(63, PerfectShortErrorProfile().pod(), 10, 1)  # a slot no test stages
     assert ei.value.code == _abi.EINVAL
     with pytest.raises(SimmrError) as ei:
         engine.pe_plan(1, MinimalLongErrorProfile().pod(), 10, 1)
