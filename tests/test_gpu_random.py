@@ -1,0 +1,57 @@
+"""Randomized parity sweep: a few hundred random (genome shape, profile, parameters, seed, shard) combinations,
+device against the oracle, every column bit for bit.  Complements the hand-picked cases of test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from simmr_amd import MinimalLongErrorProfile, MinimalShortErrorProfile, PerfectShortErrorProfile, SimmrError, _abi
+from tests import _oracle, _synth
+from tests.test_gpu_parity import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("sweep_seed", [7, 11, 2024])
+def test_random_configurations_match_the_oracle(engine, oracle, sweep_seed):
+    rng = np.random.default_rng(sweep_seed)
+    e, lib = engine, oracle
+    n_ok = 0
+    SLOT = 30
+    for it in range(220):
+        nc = int(rng.integers(1, 6))
+        lens = [int(rng.integers(700, 60_000)) for _ in range(nc)]
+        contigs = _synth.synthetic_contigs(lens, int(rng.integers(1, 1 << 30)))
+        if rng.random() < 0.4:
+            c = contigs[0].copy(); k = rng.integers(0, c.size, c.size // 20); c[k] = ord("N"); c[rng.integers(0, c.size, 30)] = ord("-"); contigs[0] = c
+        e.stage_genome(SLOT, contigs); host = _oracle.HostGenome(contigs)
+        seed = int(rng.integers(0, 1 << 62)); qoff = int(rng.choice([0, 33]))
+        kind = rng.integers(0, 4)
+        try:
+            if kind <= 1:
+                L = int(rng.integers(1, 260)); I = int(rng.integers(0, 400)); mq = int(rng.integers(0, 70))
+                if kind == 0:
+                    prof = PerfectShortErrorProfile(L, I).pod()
+                else:
+                    prof = MinimalShortErrorProfile(read_length=L, insert_size=I, mean_phred_score=mq, rng_mode=int(rng.integers(0, 2))).pod()
+                reads = int(rng.integers(0, 1500)); first = int(rng.integers(0, reads // 2 + 2)); count = int(rng.integers(0, 800))
+                if 2 * L + I >= min(lens):
+                    continue
+                dev = e.simulate_pe_reads_from_genome(SLOT, prof, reads, seed, first=first, count=count, read_id_base=3, qual_offset=qoff)
+                ora = _oracle.simulate_pe(lib, host, prof, reads, seed, first=first, count=count, read_id_base=3, qual_offset=qoff, max_len=70000)
+            else:
+                gm = float(rng.integers(300, 4000)); gs = gm * float(rng.uniform(0.3, 0.9))
+                cls = MinimalLongErrorProfile
+                rm = int(rng.integers(0, 2))
+                prof = cls(gamma_mean=gm, gamma_std=gs, length_mode=int(rng.integers(0, 2)), rng_mode=rm, uniform_start=bool(rng.integers(0, 2)), mean_phred_score=int(rng.integers(0, 60))).pod()
+                if kind == 3 and rm == 0:
+                    prof.kind = _abi.PERFECT_LONG
+                if min(lens) <= 20000 and max(lens) <= 20000:
+                    continue
+                reads = int(rng.integers(0, 60)); first = int(rng.integers(0, reads + 1)); count = int(rng.integers(0, 40))
+                dev = e.simulate_long_reads([SLOT], [reads], prof, seed, first=first, count=count, read_id_base=1, qual_offset=qoff)
+                ora = _oracle.simulate_long(lib, [host], [reads], prof, seed, first=first, count=count, read_id_base=1, qual_offset=qoff)
+            d, o = dev.to_host(), ora.trimmed()
+            assert_same(d, o, what=f"it{it} kind{kind} ")
+            n_ok += 1
+        except (SimmrError, RuntimeError):
+            pass  # both sides refuse some configurations (a contig too small for the drawn length, ...)
+    assert n_ok > 150
