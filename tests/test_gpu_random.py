@@ -55,3 +55,44 @@ def test_random_configurations_match_the_oracle(engine, oracle, sweep_seed):
         except (SimmrError, RuntimeError):
             pass  # both sides refuse some configurations (a contig too small for the drawn length, ...)
     assert n_ok > 150
+
+
+def test_random_multi_genome_plans(engine, oracle):
+    """simmr_pe_plan_multi over random genome lists, read counts, profiles and shards against the reference's loop
+    over genomes restated with the oracle (simulate.rs:121-150: same seed per genome, one global id counter)."""
+    rng = np.random.default_rng(99)
+    hosts = {}
+    for slot, lens in ((40, [30_000]), (41, [9_000, 25_000, 14_000]), (42, [50_000]), (43, [8_000, 8_500])):
+        contigs = _synth.synthetic_contigs(lens, 100 + slot)
+        if slot == 42:
+            contigs[0] = contigs[0].copy()
+            contigs[0][rng.integers(0, 50_000, 2500)] = ord("N")
+        engine.stage_genome(slot, contigs)
+        hosts[slot] = _oracle.HostGenome(contigs)
+    n_ok = 0
+    for it in range(60):
+        order = [int(x) for x in rng.choice([40, 41, 42, 43], size=int(rng.integers(1, 7)))]
+        reads = [int(rng.integers(0, 900)) for _ in order]
+        L, I = int(rng.integers(5, 200)), int(rng.integers(0, 300))
+        prof = [PerfectShortErrorProfile(L, I), MinimalShortErrorProfile(read_length=L, insert_size=I),
+                MinimalShortErrorProfile(read_length=L, insert_size=I, rng_mode=_abi.RNG_PHILOX)][int(rng.integers(0, 3))].pod()
+        seed = int(rng.integers(0, 1 << 60))
+        parts, base = [], 0
+        for gi, n in zip(order, reads):
+            o = _oracle.simulate_pe(oracle, hosts[gi], prof, n, seed, read_id_base=base, qual_offset=33, max_len=70000).trimmed()
+            o["genome"] = np.full(o["read_id"].size, gi, np.uint32)
+            parts.append(o)
+            base += n // 2
+        lens = np.concatenate([np.diff(p["seq_off"].astype(np.int64)) for p in parts])
+        whole = {c: np.concatenate([p[c] for p in parts]) for c in ("seq", "qual", "start", "end", "contig", "genome", "read_id", "flags")}
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        first, count = int(rng.integers(0, base + 2)), int(rng.integers(0, base + 2))
+        d = engine.simulate_pe_reads_multi(order, reads, prof, seed, first=first, count=count, qual_offset=33).to_host()
+        a, b = 2 * min(first, base), 2 * min(first + count, base)
+        assert np.array_equal(d["seq_off"], off[a:b + 1] - off[a]), it
+        for col in ("start", "end", "contig", "genome", "read_id", "flags"):
+            assert np.array_equal(d[col], whole[col][a:b]), (it, col)
+        assert np.array_equal(d["seq"], whole["seq"][int(off[a]):int(off[b])]), it
+        assert np.array_equal(d["qual"], whole["qual"][int(off[a]):int(off[b])]), it
+        n_ok += 1
+    assert n_ok == 60
