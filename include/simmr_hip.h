@@ -65,7 +65,8 @@ enum simmr_profile_kind {
  * PHILOX: counter-based Philox4x32-10 keyed by the read's Phred seed, counter
  *   = base index / 4, one output word per base; that word draws (Phred,
  *   substitution) from their joint law with one alias-table lookup (the law
- *   is stated in DESIGN.md section 4 and restated in oracle/philox.c).
+ *   is stated in DESIGN.md section 4 and restated in oracle/philox.c); every
+ *   profile with per-base draws except the custom ones.
  *   Positions, lengths and seeds still come from the reference streams.
  *   Statistical tolerance only (BASELINE.json north_star). */
 enum simmr_rng_mode { SIMMR_RNG_REFERENCE = 0, SIMMR_RNG_PHILOX = 1 };

@@ -11,7 +11,9 @@
  *   - that one word W draws the Phred score and the substitution together from
  *     the joint law of minimal_short.rs:83-140 with an alias table over the 1024
  *     outcomes o = q | s << 8:
- *       P(q)      = P(floor(N(mean,10)) saturated to u8 == q)
+ *       P(q)      = P(floor(N(mean,10)) saturated to u8 == q)                    (minimal profiles)
+ *                 = P(round(-10 log10(1 - min(N(0.99, 0.05), 0.9999))) == q)      (perfect-long,
+ *                   perfect_long.rs:60-78: q = 40 carries the mass of the 0.9999 cap)
  *       p_q       = P(gen::<f32>() > accuracy(q)) = (2^24 - 1 - t) / 2^24,
  *                   t = min(floor(accuracy(q) * 2^24), 2^24 - 1)   (the reference's 24-bit test)
  *       w(q, 0)   = P(q) (1 - p_q),   w(q, s) = P(q) p_q / 3 for s = 1, 2, 3
@@ -38,16 +40,30 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+/* P(Phred == q) of the profile's quality law, in closed form */
+static double phred_cdf_upper(uint32_t kind, double mean, int q) { /* P(Phred <= q) */
+  if (q >= 255) return 1.0;
+  if (kind == SIMMR_PERFECT_LONG) {
+    /* q = round(-10 log10 d), d = 1 - min(acc, 0.9999), acc ~ N(0.99, 0.05):
+     * Phred <= q  <=>  d > 10^-((q + 0.5) / 10)  <=>  acc < 1 - 10^-((q + 0.5) / 10); the cap puts everything
+     * above 0.9999 on d = 1e-4, i.e. on q = 40 */
+    if (q >= 40) return 1.0;
+    const double acc_hi = 1.0 - pow(10.0, -((double)q + 0.5) / 10.0);
+    return 0.5 * erfc(-((acc_hi - 0.99) / 0.05) / 1.4142135623730951);
+  }
+  /* floor(mean + 10 z) saturated: Phred <= q  <=>  mean + 10 z < q + 1 */
+  return 0.5 * erfc(-(((double)(q + 1) - mean) / 10.0) / 1.4142135623730951);
+}
+
 /* table[i] = thr22 | alias << 22 with thr22 in [0, 2^22 - 1], i = q | s << 8 */
-void orc_philox_joint_table(uint8_t mean_phred, uint32_t table[1024]) {
+void orc_philox_joint_table(uint32_t kind, uint8_t mean_phred, uint32_t table[1024]) {
   enum { N = 1024 };
   double odds[N];
   int alias[N], smalls[N], bigs[N];
   double cdf_prev = 0.0;
   const double mean = (double)mean_phred;
   for (int q = 0; q < 256; q++) {
-    /* P(floor(mean + 10 z) saturated == q) */
-    double upper = (q == 255) ? 1.0 : 0.5 * erfc(-(((double)(q + 1) - mean) / 10.0) / 1.4142135623730951);
+    double upper = phred_cdf_upper(kind, mean, q);
     double P = upper - cdf_prev;
     if (P < 0.0) P = 0.0;
     cdf_prev = upper;
@@ -81,7 +97,8 @@ void orc_philox_read(const simmr_error_profile* p, const uint8_t* seq, uint64_t 
                      uint8_t* qual_out, uint8_t* seq_out) {
   static _Thread_local uint32_t table[1024];
   static _Thread_local int table_for = -1;
-  if (table_for != (int)p->mean_phred) { orc_philox_joint_table(p->mean_phred, table); table_for = (int)p->mean_phred; }
+  const int want = (int)p->mean_phred | (p->kind == SIMMR_PERFECT_LONG ? 0x100 : 0);
+  if (table_for != want) { orc_philox_joint_table(p->kind, p->mean_phred, table); table_for = want; }
   const uint32_t key[2] = {(uint32_t)key64, (uint32_t)(key64 >> 32)};
   uint32_t w[4] = {0, 0, 0, 0};
   for (uint64_t b = 0; b < len; b++) {

@@ -614,7 +614,7 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
       int r2 = 0;
       if (u->end > G->len[u->contig]) { r2 = SIMMR_ERANGE; }
       /* :497 quality over end-start; :500 simulate_errors = copy; :503 mutations */
-      if (!r2 && p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_MINIMAL_LONG) {
+      if (!r2 && p->rng_mode == SIMMR_RNG_PHILOX && (p->kind == SIMMR_MINIMAL_LONG || p->kind == SIMMR_PERFECT_LONG)) {
         orc_philox_read(p, G->seq[u->contig] + u->start, n, u->read_seed, out->qual + o1, out->seq + o1);
       } else {
       if (!r2) r2 = orc_profile_simulate_phred_scores(p, n, u->read_seed, out->qual + o1);

@@ -305,8 +305,6 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
   if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_CUSTOM)
     return e->fail(SIMMR_EINVAL, "SIMMR_RNG_PHILOX covers the Normal(mean, 10) Phred profiles (minimal-short, minimal-long)");
   if (p->kind == SIMMR_CUSTOM) return make_custom_profile(e, p, want_long, out);
-  if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_PERFECT_LONG)
-    return e->fail(SIMMR_EINVAL, "SIMMR_RNG_PHILOX covers the Normal(mean, 10) Phred profiles (minimal-short, minimal-long)");
   const bool is_long = p->kind == SIMMR_PERFECT_LONG || p->kind == SIMMR_MINIMAL_LONG;
   if (is_long != want_long)
     return e->fail(SIMMR_EINVAL, want_long ? "a short-read profile was passed to the long-read path"
@@ -341,7 +339,7 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
         (!(p->read_length_std >= 0.0) || !(p->insert_size_std >= 0.0)))
       return e->fail(SIMMR_EINVAL, "negative standard deviation");
   }
-  if (p->rng_mode == SIMMR_RNG_PHILOX && (p->kind == SIMMR_MINIMAL_SHORT || p->kind == SIMMR_MINIMAL_LONG)) {
+  if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind != SIMMR_PERFECT_SHORT) {
     // Joint (Phred, substitution) alias table over the 1024 outcomes o = q | s << 8:
     // w(q,0) = P(q)(1 - p_q), w(q,s) = P(q) p_q / 3; P(q) = P(floor(N(mean, 10)) saturated to u8 == q),
     // p_q = the probability of the reference's 24-bit test gen::<f32>() > accuracy(q).  Vose's method
@@ -352,7 +350,14 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
     double prev = 0.0;
     int ns = 0, nb = 0;
     for (int q = 0; q < 256; q++) {
-      const double upper = q == 255 ? 1.0 : 0.5 * erfc(-(((double)(q + 1) - (double)p->mean_phred) / 10.0) / 1.4142135623730951);
+      // P(Phred <= q): minimal profiles floor(N(mean, 10)) saturated to u8; perfect-long (perfect_long.rs:60-78)
+      // round(-10 log10(1 - min(N(0.99, 0.05), 0.9999))), whose cap puts everything above 0.9999 on q = 40
+      double upper;
+      if (q == 255) upper = 1.0;
+      else if (p->kind == SIMMR_PERFECT_LONG)
+        upper = q >= 40 ? 1.0 : 0.5 * erfc(-(((1.0 - pow(10.0, -((double)q + 0.5) / 10.0)) - 0.99) / 0.05) / 1.4142135623730951);
+      else
+        upper = 0.5 * erfc(-(((double)(q + 1) - (double)p->mean_phred) / 10.0) / 1.4142135623730951);
       double P = upper - prev;
       if (P < 0.0) P = 0.0;
       prev = upper;

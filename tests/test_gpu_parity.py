@@ -288,17 +288,12 @@ def test_philox_mode_exceptions(engine, oracle):
     dev = engine.simulate_pe_reads_from_genome(3, prof, 3000, 8)
     ora = _oracle.simulate_pe(oracle, g, prof, 3000, 8)
     assert_same(dev.to_host(), ora.trimmed())
-    prof = PerfectLongErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()  # different Phred law: refused, not approximated
     from simmr_amd import SimmrError
-    engine.stage_genome(3, [np.tile(seq, 2)])
-    with pytest.raises(SimmrError) as ei:
-        engine.long_plan([3], [5], prof, 1)
-    assert ei.value.code == _abi.EINVAL
     from simmr_amd import CustomShortErrorProfile
     from tests import _model
     keep = CustomShortErrorProfile(_model.synthetic_short_model(n_positions=40, seed=5))
     cp = keep.pod()
-    cp.rng_mode = _abi.RNG_PHILOX  # empirical PDFs have no counter mode either
+    cp.rng_mode = _abi.RNG_PHILOX  # empirical PDFs have no counter mode
     with pytest.raises(SimmrError) as ei:
         engine.pe_plan(3, cp, 10, 1)
     assert ei.value.code == _abi.EINVAL
@@ -554,3 +549,20 @@ def test_long_reads_uniform_start(engine, oracle, genome_multi, genome_1m):
     # the reference's quirk for comparison: with the constant 20 000-base length every start is below it
     ref = engine.simulate_long_reads([1, 0], [60, 40], MinimalLongErrorProfile().pod(), 11).to_host()
     assert (ref["start"] < 65536).all()
+
+
+def test_philox_mode_perfect_long(engine, oracle, genome_multi, genome_1m):
+    """Counter mode for perfect-long (perfect_long.rs:60-119): same joint-alias machinery with that profile's Phred law;
+    bit-exact against its restatement, and the Phred histogram agrees with the bit-exact mode's."""
+    prof = PerfectLongErrorProfile(rng_mode=_abi.RNG_PHILOX, length_mode=_abi.LEN_PER_READ, gamma_mean=3000.0, gamma_std=2000.0).pod()
+    dev = engine.simulate_long_reads([1, 0], [150, 100], prof, 21).to_host()
+    ora = _oracle.simulate_long(oracle, [genome_multi, genome_1m], [150, 100], prof, 21).trimmed()
+    assert_same(dev, ora)
+    prof.rng_mode = _abi.RNG_REFERENCE
+    ref = engine.simulate_long_reads([1, 0], [150, 100], prof, 21).to_host()
+    assert np.array_equal(ref["seq_off"], dev["seq_off"])  # lengths and positions do not depend on the mode
+    n = dev["qual"].size
+    assert n > 500_000
+    ha, hb = np.bincount(dev["qual"], minlength=64) / n, np.bincount(ref["qual"], minlength=64) / n
+    assert ha[41:].sum() == 0 and hb[41:].sum() == 0 and abs(ha[40] - hb[40]) < 0.005
+    assert np.abs(ha - hb).max() < 0.005

@@ -113,7 +113,7 @@ def test_philox4x32_10_random123_vectors(oracle):
         "d16cfe09 94fdcceb 5001e420 24126ea1"
     # joint (Phred, substitution) alias table: implied outcome probabilities vs the analytic law
     t = (C.c_uint32 * 1024)()
-    oracle.orc_philox_joint_table(30, t)
+    oracle.orc_philox_joint_table(1, 30, t)  # kind 1 = minimal-short
     tab = np.array(list(t), dtype=np.uint64)
     thr, al = (tab & 0x3fffff).astype(float), (tab >> 22).astype(int)
     P = np.zeros(1024)
@@ -138,6 +138,21 @@ def test_philox4x32_10_random123_vectors(oracle):
         assert max(sub) - min(sub) <= 2 * 2.0 ** -32, q
     rate = P[256:].sum()
     assert abs(rate / 0.013404 - 1) < 1e-3, rate
+    # perfect-long law (perfect_long.rs:60-78): Monte Carlo of the f32 pipeline against the table's marginals
+    oracle.orc_philox_joint_table(2, 0, t)  # kind 2 = perfect-long
+    tab = np.array(list(t), dtype=np.uint64)
+    thr, al = (tab & 0x3fffff).astype(float), (tab >> 22).astype(int)
+    P = np.zeros(1024)
+    for i in range(1024):
+        P[i] += thr[i] / 4194304 / 1024
+        P[al[i]] += (1 - thr[i] / 4194304) / 1024
+    Pq = P.reshape(4, 256).sum(axis=0)
+    z = np.random.default_rng(1).standard_normal(4_000_000).astype(np.float32)
+    acc = np.minimum(np.float32(0.99) + np.float32(0.05) * z, np.float32(0.9999))
+    q = np.clip(np.round(np.float32(-10.0) * np.log10(np.float32(1.0) - acc)), 0, 255).astype(int)
+    emp = np.bincount(q, minlength=256) / q.size
+    assert Pq[41:].sum() == 0 and abs(Pq[40] - emp[40]) < 1e-3 and Pq[40] > 0.4
+    assert np.abs(Pq - emp).max() < 1.5e-3
 
 
 # ---- reference unit tests restated ------------------------------------------
