@@ -42,7 +42,7 @@ def test_random_configurations_match_the_oracle(engine, oracle, sweep_seed):
                 cls = MinimalLongErrorProfile
                 rm = int(rng.integers(0, 2))
                 prof = cls(gamma_mean=gm, gamma_std=gs, length_mode=int(rng.integers(0, 2)), rng_mode=rm, uniform_start=bool(rng.integers(0, 2)), mean_phred_score=int(rng.integers(0, 60))).pod()
-                if kind == 3 and rm == 0:
+                if kind == 3:
                     prof.kind = _abi.PERFECT_LONG
                 if min(lens) <= 20000 and max(lens) <= 20000:
                     continue
