@@ -1454,8 +1454,11 @@ int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst
                    reads->read_id, reads->flags};
   const uint64_t n_batches = (e->fq_reads + FQ_BATCH - 1) / FQ_BATCH;
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 8);
+  const uint32_t hdr_lds = 4 * FQ_BATCH * e->fq_hpitch;  // up to 68 KB with 255-byte headers: above the default limit
+  if (hdr_lds > 48 * 1024)
+    HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fastq_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_lds));
   HIP_TRY(e, hipEventRecord(e->ev_c, e->stream));
-  hipLaunchKernelGGL(k_fastq_write, dim3(grid), dim3(256), 4 * FQ_BATCH * e->fq_hpitch, e->stream, e->fq_tpl, tb, rd,
+  hipLaunchKernelGGL(k_fastq_write, dim3(grid), dim3(256), hdr_lds, e->stream, e->fq_tpl, tb, rd,
                      e->fq_reads, e->fq_paired ? 1u : 0u, e->fq_lit_bytes, e->fq_hpitch, e->fq_off.as<uint64_t>(), dst);
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
   hipError_t s = hipGetLastError();

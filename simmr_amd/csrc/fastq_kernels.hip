@@ -25,7 +25,7 @@ namespace simmr {
 #define FQ_MAX_SEGS 24
 #define FQ_HMAX 256u  /* longest header, including the '\n' */
 #define FQ_LIT_MAX 256u /* template literals kept in LDS (they are part of a header, so < FQ_HMAX) */
-#define FQ_BATCH 32u  /* reads per wave iteration */
+#define FQ_BATCH 64u  /* reads per wave iteration */
 
 enum FqKind : uint32_t {
   FQ_LITERAL = 0, FQ_GENOME_ID, FQ_READ_ID, FQ_SEQUENCE_ID, FQ_START, FQ_END, FQ_REVCOMP, FQ_PAIR

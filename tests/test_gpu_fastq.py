@@ -73,6 +73,14 @@ def test_fastq_long_multi_genome(engine, genome_multi, genome_1m):
     _check(engine, reads, names, "@{:sequence_id:}", False)
 
 
+def test_fastq_longest_headers(engine, genome_multi):
+    """Headers close to the 255-byte limit: the header slots then need more LDS than the default launch limit."""
+    n = len(genome_multi.contigs)
+    names = [(1, "g" * 60, ["contig %d " % i + "x" * 100 for i in range(n)])]
+    reads = engine.simulate_pe_reads_from_genome(1, MinimalShortErrorProfile(read_length=40, insert_size=60).pod(), 3000, 2, qual_offset=33)
+    _check(engine, reads, names, FMT, True)
+
+
 def test_fastq_left_to_the_host(engine, genome_multi):
     reads = engine.simulate_pe_reads_from_genome(1, PerfectShortErrorProfile().pod(), 100, 1, qual_offset=33)
     n = len(genome_multi.contigs)
