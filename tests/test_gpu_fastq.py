@@ -93,3 +93,21 @@ def test_fastq_left_to_the_host(engine, genome_multi):
     # an empty shard is an empty file
     empty = engine.simulate_pe_reads_from_genome(1, PerfectShortErrorProfile().pod(), 100, 1, first=50, count=0, qual_offset=33)
     assert engine.fastq(empty, FMT, [(1, "g", ["c"] * n)], True).numel() == 0
+
+
+def test_fastq_random_templates(engine, genome_multi):
+    """Random header templates built from placeholders, placeholder fragments, braces and text: the device's
+    compiled template must equal the reference's chain of String::replace calls (fastq.rs:34-56) on every one."""
+    rng = np.random.default_rng(77)
+    pieces = ["{:genome_id:}", "{:read_id:}", "{:sequence_id:}", "{:start_position:}", "{:end_position:}",
+              "{:reverse_complement:}", "{:pair:}", "{:", ":}", "{", "}", ":", "{:pair", "read_id:}", "{:s", "art_position:}",
+              "@", " ", "|", "sp=", "x", "{:genome_id:", "{:{:pair:}"]
+    n = len(genome_multi.contigs)
+    names = [(1, "G-1", ["ctg_%d z" % i for i in range(n)])]
+    reads = engine.simulate_pe_reads_from_genome(1, MinimalShortErrorProfile(read_length=33, insert_size=50).pod(), 400, 6, qual_offset=33)
+    for _ in range(40):
+        fmt = "".join(rng.choice(pieces, size=int(rng.integers(0, 12))))
+        try:
+            _check(engine, reads, names, fmt, True)
+        except SimmrError as ex:  # more than 24 pieces / 256 literal bytes: left to the host
+            assert ex.code == _abi.ENOTSUP
