@@ -909,6 +909,12 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, const 
                   uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_byte,
                   uint64_t first_unit, uint32_t read_id_base, OutCols o, unsigned long long* __restrict__ counters) {
   __shared__ int64_t r_pos[PERFECT_GROUP];  // absolute base position of output byte 0's source
+  __shared__ uint32_t asc[256];             // four 2-bit codes -> four ASCII bytes (genomes without exceptions)
+  {
+    const uint32_t t = threadIdx.x, acgt = 0x54474341u;  // "ACGT"
+    asc[t] = ((acgt >> (8 * (t & 3u))) & 0xffu) | (((acgt >> (8 * ((t >> 2) & 3u))) & 0xffu) << 8) |
+             (((acgt >> (8 * ((t >> 4) & 3u))) & 0xffu) << 16) | (((acgt >> (8 * (t >> 6))) & 0xffu) << 24);
+  }
   __shared__ const uint32_t* r_packed[MULTI ? PERFECT_GROUP : 1];
   __shared__ const uint32_t* r_mask[MULTI ? PERFECT_GROUP : 1];
   GenomeDev G = genomes[genome];
@@ -1011,10 +1017,14 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, const 
             exc = (exc & ((1u << na) - 1u)) | (pc_exc[1] << na);
           }
           uint4 out;
-          out.x = expand4(codes & 0xffu, exc & 0xfu);
-          out.y = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
-          out.z = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu);
-          out.w = expand4(codes >> 24, (exc >> 12) & 0xfu);
+          if (G.has_exc) {
+            out.x = expand4(codes & 0xffu, exc & 0xfu);
+            out.y = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
+            out.z = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu);
+            out.w = expand4(codes >> 24, (exc >> 12) & 0xfu);
+          } else {
+            out = make_uint4(asc[codes & 0xffu], asc[(codes >> 8) & 0xffu], asc[(codes >> 16) & 0xffu], asc[codes >> 24]);
+          }
           const uint32_t lb = cl << 4;
           const uint64_t byte0 = gbyte0 + lb;
           if (lb + 16u <= gbytes) {
