@@ -116,7 +116,11 @@ float orc_pairwise_sum_f32(const float* v, uint32_t n);
 /* WeightedAliasIndex<f32> one-shot: new(weights) then sample (custom_short.rs:497-503) */
 static int alias_f32_sample_once(const float* w, uint32_t n, orc_rng* r, uint32_t* out) {
   if (n == 0) return -1;
+  /* WeightedAliasIndex::new: every weight in [0, f32::MAX / n] (NaN fails), the sum clamped to f32::MAX, not 0 */
+  const float maxw = 3.40282347e38f / (float)n;
+  for (uint32_t i = 0; i < n; i++) if (!(0.0f <= w[i] && w[i] <= maxw)) return -3;
   float wsum = orc_pairwise_sum_f32(w, n);
+  if (wsum > 3.40282347e38f) wsum = 3.40282347e38f;
   if (wsum == 0.0f) return -2;
   float* odds = (float*)malloc(sizeof(float) * n);
   uint32_t* al = (uint32_t*)calloc(n, sizeof(uint32_t));

@@ -190,6 +190,15 @@ int orc_profile_get_random_read_length(const simmr_error_profile* p, uint64_t se
     case SIMMR_MINIMAL_SHORT: return orc_profile_get_read_length(p, seed, out); /* :47-56 */
     case SIMMR_PERFECT_LONG:
     case SIMMR_MINIMAL_LONG: return gamma_length(p, seed, out);
+    case SIMMR_CUSTOM: { /* custom_short.rs:286-301: Normal<f64>(read_length_mean, read_length_std), NOT the PDF */
+      orc_custom* c = custom_of(p);
+      if (!c) FAIL(SIMMR_EINVAL, "cannot parse the custom model");
+      const orc_model* m = orc_custom_model(c);
+      if (!isfinite(m->read_length_std)) FAIL(SIMMR_ERANGE, "Normal::new(..).unwrap() panics: read_length_std is not finite");
+      orc_rng r; orc_rng_seed_from_u64(&r, seed);
+      *out = sat_u16_f64(floor(orc_normal_f64(&r, m->read_length_mean, m->read_length_std)));
+      return 0;
+    }
     default: FAIL(SIMMR_EINVAL, "profile kind %u not restated", p->kind);
   }
 }
@@ -510,6 +519,8 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
   if (count > total - first) count = total - first;
   if (out->reads_capacity < count) FAIL(SIMMR_ERANGE, "reads_capacity too small");
   int per_read = (!has_seed) || p->length_mode == SIMMR_LEN_PER_READ;
+  if (per_read && p->kind == SIMMR_CUSTOM) FAIL(SIMMR_ENOTSUP, "custom model on the long-read path: seed and SIMMR_LEN_REFERENCE only");
+  if (p->kind == SIMMR_CUSTOM && !orc_profile_is_long_read(p)) FAIL(SIMMR_EINVAL, "a short-read custom model on the long-read path");
   long_unit* units = (long_unit*)calloc(count ? count : 1, sizeof(long_unit));
   if (!units) FAIL(SIMMR_ENOMEM, "oom");
   int rc = 0;
@@ -616,6 +627,15 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
       /* :497 quality over end-start; :500 simulate_errors = copy; :503 mutations */
       if (!r2 && p->rng_mode == SIMMR_RNG_PHILOX && (p->kind == SIMMR_MINIMAL_LONG || p->kind == SIMMR_PERFECT_LONG)) {
         orc_philox_read(p, G->seq[u->contig] + u->start, n, u->read_seed, out->qual + o1, out->seq + o1);
+      } else if (!r2 && p->kind == SIMMR_CUSTOM) {
+        /* :497 quality; :500 simulate_errors (the k-mer splice); :503 simulate_point_mutations = copy */
+        r2 = orc_profile_simulate_phred_scores(p, n, u->read_seed, out->qual + o1);
+        if (!r2) {
+          int64_t m = orc_custom_simulate_errors(orc_custom_model(custom_of(p)), G->seq[u->contig] + u->start, n,
+                                                 u->read_seed, out->seq + o1);
+          /* < 0: the reference panics; < n: a deletion in the last k-mer leaves fewer bases than qualities */
+          if (m != (int64_t)n) r2 = SIMMR_ERANGE;
+        }
       } else {
       if (!r2) r2 = orc_profile_simulate_phred_scores(p, n, u->read_seed, out->qual + o1);
       if (!r2) r2 = orc_profile_simulate_point_mutations(p, G->seq[u->contig] + u->start, out->qual + o1, n, u->read_seed, out->seq + o1);

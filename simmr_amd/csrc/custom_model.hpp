@@ -9,7 +9,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "device_types.hpp"
@@ -163,6 +165,99 @@ inline bool append_pdf(const BinsHost& b, PdfTables* t, std::string* err) {
     t->bin_zone.push_back(range ? 0xFFFFFFFFu - (uint32_t)((0x100000000ULL - range) % range) : 0xFFFFFFFFu);
   }
   t->pdfs.push_back(d);
+  return true;
+}
+
+// Tables for simulate_errors (custom_short.rs:455-516).  The reference rebuilds a HashMap of the model's
+// k-mer probabilities per call (:462-467) and a WeightedAliasIndex<f32> per visited k-mer (:497-499); both
+// depend on the model only, so they are built once here: an open-addressing table keyed by the 3-bit k-mer
+// code and, per entry, the alias columns with the alternates already resolved.
+struct KmerTables {
+  std::vector<Rec16> slots;
+  std::vector<Rec16> recs;
+  uint32_t mask = 0;
+};
+
+inline float pairwise_sum_f32(const float* v, size_t n) {
+  if (n <= 32) { float s = 0.0f; for (size_t i = 0; i < n; i++) s += v[i]; return s; }
+  size_t mid = n / 2;
+  return pairwise_sum_f32(v, mid) + pairwise_sum_f32(v + mid, n - mid);
+}
+inline uint32_t f32_to_bits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
+inline float bits_to_f32(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+inline uint32_t kmer_hash(uint32_t key) { return (key * 0x9E3779B1u) >> 7; }
+
+inline bool build_kmer_tables(const ModelHost& m, KmerTables* t, std::string* err) {
+  if (m.kmer_size == 0 || m.kmer_size > 10) {
+    *err = "custom model: kmer_size must be 1..10 (a 3-bit code of more bases does not fit the model's u32 keys)";
+    return false;
+  }
+  // HashMap::from_iter over the list: a repeated key keeps its LAST entry
+  std::vector<size_t> last;
+  {
+    std::vector<std::pair<uint32_t, size_t>> order;
+    for (size_t i = 0; i < m.probabilities.size(); i++) order.emplace_back(m.probabilities[i].first, i);
+    std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (size_t i = 0; i < order.size(); i++)
+      if (i + 1 == order.size() || order[i + 1].first != order[i].first) last.push_back(order[i].second);
+  }
+  uint32_t n_slots = 16;
+  while ((uint64_t)n_slots < 2 * (uint64_t)last.size() + 1) n_slots <<= 1;
+  t->mask = n_slots - 1;
+  t->slots.assign(n_slots, Rec16{0xFFFFFFFFu, 0u, 0u, 0u});
+  t->recs.clear();
+  for (size_t e : last) {
+    const uint32_t key = m.probabilities[e].first;
+    const auto& alts = m.probabilities[e].second;
+    if (key == 0xFFFFFFFFu) continue;  // not the code of any k-mer of <= 10 bases
+    const uint32_t n = (uint32_t)alts.size();
+    Rec16 slot{key, (uint32_t)t->recs.size(), 0u, 0u};
+    // WeightedAliasIndex::<f32>::new: n == 0, a weight outside [0, f32::MAX / n] or a zero sum is an Err,
+    // which the reference unwraps (slot.z stays 0 = "panics when visited")
+    bool ok = n > 0;
+    std::vector<float> w(n);
+    for (uint32_t i = 0; i < n; i++) w[i] = alts[i].second;
+    const float maxw = n ? 3.40282347e38f / (float)n : 0.0f;
+    for (uint32_t i = 0; i < n && ok; i++) ok = (0.0f <= w[i]) && (w[i] <= maxw);
+    float wsum = 0.0f;
+    if (ok) {
+      wsum = pairwise_sum_f32(w.data(), n);
+      if (wsum > 3.40282347e38f) wsum = 3.40282347e38f;
+      ok = wsum != 0.0f;
+    }
+    if (ok) {
+      std::vector<float> odds(n);
+      std::vector<uint32_t> al(n, 0);
+      const float nf = (float)n;
+      for (uint32_t i = 0; i < n; i++) odds[i] = w[i] * nf;
+      uint32_t smalls = 0xFFFFFFFFu, bigs = 0xFFFFFFFFu;
+      for (uint32_t i = 0; i < n; i++) {
+        if (odds[i] < wsum) { al[i] = smalls; smalls = i; } else { al[i] = bigs; bigs = i; }
+      }
+      while (smalls != 0xFFFFFFFFu && bigs != 0xFFFFFFFFu) {
+        const uint32_t s = smalls; smalls = al[s];
+        const uint32_t g = bigs; bigs = al[g];
+        al[s] = g;
+        odds[g] = odds[g] - wsum + odds[s];
+        if (odds[g] < wsum) { al[g] = smalls; smalls = g; } else { al[g] = bigs; bigs = g; }
+      }
+      while (smalls != 0xFFFFFFFFu) { const uint32_t s = smalls; smalls = al[s]; odds[s] = wsum; }
+      while (bigs != 0xFFFFFFFFu) { const uint32_t g = bigs; bigs = al[g]; odds[g] = wsum; }
+      // Uniform::new(0.0f32, weight_sum): the scale is lowered until the largest draw stays below the sum
+      const float max_rand = bits_to_f32((0xFFFFFFFFu >> 9) | 0x3F800000u) - 1.0f;
+      float scale = wsum;
+      while (scale * max_rand + 0.0f >= wsum) scale = bits_to_f32(f32_to_bits(scale) - 1u);
+      slot.z = n;
+      slot.w = 0xFFFFFFFFu - (uint32_t)((0x100000000ULL - n) % n);  // Uniform::new(0u32, n)
+      // a column left on a stack keeps its link in al[] and odds == sum: its alias is never taken
+      for (uint32_t c = 0; c < n; c++)
+        t->recs.push_back(Rec16{f32_to_bits(odds[c]), alts[c].first, alts[al[c] < n ? al[c] : c].first, f32_to_bits(scale)});
+    }
+    uint32_t h = kmer_hash(key) & t->mask;
+    while (t->slots[h].x != 0xFFFFFFFFu) h = (h + 1) & t->mask;
+    t->slots[h] = slot;
+  }
+  if (t->recs.empty()) t->recs.push_back(Rec16{0u, 0u, 0u, 0u});
   return true;
 }
 

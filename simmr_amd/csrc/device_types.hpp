@@ -35,6 +35,7 @@ struct GenomeDev {
 
 #define SIMMR_K_CUSTOM 4u
 #define SIMMR_ERRBIT_FASTQ 8u /* a FASTQ header does not fit, or a genome / contig index has no name */
+#define SIMMR_ERRBIT_KMER 16u /* simulate_errors chose an alternate the reference cannot splice (deletion / bad code / bad weights) */
 #define SIMMR_ERRBIT_PDF 4u /* custom PDF picked a bin without a range (a reference panic) or ran out of words */
 
 // One CustomPDF entry (custom_short.rs:28-35): WeightedAliasIndex<f64> + per-bin Uniform<u32>,
@@ -60,6 +61,11 @@ struct CustomDev {
   const Rec16* bin_rec;  // {range, zone, low, -}
   uint32_t n_quality;
   uint32_t pad;
+  // simulate_errors (custom_short.rs:455-516), long reads only: open-addressing table over the 3-bit k-mer codes
+  const Rec16* kmer_slots;  // {key (~0 = empty), first record, n alternates (0 = the reference panics), Uniform(0, n) zone}
+  const Rec16* kmer_recs;   // per alias column c: {odds f32, alternate c, alternate alias(c), Uniform(0, sum) scale f32}
+  uint32_t kmer_mask;       // slots - 1
+  uint32_t kmer_size;
 };
 
 // Device form of simmr_error_profile, with host-derived constants.

@@ -89,7 +89,7 @@ struct simmr_engine {
   // long-read runs
   DevBuf d_runs, d_usable;
   // custom profile tables
-  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, c_colrec, c_binrec, ph_table;
+  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, c_colrec, c_binrec, c_kslots, c_krecs, ph_table;
   // FASTQ framing
   DevBuf fq_blob, fq_gid_off, fq_gid_len, fq_cbase, fq_ncontig, fq_coff, fq_clen, fq_len, fq_off;
   FqTemplate fq_tpl{};
@@ -252,10 +252,12 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
   ModelHost m;
   std::string err;
   if (!parse_model((const uint8_t*)p->custom_model, p->custom_model_bytes, &m, &err)) return e->fail(SIMMR_EINVAL, "%s", err.c_str());
-  // main.rs:30-33: a custom-short profile must not be a long-read model; simulate_errors (the k-mer
-  // splice of long reads, custom_short.rs:455-516) is not on the paired-end path and not built here
-  if (m.is_long || want_long)
+  // main.rs:30-33: a custom-short profile must not be a long-read model.  The long-read path takes the
+  // profile through is_long_read() (custom_short.rs:540-542, main.rs:180-186), i.e. only an is_long model.
+  if (m.is_long && !want_long)
     return e->fail(SIMMR_EINVAL, "You specified a custom short-read error profile but the provided error profile is for long reads");
+  if (!m.is_long && want_long)
+    return e->fail(SIMMR_EINVAL, "a short-read custom model was passed to the long-read path (is_long_read() is false)");
   if (m.quality.empty()) return e->fail(SIMMR_EINVAL, "custom model has no quality distributions");
   PdfTables t;
   if (!append_pdf(m.read_length_bins, &t, &err)) return e->fail(SIMMR_EINVAL, "%s", err.c_str());
@@ -277,6 +279,11 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
   }
   for (size_t i = 0; i < t.bin_low.size(); i++) binrec[i] = Rec16{t.bin_range[i], t.bin_zone[i], t.bin_low[i], 0u};
   if ((rc = upload_vec(e, e->c_colrec, colrec)) || (rc = upload_vec(e, e->c_binrec, binrec))) return rc;
+  KmerTables kt;
+  if (want_long) {  // simulate_errors only runs for long reads (simulate.rs:500)
+    if (!build_kmer_tables(m, &kt, &err)) return e->fail(SIMMR_ENOTSUP, "%s", err.c_str());
+    if ((rc = upload_vec(e, e->c_kslots, kt.slots)) || (rc = upload_vec(e, e->c_krecs, kt.recs))) return rc;
+  }
   if ((rc = sync_check(e, "custom table upload"))) return rc;  // the host vectors go out of scope
   ProfileDev d{};
   d.kind = SIMMR_K_CUSTOM;
@@ -293,6 +300,17 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
   d.custom.col_rec = e->c_colrec.as<Rec16>();
   d.custom.bin_rec = e->c_binrec.as<Rec16>();
   d.custom.n_quality = (uint32_t)m.quality.size();
+  if (want_long) {
+    // get_random_read_length (custom_short.rs:286-301): Normal::new(mean, std).unwrap() needs a finite std
+    if (!std::isfinite(m.read_length_std))
+      return e->fail(SIMMR_ERANGE, "custom model: read_length_std is not finite (Normal::new(..).unwrap() panics)");
+    d.read_length_std = m.read_length_std;
+    d.insert_size_std = m.read_length_mean;  // k_const_length reads the mean from this slot
+    d.custom.kmer_slots = e->c_kslots.as<Rec16>();
+    d.custom.kmer_recs = e->c_krecs.as<Rec16>();
+    d.custom.kmer_mask = kt.mask;
+    d.custom.kmer_size = (uint32_t)m.kmer_size;
+  }
   *out = d;
   return SIMMR_OK;
 }
@@ -649,7 +667,7 @@ void simmr_engine_destroy(simmr_engine* e) {
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_bytes, &e->u_qs2,
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
-                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->ph_table,
+                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->c_kslots, &e->c_krecs, &e->ph_table,
                     &e->fq_blob, &e->fq_gid_off, &e->fq_gid_len, &e->fq_cbase, &e->fq_ncontig, &e->fq_coff, &e->fq_clen,
                     &e->fq_len, &e->fq_off, &e->m_genomes, &e->m_contig, &e->m_seed};
   for (DevBuf* b : bufs) b->release();
@@ -1113,6 +1131,17 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                          e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
                          out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
+    } else if (e->prof.kind == SIMMR_K_CUSTOM && !paired) {
+      HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
+      bool exc = false;
+      for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
+      const uint64_t blocks = (n_reads + 255) / 256;
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
+      auto kern = exc ? k_emit_custom_long<true> : k_emit_custom_long<false>;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), n_units, pl,
+                         e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
+                         e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset, counters,
+                         e->d_err.as<uint32_t>());
     } else if (e->prof.kind == SIMMR_K_CUSTOM) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
       const uint64_t blocks = (n_reads + 255) / 256;
@@ -1166,6 +1195,9 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
     if ((rc = read_err_word(e, &errw))) return rc;
     if (errw & SIMMR_ERRBIT_PDF)
       return e->fail(SIMMR_ERANGE, "a custom quality PDF selected a density without a bin range (the reference panics: index out of bounds)");
+    if (errw & SIMMR_ERRBIT_KMER)
+      return e->fail(SIMMR_ERANGE, "simulate_errors chose an alternate k-mer with a deletion or an invalid code, or met unusable weights "
+                                   "(the reference panics, or returns fewer bases than qualities, custom_short.rs:475-509)");
   }
   return SIMMR_OK;
 }
@@ -1196,6 +1228,8 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   uint64_t first = std::min(shard.first, total_reads);
   uint64_t count = std::min(shard.count, total_reads - first);
   const bool per_read = !has_seed || profile->length_mode == SIMMR_LEN_PER_READ;
+  if (per_read && prof.kind == SIMMR_K_CUSTOM)
+    return e->fail(SIMMR_ENOTSUP, "a custom model on the long-read path needs a seed and SIMMR_LEN_REFERENCE (the per-read length extension draws from the gamma law)");
   if (!has_seed) seed = os_entropy_u64();
   if ((rc = ensure_plan_arrays(e, count, false, true))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_a, e->stream));

@@ -697,6 +697,13 @@ extern "C" __global__ void k_const_length(ProfileDev prof, uint64_t seed,
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   LaneRng rng;
   rng.seed_from_u64(seed, row);
+  if (prof.kind == SIMMR_K_CUSTOM) {
+    // custom_short.rs:286-301: get_random_read_length is Normal<f64>(read_length_mean, read_length_std),
+    // floor, `as u16` (the PDF only serves get_read_length); the model's values ride in read_length_std / insert_size_std
+    const double z = rng.standard_normal(T);
+    *out = sat_u16_f64(floor(__dadd_rn(prof.insert_size_std, __dmul_rn(prof.read_length_std, z))));
+    return;
+  }
   *out = sat_u16_f32(floorf(rng.gamma_f32(T, prof.gamma_shape, prof.gamma_scale)));
 }
 
@@ -2258,6 +2265,211 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
   }
   if ((threadIdx.x & 63u) == 0 && counters) {
     atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
+    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
+  }
+}
+
+// ===========================================================================
+// 9c. Emit: a custom model on the long-read path (simulate.rs:497-503 with
+//     CustomShortErrorProfile: simulate_phred_scores :332-353, simulate_errors
+//     :455-516, simulate_point_mutations = copy :522-529).
+//
+// One lane per read.  Qualities as in 9b; positions from n_quality - 1 on share
+// one PDF and one seed, i.e. one value, which is drawn once and stored 16 bytes
+// at a time.  simulate_errors walks the read k-mer by k-mer, each visited k-mer
+// replaced IN PLACE by an alternate before the next one is read, so k-mer i is
+// the last k - 1 bases of the alternate chosen at i - 1 plus source base
+// i + k - 1: the lane keeps that window as a 3-bit-per-base register, which is
+// also the model's key.  The reference's per-call HashMap and per-k-mer
+// WeightedAliasIndex<f32> are the precomputed tables of CustomDev (the host
+// builds them with the same f32 arithmetic); the draws come from the read's own
+// StdRng stream, one block at a time in the lane's LDS row.  An alternate with an
+// 'N' field is a deletion: the reference then panics on its next slice (or, at
+// the last k-mer, returns fewer bases than qualities), so the lane raises
+// SIMMR_ERRBIT_KMER instead.
+// ===========================================================================
+__device__ __attribute__((noinline)) void refill_words(const Key key, uint32_t blk, uint32_t* __restrict__ row) {
+  uint32_t o[16];
+  chacha12_block(key, (uint64_t)blk, o);
+#pragma unroll
+  for (int i = 0; i < 16; i++) row[i] = o[i];
+}
+
+template <bool HAS_EXC>
+__global__ void __launch_bounds__(256)
+k_emit_custom_long(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint64_t n_units, PlanArrays pl,
+                   const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
+                   const uint32_t* __restrict__ u_genome, const uint64_t* __restrict__ u_seed,
+                   uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_offset,
+                   unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
+  __shared__ uint32_t words[256][CUSTOM2_WORDS + 1];
+  __shared__ __attribute__((aligned(16))) uint8_t rings[256 * RING_PITCH];
+  const CustomDev C = prof.custom;
+  const uint32_t K = C.kmer_size;                    // 1..10 (checked on the host)
+  const uint32_t kmask = K >= 10u ? 0x3fffffffu : ((1u << (3u * K)) - 1u);
+  const uint32_t top = 3u * (K - 1u);
+  const uint32_t bit2 = 0x24924924u & kmask;         // bit 2 of every field: set for N (4) and '-' (5)
+  uint64_t qsum = 0;
+  uint32_t n_acgt = 0, n_subst = 0;
+  bool bad = false, bad_kmer = false;
+  const uint32_t qoff = qual_offset & 0xffu;
+  uint32_t* const row = words[threadIdx.x];
+  uint8_t* const my_ring = rings + threadIdx.x * RING_PITCH;
+  for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n_units; r0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t u = r0 + threadIdx.x;
+    uint32_t n = 0;
+    uint64_t off = 0, src0 = 0, seed = 0;
+    const uint32_t* packed = nullptr;
+    const uint32_t* mask = nullptr;
+    if (u < n_units) {
+      n = pl.len[u];
+      off = u_off[u];
+      const GenomeDev* G = genomes + u_genome[u];
+      packed = G->packed;
+      mask = (HAS_EXC && G->has_exc) ? G->mask : nullptr;
+      src0 = G->contigs[u_contig[u]].base + pl.a[u];
+      seed = u_seed[u];  // read_seed re-seeds every per-read generator (simulate.rs:497-503)
+    }
+    const Key key = pcg32_expand(seed);
+    uint32_t o[16];
+    chacha12_block(key, 0, o);
+#pragma unroll
+    for (int i = 0; i < 16; i++) row[i] = o[i];
+    // ---- simulate_phred_scores
+    {
+      const uint32_t w0 = o[0], w3 = o[3];
+      const double v01 = __longlong_as_double((long long)(((((uint64_t)o[2] << 32) | o[1]) >> 12) | 0x3FF0000000000000ULL)) - 1.0;
+      auto sample = [&](const PdfDev pdf) -> uint32_t {
+        const uint64_t m = (uint64_t)w0 * pdf.n;
+        uint32_t q = 0;
+        bool fast = (uint32_t)m <= pdf.idx_zone;
+        if (fast) {
+          const uint32_t col = (uint32_t)(m >> 32);
+          const Rec16 cr = C.col_rec[pdf.off + col];
+          const double odds = __longlong_as_double((long long)(((uint64_t)cr.y << 32) | cr.x));
+          const uint32_t bin = (__dmul_rn(v01, pdf.w_scale) < odds) ? col : cr.z;
+          fast = bin < pdf.n_bins;
+          if (fast) {
+            const Rec16 br = C.bin_rec[pdf.off_bins + bin];
+            const uint64_t m2 = (uint64_t)w3 * br.x;
+            if (br.x == 0) q = w3;
+            else if ((uint32_t)m2 <= br.y) q = br.z + (uint32_t)(m2 >> 32);
+            else fast = false;
+          }
+        }
+        if (!fast) {
+          bool ovf = false;
+          q = pdf_sample_words(row, CUSTOM2_WORDS, C, pdf, &bad, &ovf);
+          if (ovf) q = pdf_sample_stream(seed, C, pdf, &bad);
+        }
+        return q & 0xffu;  // `as u8`
+      };
+      uint32_t q_last = 0;  // the value of every position >= n_quality - 1 (custom_short.rs:339-350)
+      if (n >= C.n_quality) q_last = sample(C.pdfs[2 + C.n_quality - 1]);
+      const uint64_t fill = ((q_last + qoff) & 0xffu) * 0x0101010101010101ULL;
+      for (uint32_t b0 = 0; __any(b0 < n); b0 += 16) {
+        if (b0 >= n) continue;
+        const uint32_t cnt = (n - b0) < 16u ? (n - b0) : 16u;
+        uint64_t q_lo = fill, q_hi = fill;
+        if (b0 + 1u >= C.n_quality) {  // wave-uniform
+          qsum += (uint64_t)q_last * cnt;
+        } else {
+          q_lo = 0; q_hi = 0;
+          for (uint32_t j = 0; j < 16; j++) {
+            const uint32_t p = b0 + j;
+            const PdfDev pdf = C.pdfs[2 + (p < C.n_quality ? p : C.n_quality - 1)];
+            if (j >= cnt) continue;
+            const uint32_t q = sample(pdf);
+            qsum += q;
+            const uint64_t enc = (q + qoff) & 0xffu;
+            if (j < 8u) q_lo |= enc << (8u * j); else q_hi |= enc << (8u * (j - 8u));
+          }
+        }
+        uint8_t* qd = qual + off + b0;
+        if (cnt == 16u) {
+          *reinterpret_cast<u64_unaligned*>(qd) = q_lo;
+          *reinterpret_cast<u64_unaligned*>(qd + 8) = q_hi;
+        } else {
+          store_tail(qd, q_lo, q_hi, cnt);
+        }
+      }
+    }
+    // ---- simulate_errors
+    {
+      uint32_t wpos = 0, cur = 0;  // next word of StdRng(read_seed); block `cur` is in the row
+      auto next_word = [&]() -> uint32_t {
+        if ((wpos >> 4) != cur) { cur = wpos >> 4; refill_words(key, cur, row); }
+        return row[(wpos++) & 15u];
+      };
+      uint32_t creg = 0, ereg = 0;
+      auto src_code = [&](uint32_t sp) -> uint32_t {  // 3-bit code of source base sp: ACGT 0-3, N 4, '-' 5
+        if ((sp & 15u) == 0u) {
+          creg = fetch_codes16(packed, (int64_t)(src0 + sp));
+          if (HAS_EXC) ereg = mask ? fetch_mask16(mask, (int64_t)(src0 + sp)) : 0u;
+        }
+        uint32_t c = (creg >> (2u * (sp & 15u))) & 3u;
+        if (HAS_EXC && ((ereg >> (sp & 15u)) & 1u)) c = 4u + (c & 1u);
+        return c;
+      };
+      OutRing ring;
+      ring_init(ring, my_ring, seq + off, n, false);
+      uint32_t win = 0, owin = 0;  // bases i .. i+K-1 of the edited / the original sequence
+      for (uint32_t j = 0; j < K; j++) {
+        if (!__any(j < n)) break;
+        if (j < n) { const uint32_t c = src_code(j); win |= c << (3u * j); }
+      }
+      owin = win;
+      bool dead = false;  // after an error the lane only copies
+      for (uint32_t i = 0; __any(i < n); i++) {
+        if (i >= n) continue;
+        if (i + K <= n && !dead) {
+          // three_bit_encode_kmer fails on anything but ACGTN (encoding.rs:149-176): '-' has bits 2 and 0
+          const bool encodable = ((win & bit2) & (win << 2)) == 0u;
+          if (encodable) {
+            uint32_t h = ((win * 0x9E3779B1u) >> 7) & C.kmer_mask;
+            Rec16 slot = C.kmer_slots[h];
+            while (slot.x != win && slot.x != 0xFFFFFFFFu) { h = (h + 1u) & C.kmer_mask; slot = C.kmer_slots[h]; }
+            if (slot.x == win) {
+              if (slot.z == 0u) {
+                bad_kmer = true; dead = true;  // WeightedAliasIndex::new(..).unwrap() panics
+              } else {
+                uint32_t c;
+                for (;;) {  // uniform_index.sample
+                  const uint64_t m = (uint64_t)next_word() * slot.z;
+                  if ((uint32_t)m <= slot.w) { c = (uint32_t)(m >> 32); break; }
+                }
+                const Rec16 rec = C.kmer_recs[slot.y + c];
+                const float v12 = __uint_as_float((next_word() >> 9) | 0x3F800000u);
+                const float x = __fadd_rn(__fmul_rn(__fsub_rn(v12, 1.0f), __uint_as_float(rec.w)), 0.0f);
+                const uint32_t alt = (x < __uint_as_float(rec.x) ? rec.y : rec.z) & kmask;
+                if (alt & bit2) { bad_kmer = true; dead = true; }  // an N = a deletion, 5-7 = decode error
+                else win = alt;
+              }
+            }
+          }
+        }
+        const uint32_t code = win & 7u, ocode = owin & 7u;
+        n_acgt += ocode < 4u ? 1u : 0u;
+        n_subst += code != ocode ? 1u : 0u;
+        const uint32_t ch = code < 4u ? (0x54474341u >> (8u * code)) & 0xffu : (code == 4u ? 'N' : '-');
+        ring_put(ring, i, ch);
+        win >>= 3; owin >>= 3;
+        if (i + K < n) { const uint32_t c = src_code(i + K); win |= c << top; owin |= c << top; }
+        if ((i & 15u) == 15u) ring_flush_fwd(ring, i + 1u);
+      }
+      ring_flush_fwd(ring, n);
+    }
+  }
+  if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
+  if (bad_kmer) atomicOr(err, SIMMR_ERRBIT_KMER);
+  for (int d = 32; d > 0; d >>= 1) {
+    n_acgt += __shfl_down(n_acgt, d, 64);
+    n_subst += __shfl_down(n_subst, d, 64);
+    qsum += __shfl_down(qsum, d, 64);
+  }
+  if ((threadIdx.x & 63u) == 0 && counters) {
+    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
+    atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
     atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
   }
 }

@@ -152,7 +152,9 @@ class CustomShortErrorProfile(ErrorProfile):
         return p
 
     def is_long_read(self):
-        return False  # main.rs:30-33 refuses long-read models for custom-short
+        # custom_short.rs:540-542: the model's is_long flag, the last byte of the bincode struct
+        # (main.rs:30-33 refuses such a model for the custom-short CLI value; the library takes it on the long-read path)
+        return len(self.model) > 0 and self.model[-1] != 0
 
 
 # ---------------------------------------------------------------------------

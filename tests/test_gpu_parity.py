@@ -397,6 +397,99 @@ def test_custom_short_rejects_bad_models(engine, genome_multi):
     assert ei.value.code == _abi.ERANGE
 
 
+# custom model on the long-read path: empirical qualities + the k-mer splice of simulate_errors
+@pytest.mark.parametrize("k,seed,n_positions", [(7, 42, 300), (3, 7, 40), (10, 5, 5000), (1, 9, 10)])
+def test_custom_long_bit_exact(engine, oracle, genome_multi, genome_1m, k, seed, n_positions):
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    blob = _model.synthetic_long_model(kmer_size=k, n_positions=n_positions, seed=seed,
+                                       n_kmers=3000 if k >= 6 else 4 ** k)
+    prof = CustomShortErrorProfile(blob)
+    assert prof.is_long_read()
+    pod = prof.pod()
+    engine.stage_genome(4, genome_1m.contigs)
+    engine.counters_reset()
+    reads = [90, 0, 70]
+    dev = engine.simulate_long_reads([1, 4, 0], reads, pod, seed, read_id_base=11, qual_offset=33)
+    ora = _oracle.simulate_long(oracle, [genome_multi, genome_1m, genome_1m], reads, pod, seed, read_id_base=11,
+                                qual_offset=33)
+    d, o = dev.to_host(), ora.trimmed()
+    o["genome"] = np.array([1, 4, 0], dtype=np.uint32)[o["genome"]]
+    assert_same(d, o, cols=COLS + ("genome",))
+    # the splice really edits bases, and the counter says how many
+    g = {1: genome_multi, 0: genome_1m}
+    mism = 0
+    for r in range(len(d["start"])):
+        ref = g[int(d["genome"][r])].contigs[int(d["contig"][r])][int(d["start"][r]):int(d["end"][r])]
+        mism += int((d["seq"][d["seq_off"][r]:d["seq_off"][r + 1]] != ref).sum())
+    c = engine.counters()
+    assert c[_abi.CNT_SUBSTITUTIONS] == mism and (mism > 0 or k == 10)
+    assert c[_abi.CNT_QUAL_SUM] == ((d["qual"].astype(np.int64) - 33) % 256).sum()
+
+
+def test_custom_long_exceptions_and_sharding(engine, oracle):
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    rng = np.random.default_rng(21)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 60000)].copy()
+    seq[rng.integers(0, 60000, 1500)] = ord("N")
+    seq[rng.integers(0, 60000, 300)] = ord("-")
+    seq[30000:30050] = ord("N")
+    short = seq[:2500].copy()  # shorter than most drawn lengths: reads are re-cut at the sequence end
+    engine.stage_genome(3, [seq, short])
+    g = _oracle.HostGenome([seq, short])
+    pod = CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=4, n_positions=100, seed=2, n_kmers=256,
+                                                             lengths=(300, 2400, 50))).pod()
+    whole = _oracle.simulate_long(oracle, [g], [400], pod, 6).trimmed()
+    dev = engine.simulate_long_reads([3], [400], pod, 6)
+    d = dev.to_host()
+    whole["genome"][:] = 3
+    assert_same(d, whole, cols=COLS + ("genome",))
+    for first, count in [(0, 17), (123, 200), (399, 5)]:
+        part = engine.simulate_long_reads([3], [400], pod, 6, first=first, count=count).to_host()
+        n = min(count, 400 - first)
+        base = whole["seq_off"][first]
+        assert np.array_equal(part["seq_off"], whole["seq_off"][first:first + n + 1] - base)
+        assert np.array_equal(part["seq"], whole["seq"][base:whole["seq_off"][first + n]])
+        assert np.array_equal(part["qual"], whole["qual"][base:whole["seq_off"][first + n]])
+
+
+def test_custom_long_error_paths(engine, oracle, genome_multi):
+    from simmr_amd import CustomShortErrorProfile, SimmrError
+    from tests import _model
+    # a deletion: the reference panics on its next slice; both sides answer ERANGE
+    blob = _model.synthetic_long_model(kmer_size=5, n_positions=20, seed=1, n_kmers=100, deletion=True)
+    pod = CustomShortErrorProfile(blob).pod()
+    with pytest.raises(SimmrError) as ei:
+        engine.simulate_long_reads([1], [50], pod, 3)
+    assert ei.value.code == _abi.ERANGE and "simulate_errors" in ei.value.msg
+    with pytest.raises(RuntimeError) as oi:
+        _oracle.simulate_long(oracle, [genome_multi], [50], pod, 3)
+    assert f"oracle error {_abi.ERANGE}" in str(oi.value)
+    good = CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=5, n_positions=20, seed=1, n_kmers=100))
+    # the per-read length extension draws from the gamma law: not defined for a custom model
+    pr = good.pod()
+    pr.length_mode = _abi.LEN_PER_READ
+    with pytest.raises(SimmrError) as ei:
+        engine.long_plan([1], [10], pr, 3)
+    assert ei.value.code == _abi.ENOTSUP
+    # a short-read model has is_long_read() == false and never reaches simulate_long_reads
+    with pytest.raises(SimmrError) as ei:
+        engine.long_plan([1], [10], CustomShortErrorProfile(_model.synthetic_short_model()).pod(), 3)
+    assert ei.value.code == _abi.EINVAL
+    # a 3-bit code of 11 bases does not fit the model's u32 keys
+    with pytest.raises(SimmrError) as ei:
+        engine.long_plan([1], [10], CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=11, n_kmers=10)).pod(), 3)
+    assert ei.value.code == _abi.ENOTSUP
+    # weights WeightedAliasIndex::new refuses: the reference unwraps the Err when the k-mer is visited
+    probs = [(c, [(c, 0.0), (c ^ 1, 0.0)]) for c in range(4)]
+    zero = _model.serialize_model([([1.0], [(30, 30)])] * 3, ([1.0], [(700, 700)]), probabilities=probs, kmer_size=1,
+                                  read_length_mean=700.0, insert_size_mean=0.0, is_long=True)
+    with pytest.raises(SimmrError) as ei:
+        engine.simulate_long_reads([1], [5], CustomShortErrorProfile(zero).pod(), 3)
+    assert ei.value.code == _abi.ERANGE
+
+
 def test_error_paths(engine, genome_multi):
     from simmr_amd import SimmrError
     with pytest.raises(SimmrError) as ei:  # contig 2 (30 017) <= 2*20000+... required

@@ -86,3 +86,51 @@ def test_alias_sampler_distribution(lib):
     counts = np.bincount([lib.orc_alias_sample(a, C.byref(r)) for _ in range(n)], minlength=5)
     assert counts[1] == 0
     assert np.abs(counts / n - w).max() < 0.005
+
+
+def test_long_path_with_a_custom_model(oracle):
+    """simulate.rs:497-503 with CustomShortErrorProfile: qualities from the per-position PDFs (one value from
+    position n_quality - 1 on), then the k-mer splice, then an identity simulate_point_mutations.  With one
+    alternate per k-mer the splice needs no random choice, so a plain Python walk predicts it."""
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _synth
+    rng = np.random.default_rng(4)
+    k = 4
+    table = {}
+    probs = []
+    for idx in rng.choice(4 ** k, size=120, replace=False):
+        key = sum(((int(idx) >> (2 * j)) & 3) << (3 * j) for j in range(k))
+        alt = key ^ (int(rng.integers(1, 4)) << (3 * int(rng.integers(0, k))))
+        alt = sum((((alt >> (3 * j)) & 7) & 3) << (3 * j) for j in range(k))  # keep the fields in ACGT
+        probs.append((key, [(alt, 2.5)]))
+        table[key] = alt
+    quality = [([0.2, 0.5, 0.3], [(10 + p % 7, 12 + p % 7), (20, 20), (30, 33)]) for p in range(25)]
+    blob = _model.serialize_model(quality, ([1.0], [(900, 900)]), probabilities=probs, kmer_size=k,
+                                  read_length_mean=900.0, insert_size_mean=0.0, is_long=True)
+    prof = CustomShortErrorProfile(blob)
+    assert prof.is_long_read()
+    contigs = _synth.synthetic_contigs([5000, 1200], 3)
+    g = _oracle.HostGenome(contigs)
+    res = _oracle.simulate_long(oracle, [g], [60], prof.pod(), 11)
+    out = res.trimmed()
+    # one length for the run (simulate.rs:358): get_random_read_length = floor(N(read_length_mean, read_length_std))
+    assert out["seq_off"][-1] == out["seq"].size and 800 < res.const_len < 1000 and (np.diff(out["seq_off"]) <= res.const_len).all()
+    lut = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3}
+    for r in range(60):
+        s, e = int(out["start"][r]), int(out["end"][r])
+        seq = bytearray(contigs[int(out["contig"][r])][s:e].tobytes())
+        n = len(seq)
+        for i in range(n - k + 1):
+            key = sum(lut[seq[i + j]] << (3 * j) for j in range(k))
+            if key in table:
+                alt = table[key]
+                seq[i:i + k] = bytes(b"ACGT"[(alt >> (3 * j)) & 7] for j in range(k))
+        got = out["seq"][out["seq_off"][r]:out["seq_off"][r + 1]]
+        assert got.tobytes() == bytes(seq), r
+        q = out["qual"][out["seq_off"][r]:out["seq_off"][r + 1]]
+        assert (q[24:] == q[24]).all() and set(np.unique(q)) <= set(range(10, 34))
+    # the per-read length extension is not defined for a custom model
+    pod = prof.pod()
+    pod.length_mode = 1
+    with pytest.raises(RuntimeError):
+        _oracle.simulate_long(oracle, [g], [5], pod, 11)
