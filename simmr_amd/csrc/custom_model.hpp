@@ -170,11 +170,14 @@ inline bool append_pdf(const BinsHost& b, PdfTables* t, std::string* err) {
 
 // Tables for simulate_errors (custom_short.rs:455-516).  The reference rebuilds a HashMap of the model's
 // k-mer probabilities per call (:462-467) and a WeightedAliasIndex<f32> per visited k-mer (:497-499); both
-// depend on the model only, so they are built once here: an open-addressing table keyed by the 3-bit k-mer
-// code and, per entry, the alias columns with the alternates already resolved.
+// depend on the model only, so they are built once here.  A k-mer of ACGT only is looked up in a direct
+// table indexed by its 2-bit code (4^k entries); one with an N (three_bit_encode_kmer accepts it) in a small
+// open-addressing table keyed by the model's 3-bit code.  Per entry: the alias columns with the alternates
+// already resolved and packed to 2 bits per base (bit 31 = the alternate has an N or an invalid field).
 struct KmerTables {
-  std::vector<Rec16> slots;
-  std::vector<Rec16> recs;
+  std::vector<Rec16> direct;  // {first record, n alternates (0 = not in the model, ~0 = unusable weights), zone, -}
+  std::vector<Rec16> slots;   // {3-bit key (~0 = empty), first record, n alternates (~0 = unusable weights), zone}
+  std::vector<Rec16> recs;    // {odds f32, alternate c, alternate alias(c), Uniform(0, sum) scale f32}
   uint32_t mask = 0;
 };
 
@@ -192,6 +195,18 @@ inline bool build_kmer_tables(const ModelHost& m, KmerTables* t, std::string* er
     *err = "custom model: kmer_size must be 1..10 (a 3-bit code of more bases does not fit the model's u32 keys)";
     return false;
   }
+  const uint32_t K = (uint32_t)m.kmer_size;
+  const uint32_t kmask = K >= 10 ? 0x3fffffffu : ((1u << (3 * K)) - 1u);
+  // 3-bit code -> 2 bits per base; bit 31 if a field is not ACGT
+  auto pack2 = [&](uint32_t code3) {
+    uint32_t v = 0;
+    for (uint32_t j = 0; j < K; j++) {
+      const uint32_t f = (code3 >> (3 * j)) & 7u;
+      if (f >= 4) v |= 0x80000000u;
+      v |= (f & 3u) << (2 * j);
+    }
+    return v;
+  };
   // HashMap::from_iter over the list: a repeated key keeps its LAST entry
   std::vector<size_t> last;
   {
@@ -201,19 +216,29 @@ inline bool build_kmer_tables(const ModelHost& m, KmerTables* t, std::string* er
     for (size_t i = 0; i < order.size(); i++)
       if (i + 1 == order.size() || order[i + 1].first != order[i].first) last.push_back(order[i].second);
   }
+  size_t n_hashed = 0;
+  for (size_t e : last) {
+    const uint32_t key = m.probabilities[e].first;
+    if (key <= kmask && (pack2(key) & 0x80000000u)) n_hashed++;
+  }
   uint32_t n_slots = 16;
-  while ((uint64_t)n_slots < 2 * (uint64_t)last.size() + 1) n_slots <<= 1;
+  while ((uint64_t)n_slots < 2 * (uint64_t)n_hashed + 1) n_slots <<= 1;
   t->mask = n_slots - 1;
   t->slots.assign(n_slots, Rec16{0xFFFFFFFFu, 0u, 0u, 0u});
+  t->direct.assign((size_t)1 << (2 * K), Rec16{0u, 0u, 0u, 0u});
   t->recs.clear();
   for (size_t e : last) {
     const uint32_t key = m.probabilities[e].first;
+    if (key > kmask) continue;  // not the code of any k-mer of this size
+    bool window_can_hold = true;  // a window only ever holds A, C, G, T, N when it is encodable
+    for (uint32_t j = 0; j < K; j++) window_can_hold = window_can_hold && ((key >> (3 * j)) & 7u) <= 4u;
+    if (!window_can_hold) continue;
     const auto& alts = m.probabilities[e].second;
-    if (key == 0xFFFFFFFFu) continue;  // not the code of any k-mer of <= 10 bases
     const uint32_t n = (uint32_t)alts.size();
-    Rec16 slot{key, (uint32_t)t->recs.size(), 0u, 0u};
+    const uint32_t first = (uint32_t)t->recs.size();
+    uint32_t n_field = 0xFFFFFFFFu, zone = 0;
     // WeightedAliasIndex::<f32>::new: n == 0, a weight outside [0, f32::MAX / n] or a zero sum is an Err,
-    // which the reference unwraps (slot.z stays 0 = "panics when visited")
+    // which the reference unwraps: n_field stays ~0 = "panics when visited"
     bool ok = n > 0;
     std::vector<float> w(n);
     for (uint32_t i = 0; i < n; i++) w[i] = alts[i].second;
@@ -247,15 +272,21 @@ inline bool build_kmer_tables(const ModelHost& m, KmerTables* t, std::string* er
       const float max_rand = bits_to_f32((0xFFFFFFFFu >> 9) | 0x3F800000u) - 1.0f;
       float scale = wsum;
       while (scale * max_rand + 0.0f >= wsum) scale = bits_to_f32(f32_to_bits(scale) - 1u);
-      slot.z = n;
-      slot.w = 0xFFFFFFFFu - (uint32_t)((0x100000000ULL - n) % n);  // Uniform::new(0u32, n)
+      n_field = n;
+      zone = 0xFFFFFFFFu - (uint32_t)((0x100000000ULL - n) % n);  // Uniform::new(0u32, n)
       // a column left on a stack keeps its link in al[] and odds == sum: its alias is never taken
       for (uint32_t c = 0; c < n; c++)
-        t->recs.push_back(Rec16{f32_to_bits(odds[c]), alts[c].first, alts[al[c] < n ? al[c] : c].first, f32_to_bits(scale)});
+        t->recs.push_back(Rec16{f32_to_bits(odds[c]), pack2(alts[c].first & kmask),
+                                pack2(alts[al[c] < n ? al[c] : c].first & kmask), f32_to_bits(scale)});
     }
-    uint32_t h = kmer_hash(key) & t->mask;
-    while (t->slots[h].x != 0xFFFFFFFFu) h = (h + 1) & t->mask;
-    t->slots[h] = slot;
+    const uint32_t p2 = pack2(key);
+    if (!(p2 & 0x80000000u)) {
+      t->direct[p2] = Rec16{first, n_field, zone, 0u};
+    } else {
+      uint32_t h = kmer_hash(key) & t->mask;
+      while (t->slots[h].x != 0xFFFFFFFFu) h = (h + 1) & t->mask;
+      t->slots[h] = Rec16{key, first, n_field, zone};
+    }
   }
   if (t->recs.empty()) t->recs.push_back(Rec16{0u, 0u, 0u, 0u});
   return true;

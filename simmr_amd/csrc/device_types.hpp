@@ -61,9 +61,10 @@ struct CustomDev {
   const Rec16* bin_rec;  // {range, zone, low, -}
   uint32_t n_quality;
   uint32_t pad;
-  // simulate_errors (custom_short.rs:455-516), long reads only: open-addressing table over the 3-bit k-mer codes
-  const Rec16* kmer_slots;  // {key (~0 = empty), first record, n alternates (0 = the reference panics), Uniform(0, n) zone}
-  const Rec16* kmer_recs;   // per alias column c: {odds f32, alternate c, alternate alias(c), Uniform(0, sum) scale f32}
+  // simulate_errors (custom_short.rs:455-516), long reads only
+  const Rec16* kmer_direct;  // by 2-bit k-mer code: {first record, n alternates (0 = absent, ~0 = the reference panics), Uniform(0, n) zone, -}
+  const Rec16* kmer_slots;   // k-mers with an N, open addressing by 3-bit code: {key (~0 = empty), first record, n (~0 = panics), zone}
+  const Rec16* kmer_recs;    // per alias column c: {odds f32, alternate c, alternate alias(c) (2 bits per base, bit 31 = not ACGT), scale f32}
   uint32_t kmer_mask;       // slots - 1
   uint32_t kmer_size;
 };

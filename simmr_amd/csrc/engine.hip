@@ -89,7 +89,7 @@ struct simmr_engine {
   // long-read runs
   DevBuf d_runs, d_usable;
   // custom profile tables
-  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, c_colrec, c_binrec, c_kslots, c_krecs, ph_table;
+  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, c_colrec, c_binrec, c_kslots, c_krecs, c_kdirect, ph_table;
   // FASTQ framing
   DevBuf fq_blob, fq_gid_off, fq_gid_len, fq_cbase, fq_ncontig, fq_coff, fq_clen, fq_len, fq_off;
   FqTemplate fq_tpl{};
@@ -282,7 +282,9 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
   KmerTables kt;
   if (want_long) {  // simulate_errors only runs for long reads (simulate.rs:500)
     if (!build_kmer_tables(m, &kt, &err)) return e->fail(SIMMR_ENOTSUP, "%s", err.c_str());
-    if ((rc = upload_vec(e, e->c_kslots, kt.slots)) || (rc = upload_vec(e, e->c_krecs, kt.recs))) return rc;
+    if ((rc = upload_vec(e, e->c_kslots, kt.slots)) || (rc = upload_vec(e, e->c_krecs, kt.recs)) ||
+        (rc = upload_vec(e, e->c_kdirect, kt.direct)))
+      return rc;
   }
   if ((rc = sync_check(e, "custom table upload"))) return rc;  // the host vectors go out of scope
   ProfileDev d{};
@@ -306,6 +308,7 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
       return e->fail(SIMMR_ERANGE, "custom model: read_length_std is not finite (Normal::new(..).unwrap() panics)");
     d.read_length_std = m.read_length_std;
     d.insert_size_std = m.read_length_mean;  // k_const_length reads the mean from this slot
+    d.custom.kmer_direct = e->c_kdirect.as<Rec16>();
     d.custom.kmer_slots = e->c_kslots.as<Rec16>();
     d.custom.kmer_recs = e->c_krecs.as<Rec16>();
     d.custom.kmer_mask = kt.mask;
@@ -667,7 +670,7 @@ void simmr_engine_destroy(simmr_engine* e) {
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_bytes, &e->u_qs2,
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
-                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->c_kslots, &e->c_krecs, &e->ph_table,
+                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->c_kslots, &e->c_krecs, &e->c_kdirect, &e->ph_table,
                     &e->fq_blob, &e->fq_gid_off, &e->fq_gid_len, &e->fq_cbase, &e->fq_ncontig, &e->fq_coff, &e->fq_clen,
                     &e->fq_len, &e->fq_off, &e->m_genomes, &e->m_contig, &e->m_seed};
   for (DevBuf* b : bufs) b->release();
@@ -1137,11 +1140,13 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
       const uint64_t blocks = (n_reads + 255) / 256;
       const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
-      auto kern = exc ? k_emit_custom_long<true> : k_emit_custom_long<false>;
+      hipLaunchKernelGGL(k_custom_long_qual, dim3(grid), dim3(256), 0, e->stream, e->prof, n_units, pl,
+                         e->u_off.as<uint64_t>(), e->u_seed.as<uint64_t>(), out->qual, out->qual_offset, counters,
+                         e->d_err.as<uint32_t>());
+      auto kern = exc ? k_custom_long_splice<true> : k_custom_long_splice<false>;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), n_units, pl,
                          e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
-                         e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset, counters,
-                         e->d_err.as<uint32_t>());
+                         e->u_seed.as<uint64_t>(), out->seq, counters, e->d_err.as<uint32_t>());
     } else if (e->prof.kind == SIMMR_K_CUSTOM) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
       const uint64_t blocks = (n_reads + 255) / 256;

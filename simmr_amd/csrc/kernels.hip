@@ -2274,15 +2274,18 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
 //     CustomShortErrorProfile: simulate_phred_scores :332-353, simulate_errors
 //     :455-516, simulate_point_mutations = copy :522-529).
 //
-// One lane per read.  Qualities as in 9b; positions from n_quality - 1 on share
+// Two kernels, one lane per read each (k_custom_long_qual, k_custom_long_splice: the splice then
+// fits 70 VGPRs).  Qualities as in 9b; positions from n_quality - 1 on share
 // one PDF and one seed, i.e. one value, which is drawn once and stored 16 bytes
 // at a time.  simulate_errors walks the read k-mer by k-mer, each visited k-mer
 // replaced IN PLACE by an alternate before the next one is read, so k-mer i is
 // the last k - 1 bases of the alternate chosen at i - 1 plus source base
-// i + k - 1: the lane keeps that window as a 3-bit-per-base register, which is
-// also the model's key.  The reference's per-call HashMap and per-k-mer
-// WeightedAliasIndex<f32> are the precomputed tables of CustomDev (the host
-// builds them with the same f32 arithmetic); the draws come from the read's own
+// i + k - 1: the lane keeps that window in a register (2 bits per base plus a
+// flag bit per base for N and for '-') and shifts one source base in per step.
+// The reference's per-call HashMap and per-k-mer WeightedAliasIndex<f32> are
+// the precomputed tables of CustomDev (the host builds them with the same f32
+// arithmetic): a k-mer of ACGT indexes a direct table with its window value,
+// one with an N probes a small hash table; the draws come from the read's own
 // StdRng stream, one block at a time in the lane's LDS row.  An alternate with an
 // 'N' field is a deletion: the reference then panics on its next slice (or, at
 // the last k-mer, returns fewer bases than qualities), so the lane raises
@@ -2295,44 +2298,24 @@ __device__ __attribute__((noinline)) void refill_words(const Key key, uint32_t b
   for (int i = 0; i < 16; i++) row[i] = o[i];
 }
 
-template <bool HAS_EXC>
-__global__ void __launch_bounds__(256)
-k_emit_custom_long(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint64_t n_units, PlanArrays pl,
-                   const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
-                   const uint32_t* __restrict__ u_genome, const uint64_t* __restrict__ u_seed,
-                   uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_offset,
+// qualities of the long reads (simulate_phred_scores, custom_short.rs:332-353): one lane per read
+extern "C" __global__ void __launch_bounds__(256)
+k_custom_long_qual(ProfileDev prof, uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
+                   const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ qual, uint32_t qual_offset,
                    unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
   __shared__ uint32_t words[256][CUSTOM2_WORDS + 1];
-  __shared__ __attribute__((aligned(16))) uint8_t rings[256 * RING_PITCH];
   const CustomDev C = prof.custom;
-  const uint32_t K = C.kmer_size;                    // 1..10 (checked on the host)
-  const uint32_t kmask = K >= 10u ? 0x3fffffffu : ((1u << (3u * K)) - 1u);
-  const uint32_t top = 3u * (K - 1u);
-  const uint32_t bit2 = 0x24924924u & kmask;         // bit 2 of every field: set for N (4) and '-' (5)
   uint64_t qsum = 0;
-  uint32_t n_acgt = 0, n_subst = 0;
-  bool bad = false, bad_kmer = false;
+  bool bad = false;
   const uint32_t qoff = qual_offset & 0xffu;
   uint32_t* const row = words[threadIdx.x];
-  uint8_t* const my_ring = rings + threadIdx.x * RING_PITCH;
   for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n_units; r0 += (uint64_t)gridDim.x * 256) {
     const uint64_t u = r0 + threadIdx.x;
     uint32_t n = 0;
-    uint64_t off = 0, src0 = 0, seed = 0;
-    const uint32_t* packed = nullptr;
-    const uint32_t* mask = nullptr;
-    if (u < n_units) {
-      n = pl.len[u];
-      off = u_off[u];
-      const GenomeDev* G = genomes + u_genome[u];
-      packed = G->packed;
-      mask = (HAS_EXC && G->has_exc) ? G->mask : nullptr;
-      src0 = G->contigs[u_contig[u]].base + pl.a[u];
-      seed = u_seed[u];  // read_seed re-seeds every per-read generator (simulate.rs:497-503)
-    }
-    const Key key = pcg32_expand(seed);
+    uint64_t off = 0, seed = 0;
+    if (u < n_units) { n = pl.len[u]; off = u_off[u]; seed = u_seed[u]; }  // read_seed (simulate.rs:497)
     uint32_t o[16];
-    chacha12_block(key, 0, o);
+    chacha12_block(pcg32_expand(seed), 0, o);
 #pragma unroll
     for (int i = 0; i < 16; i++) row[i] = o[i];
     // ---- simulate_phred_scores
@@ -2394,15 +2377,57 @@ k_emit_custom_long(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint6
         }
       }
     }
+  }
+  if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
+  for (int d = 32; d > 0; d >>= 1) qsum += __shfl_down(qsum, d, 64);
+  if ((threadIdx.x & 63u) == 0 && counters) atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
+}
+
+// bases of the long reads (simulate_errors, custom_short.rs:455-516): one lane per read
+template <bool HAS_EXC>
+__global__ void __launch_bounds__(256)
+k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint64_t n_units, PlanArrays pl,
+                     const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
+                     const uint32_t* __restrict__ u_genome, const uint64_t* __restrict__ u_seed,
+                     uint8_t* __restrict__ seq, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
+  __shared__ uint32_t words[256][33];  // per lane: two blocks of its stream
+  const CustomDev C = prof.custom;
+  const uint32_t K = C.kmer_size;  // 1..10 (checked on the host)
+  uint32_t n_acgt = 0, n_subst = 0;
+  bool bad_kmer = false;
+  uint32_t* const row = words[threadIdx.x];
+  for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n_units; r0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t u = r0 + threadIdx.x;
+    uint32_t n = 0;
+    uint64_t off = 0, src0 = 0, seed = 0;
+    const uint32_t* packed = nullptr;
+    const uint32_t* mask = nullptr;
+    if (u < n_units) {
+      n = pl.len[u];
+      off = u_off[u];
+      const GenomeDev* G = genomes + u_genome[u];
+      packed = G->packed;
+      mask = (HAS_EXC && G->has_exc) ? G->mask : nullptr;
+      src0 = G->contigs[u_contig[u]].base + pl.a[u];
+      seed = u_seed[u];  // read_seed re-seeds every per-read generator (simulate.rs:497-503)
+    }
+    const Key key = pcg32_expand(seed);
+    refill_words(key, 0, row);
     // ---- simulate_errors
     {
-      uint32_t wpos = 0, cur = 0;  // next word of StdRng(read_seed); block `cur` is in the row
+      // StdRng(read_seed): the row holds two blocks of the stream, block b at words (b & 1) * 16.  Every 8
+      // steps all lanes that are about to run out generate their next block TOGETHER (a step takes two
+      // words, so lanes that drifted apart still refill in the same call); a lane that needs more in
+      // between (rejected draws) generates on its own.
+      uint32_t wpos = 0, have = 1;  // next word; blocks [0, have) were generated
       auto next_word = [&]() -> uint32_t {
-        if ((wpos >> 4) != cur) { cur = wpos >> 4; refill_words(key, cur, row); }
-        return row[(wpos++) & 15u];
+        if ((wpos >> 4) >= have) { refill_words(key, have, row + (have & 1u) * 16u); have++; }
+        const uint32_t w = row[wpos & 31u];
+        wpos++;
+        return w;
       };
       uint32_t creg = 0, ereg = 0;
-      auto src_code = [&](uint32_t sp) -> uint32_t {  // 3-bit code of source base sp: ACGT 0-3, N 4, '-' 5
+      auto src_code = [&](uint32_t sp) -> uint32_t {  // source base sp: ACGT 0-3, N 4, '-' 5
         if ((sp & 15u) == 0u) {
           creg = fetch_codes16(packed, (int64_t)(src0 + sp));
           if (HAS_EXC) ereg = mask ? fetch_mask16(mask, (int64_t)(src0 + sp)) : 0u;
@@ -2411,66 +2436,104 @@ k_emit_custom_long(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint6
         if (HAS_EXC && ((ereg >> (sp & 15u)) & 1u)) c = 4u + (c & 1u);
         return c;
       };
-      OutRing ring;
-      ring_init(ring, my_ring, seq + off, n, false);
-      uint32_t win = 0, owin = 0;  // bases i .. i+K-1 of the edited / the original sequence
+      // bases i .. i+K-1 of the edited sequence: 2 bits per base plus one flag bit per base for N and for '-';
+      // owin / oexc: the same positions of the original (for the counters)
+      uint32_t win = 0, nm = 0, dm = 0, owin = 0, oexc = 0;
       for (uint32_t j = 0; j < K; j++) {
         if (!__any(j < n)) break;
-        if (j < n) { const uint32_t c = src_code(j); win |= c << (3u * j); }
+        if (j < n) {
+          const uint32_t c = src_code(j);
+          win |= (c < 4u ? c : 0u) << (2u * j);
+          if (HAS_EXC) { nm |= (c == 4u ? 1u : 0u) << j; dm |= (c == 5u ? 1u : 0u) << j; }
+        }
       }
-      owin = win;
+      owin = win; oexc = nm | dm;
       bool dead = false;  // after an error the lane only copies
+      uint64_t acc_lo = 0, acc_hi = 0;  // 16 output bases
+      uint8_t* const sd = seq + off;
       for (uint32_t i = 0; __any(i < n); i++) {
-        if (i >= n) continue;
-        if (i + K <= n && !dead) {
-          // three_bit_encode_kmer fails on anything but ACGTN (encoding.rs:149-176): '-' has bits 2 and 0
-          const bool encodable = ((win & bit2) & (win << 2)) == 0u;
-          if (encodable) {
-            uint32_t h = ((win * 0x9E3779B1u) >> 7) & C.kmer_mask;
-            Rec16 slot = C.kmer_slots[h];
-            while (slot.x != win && slot.x != 0xFFFFFFFFu) { h = (h + 1u) & C.kmer_mask; slot = C.kmer_slots[h]; }
-            if (slot.x == win) {
-              if (slot.z == 0u) {
-                bad_kmer = true; dead = true;  // WeightedAliasIndex::new(..).unwrap() panics
-              } else {
-                uint32_t c;
-                for (;;) {  // uniform_index.sample
-                  const uint64_t m = (uint64_t)next_word() * slot.z;
-                  if ((uint32_t)m <= slot.w) { c = (uint32_t)(m >> 32); break; }
-                }
-                const Rec16 rec = C.kmer_recs[slot.y + c];
-                const float v12 = __uint_as_float((next_word() >> 9) | 0x3F800000u);
-                const float x = __fadd_rn(__fmul_rn(__fsub_rn(v12, 1.0f), __uint_as_float(rec.w)), 0.0f);
-                const uint32_t alt = (x < __uint_as_float(rec.x) ? rec.y : rec.z) & kmask;
-                if (alt & bit2) { bad_kmer = true; dead = true; }  // an N = a deletion, 5-7 = decode error
-                else win = alt;
-              }
-            }
+        if ((i & 7u) == 0u) {
+          const bool need = i < n && have < (wpos >> 4) + 2u;
+          if (__any(need)) {
+            if (need) { refill_words(key, have, row + (have & 1u) * 16u); have++; }
           }
         }
-        const uint32_t code = win & 7u, ocode = owin & 7u;
-        n_acgt += ocode < 4u ? 1u : 0u;
-        n_subst += code != ocode ? 1u : 0u;
-        const uint32_t ch = code < 4u ? (0x54474341u >> (8u * code)) & 0xffu : (code == 4u ? 'N' : '-');
-        ring_put(ring, i, ch);
-        win >>= 3; owin >>= 3;
-        if (i + K < n) { const uint32_t c = src_code(i + K); win |= c << top; owin |= c << top; }
-        if ((i & 15u) == 15u) ring_flush_fwd(ring, i + 1u);
+        if (i >= n) continue;
+        // three_bit_encode_kmer fails on anything but ACGTN (encoding.rs:149-176): a '-' skips the k-mer
+        if (i + K <= n && !dead && (!HAS_EXC || dm == 0u)) {
+          uint32_t first = 0, cnt = 0, zone = 0;
+          if (!HAS_EXC || nm == 0u) {
+            const Rec16 d = C.kmer_direct[win];
+            first = d.x; cnt = d.y; zone = d.z;
+          } else {
+            uint32_t key3 = 0;  // the model's code of a k-mer with an N
+            for (uint32_t j = 0; j < K; j++)
+              key3 |= (((nm >> j) & 1u) ? 4u : ((win >> (2u * j)) & 3u)) << (3u * j);
+            uint32_t h = ((key3 * 0x9E3779B1u) >> 7) & C.kmer_mask;
+            Rec16 slot = C.kmer_slots[h];
+            while (slot.x != key3 && slot.x != 0xFFFFFFFFu) { h = (h + 1u) & C.kmer_mask; slot = C.kmer_slots[h]; }
+            if (slot.x == key3) { first = slot.y; cnt = slot.z; zone = slot.w; }
+          }
+          if (cnt == 0xFFFFFFFFu) {
+            bad_kmer = true; dead = true;  // WeightedAliasIndex::new(..).unwrap() panics
+          } else if (cnt != 0u) {
+            uint32_t c;
+            for (;;) {  // uniform_index.sample
+              const uint64_t m = (uint64_t)next_word() * cnt;
+              if ((uint32_t)m <= zone) { c = (uint32_t)(m >> 32); break; }
+            }
+            const Rec16 rec = C.kmer_recs[first + c];
+            const float v12 = __uint_as_float((next_word() >> 9) | 0x3F800000u);
+            const float x = __fadd_rn(__fmul_rn(__fsub_rn(v12, 1.0f), __uint_as_float(rec.w)), 0.0f);
+            const uint32_t alt = x < __uint_as_float(rec.x) ? rec.y : rec.z;
+            if (alt & 0x80000000u) { bad_kmer = true; dead = true; }  // an N = a deletion, 5-7 = decode error
+            else { win = alt; nm = 0u; }
+          }
+        }
+        const uint32_t code = win & 3u, ocode = owin & 3u;
+        uint32_t ch = (0x54474341u >> (8u * code)) & 0xffu;
+        bool differs = code != ocode;
+        if (HAS_EXC) {
+          const uint32_t en = nm & 1u, ed = dm & 1u, oe = oexc & 1u;
+          if (en) ch = 'N';
+          if (ed) ch = '-';
+          differs = (en | ed) ? false : (oe != 0u || code != ocode);  // an exception is only ever replaced, never created
+          n_acgt += oe ? 0u : 1u;
+        } else {
+          n_acgt++;
+        }
+        n_subst += differs ? 1u : 0u;
+        const uint64_t put = (uint64_t)ch << (8u * (i & 7u));
+        if (i & 8u) acc_hi |= put; else acc_lo |= put;
+        win >>= 2; owin >>= 2;
+        if (HAS_EXC) { nm >>= 1; dm >>= 1; oexc >>= 1; }
+        if (i + K < n) {
+          const uint32_t c = src_code(i + K);
+          const uint32_t c2 = c < 4u ? c : 0u;
+          win |= c2 << (2u * (K - 1u)); owin |= c2 << (2u * (K - 1u));
+          if (HAS_EXC) {
+            nm |= (c == 4u ? 1u : 0u) << (K - 1u); dm |= (c == 5u ? 1u : 0u) << (K - 1u);
+            oexc |= (c >= 4u ? 1u : 0u) << (K - 1u);
+          }
+        }
+        if ((i & 15u) == 15u) {
+          *reinterpret_cast<u64_unaligned*>(sd + (i - 15u)) = acc_lo;
+          *reinterpret_cast<u64_unaligned*>(sd + (i - 7u)) = acc_hi;
+          acc_lo = 0; acc_hi = 0;
+        } else if (i + 1u == n) {
+          store_tail(sd + (i & ~15u), acc_lo, acc_hi, (i & 15u) + 1u);
+        }
       }
-      ring_flush_fwd(ring, n);
     }
   }
-  if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
   if (bad_kmer) atomicOr(err, SIMMR_ERRBIT_KMER);
   for (int d = 32; d > 0; d >>= 1) {
     n_acgt += __shfl_down(n_acgt, d, 64);
     n_subst += __shfl_down(n_subst, d, 64);
-    qsum += __shfl_down(qsum, d, 64);
   }
   if ((threadIdx.x & 63u) == 0 && counters) {
     atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
     atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
-    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
   }
 }
 
