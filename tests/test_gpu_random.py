@@ -96,3 +96,51 @@ def test_random_multi_genome_plans(engine, oracle):
         assert np.array_equal(d["qual"], whole["qual"][int(off[a]):int(off[b])]), it
         n_ok += 1
     assert n_ok == 60
+
+
+def test_random_custom_long_models(engine, oracle):
+    """Random long-read models (k-mer size, sparsity of the k-mer table, modelled positions, length law) on random
+    genomes with N / '-' runs: qualities and the k-mer splice against the oracle; a refusal must be mutual."""
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    rng = np.random.default_rng(99)
+    SLOT = 31
+    n_ok = n_refused = 0
+    for it in range(40):
+        k = int(rng.integers(1, 9))
+        n_kmers = int(min(4 ** k, rng.choice([4, 60, 1000, 20000])))
+        lo = int(rng.integers(50, 800)); hi = lo + int(rng.integers(200, 3000))
+        blob = _model.synthetic_long_model(kmer_size=k, n_positions=int(rng.integers(1, 1500)), seed=int(rng.integers(0, 1 << 30)),
+                                           n_kmers=n_kmers, lengths=(lo, hi, 50), deletion=(it % 8 == 3))
+        prof = CustomShortErrorProfile(blob)
+        pod = prof.pod()
+        nc = int(rng.integers(1, 4))
+        lens = [int(rng.integers(hi + 500, 30_000)) for _ in range(nc)]
+        contigs = _synth.synthetic_contigs(lens, int(rng.integers(1, 1 << 30)))
+        if rng.random() < 0.5:
+            c = contigs[0].copy()
+            c[rng.integers(0, c.size, c.size // 15)] = ord("N")
+            c[rng.integers(0, c.size, 20)] = ord("-")
+            s = int(rng.integers(0, c.size - 40)); c[s:s + 30] = ord("N")
+            contigs[0] = c
+        engine.stage_genome(SLOT, contigs)
+        host = _oracle.HostGenome(contigs)
+        seed = int(rng.integers(0, 1 << 62)); qoff = int(rng.choice([0, 33]))
+        reads = int(rng.integers(1, 200)); first = int(rng.integers(0, reads)); count = int(rng.integers(1, 150))
+        dev = ora = None
+        try:
+            ora = _oracle.simulate_long(oracle, [host], [reads], pod, seed, first=first, count=count, read_id_base=5, qual_offset=qoff)
+        except RuntimeError:
+            pass
+        try:
+            dev = engine.simulate_long_reads([SLOT], [reads], pod, seed, first=first, count=count, read_id_base=5, qual_offset=qoff)
+        except SimmrError:
+            pass
+        assert (dev is None) == (ora is None), f"it{it}: device {'refused' if dev is None else 'ran'}, oracle {'refused' if ora is None else 'ran'}"
+        if dev is None:
+            n_refused += 1
+            continue
+        o = ora.trimmed(); o["genome"][:] = SLOT
+        assert_same(dev.to_host(), o, cols=("seq_off", "start", "end", "contig", "read_id", "flags", "qual", "seq", "genome"), what=f"it{it} k{k} ")
+        n_ok += 1
+    assert n_ok >= 25 and n_refused >= 3
