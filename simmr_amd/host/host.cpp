@@ -376,6 +376,8 @@ std::string usage() {
          "  --insert-size <N>             Insert size for PE reads (nt) [default: 150]\n"
          "  --mean-phred-score <N>        Average Phred quality score [default: 30]\n"
          "  --error-profile <P>           minimal-short | minimal-long | perfect-short | perfect-long | custom-short [default: perfect-short]\n"
+         "                                (extension: custom-long = a simmrd long-read model through the long-read path,\n"
+         "                                 which the reference's own enum cannot select, cli.rs:62-70)\n"
          "  --abundance-profile <P>       exact | uniform | custom [default: uniform]\n"
          "  --custom-profile <FILE>       Filepath to a custom error profile (simmrd model) for custom-short\n"
          "  --with-ani <N>                [not implemented, as in the reference]\n"
@@ -426,6 +428,7 @@ bool parse_cli_args(int argc, const char* const* argv, CliArgs* a, std::string* 
       else if (v == "perfect-short") a->error_profile = ErrorProfileKind::PerfectShort;
       else if (v == "perfect-long") a->error_profile = ErrorProfileKind::PerfectLong;
       else if (v == "custom-short") a->error_profile = ErrorProfileKind::CustomShort;
+      else if (v == "custom-long") a->error_profile = ErrorProfileKind::CustomLong;  // extension, see usage()
       else { *err = "invalid value '" + v + "' for '--error-profile'"; return false; }
     } else if (arg == "--abundance-profile") {
       if (!need(&v)) return false;
@@ -490,8 +493,9 @@ std::unique_ptr<ErrorProfile> determine_error_profile(const CliArgs& args, std::
       if (args.uniform_start) p->long_start_mode = SIMMR_START_UNIFORM;
       return p;
     }
+    case ErrorProfileKind::CustomLong:    // extension: the same object, driven through simulate_long_reads
     case ErrorProfileKind::CustomShort: {  // cli.rs:255-272
-      if (!args.custom_profile) { *err = "--custom-profile is required with --error-profile custom-short"; return nullptr; }
+      if (!args.custom_profile) { *err = "--custom-profile is required with --error-profile custom-short / custom-long"; return nullptr; }
       std::string e2;
       auto p = CustomShortErrorProfile::from_path(*args.custom_profile, &e2);
       if (!p) { *err = "Error parsing custom error profile: " + e2; return nullptr; }

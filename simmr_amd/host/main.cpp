@@ -160,6 +160,8 @@ static int run_main(int argc, char** argv) {
   // main.rs:30-33
   if (args.error_profile == ErrorProfileKind::CustomShort && eprofile->is_long_read())
     return die("You specified a custom short-read error profile but the provided error profile is for long reads");
+  if (args.error_profile == ErrorProfileKind::CustomLong && !eprofile->is_long_read())
+    return die("You specified a custom long-read error profile but the provided error profile is for short reads");
 
   simmr_engine* eng = nullptr;
   if (simmr_engine_create(args.device, &eng) != SIMMR_OK) return die(std::string("cannot create engine: ") + simmr_last_error(nullptr));

@@ -167,7 +167,7 @@ struct CustomAbundanceProfile : AbundanceProfile {  // custom.rs
 };
 
 // ---------------------------------------------------------------- cli.rs
-enum class ErrorProfileKind { MinimalShort, MinimalLong, PerfectShort, PerfectLong, CustomShort };
+enum class ErrorProfileKind { MinimalShort, MinimalLong, PerfectShort, PerfectLong, CustomShort, CustomLong /* extension */ };
 enum class AbundanceProfileKind { Exact, Uniform, Custom };
 struct CliArgs {  // cli.rs:93-220, same flags and defaults
   std::vector<std::string> genome;

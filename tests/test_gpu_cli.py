@@ -109,6 +109,52 @@ def test_cli_long_fastq_bytes(workdir, oracle):
     assert out.read_bytes() == bytes(expected)
 
 
+def test_cli_custom_long_with_abundances(workdir, oracle):
+    """BASELINE config 5 in small: a simmrd long-read model, a genome TSV with abundances, the long-read path
+    (`custom-long` is an extension of this CLI: the reference's enum has no value that reaches
+    CustomShortErrorProfile::simulate_errors, cli.rs:62-70, main.rs:30-33)."""
+    from simmr_amd import CustomShortErrorProfile
+    from simmr_amd.profiles import CustomAbundanceProfile
+    from tests import _model
+    d, genomes = workdir
+    blob = _model.synthetic_long_model(kmer_size=6, n_positions=400, seed=8, n_kmers=4 ** 6, lengths=(1500, 6000, 100))
+    (d / "long_model.bin").write_bytes(blob)
+    (d / "abund.tsv").write_text("path\tid\tabundance\n" + f"{d}/g0.fna\tgA\t0.7\n{d}/g1.fna\tgB\t0.3\n")
+    out = d / "custom_long.fq"
+    fmt = "@{:read_id:} {:genome_id:}|{:sequence_id:}|{:start_position:}|{:end_position:}"
+    subprocess.check_call([str(EXE), "--genome-file", str(d / "abund.tsv"), "--output", str(out), "--num-reads", "41",
+                           "--seed", "19", "--error-profile", "custom-long", "--custom-profile", str(d / "long_model.bin"),
+                           "--abundance-profile", "custom", "--read-header-format", fmt])
+    prof = CustomShortErrorProfile(blob)
+    required = 2 * 3750  # custom_short.rs:535-538 with the model's means (3750, 0)
+    hosts, names_all = [], []
+    for contigs, names in genomes:
+        keep = [i for i, c in enumerate(contigs) if c.size > required]
+        hosts.append(_oracle.HostGenome([contigs[i] for i in keep]))
+        names_all.append([names[i] for i in keep])
+    counts = [n for n, _ in CustomAbundanceProfile([0.7, 0.3]).determine_abundances(41, 2)]
+    assert counts == [29, 13]
+    o = _oracle.simulate_long(oracle, hosts, counts, prof.pod(), 19, qual_offset=33)
+    dd = o.trimmed()
+    expected = bytearray()
+    for r in range(o.n_reads):
+        g = int(dd["genome"][r])
+        a, b = int(dd["seq_off"][r]), int(dd["seq_off"][r + 1])
+        h = f"@{int(dd['read_id'][r])} {'gA' if g == 0 else 'gB'}|{names_all[g][int(dd['contig'][r])]}|{int(dd['start'][r])}|{int(dd['end'][r])}"
+        expected += h.encode() + b"\n" + dd["seq"][a:b].tobytes() + b"\n+\n" + dd["qual"][a:b].tobytes() + b"\n"
+    assert out.read_bytes() == bytes(expected)
+    meta = (d / "custom_long.fq.tsv").read_text().split("\n")
+    assert meta[1] == f"gA\t{d}/g0.fna\t29\t0.7" and meta[2] == f"gB\t{d}/g1.fna\t13\t0.3"
+    # a short-read model is refused for custom-long, as a long-read model is for custom-short (main.rs:30-33)
+    (d / "short_model.bin").write_bytes(_model.synthetic_short_model())
+    r = subprocess.run([str(EXE), "--genome", str(d / "g1.fna"), "--output", str(d / "x.fq"), "--error-profile", "custom-long",
+                        "--custom-profile", str(d / "short_model.bin")], capture_output=True)
+    assert r.returncode != 0 and b"short reads" in r.stderr
+    r = subprocess.run([str(EXE), "--genome", str(d / "g1.fna"), "--output", str(d / "x.fq"), "--error-profile", "custom-short",
+                        "--custom-profile", str(d / "long_model.bin")], capture_output=True)
+    assert r.returncode != 0 and b"long reads" in r.stderr
+
+
 def test_cli_contiguous(workdir, oracle):
     d, genomes = workdir
     out = d / "contig.fq"
