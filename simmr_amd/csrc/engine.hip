@@ -265,11 +265,11 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
   for (const BinsHost& b : m.quality) if (!append_pdf(b, &t, &err)) return e->fail(SIMMR_EINVAL, "%s", err.c_str());
   if (t.pdfs[0].n == 0) return e->fail(SIMMR_EINVAL, "custom model has an empty read-length distribution");
   for (size_t i = 2; i < t.pdfs.size(); i++) if (t.pdfs[i].n == 0) return e->fail(SIMMR_EINVAL, "custom model has an empty quality distribution");
-  int rc;
-  if ((rc = upload_vec(e, e->c_pdfs, t.pdfs)) || (rc = upload_vec(e, e->c_odds, t.odds)) ||
-      (rc = upload_vec(e, e->c_alias, t.alias)) || (rc = upload_vec(e, e->c_low, t.bin_low)) ||
-      (rc = upload_vec(e, e->c_range, t.bin_range)) || (rc = upload_vec(e, e->c_zone, t.bin_zone)))
-    return rc;
+  // every host table is built before the first (asynchronous) upload
+  KmerTables kt;
+  if (want_long && !build_kmer_tables(m, &kt, &err)) return e->fail(SIMMR_ENOTSUP, "%s", err.c_str());
+  if (want_long && !std::isfinite(m.read_length_std))
+    return e->fail(SIMMR_ERANGE, "custom model: read_length_std is not finite (Normal::new(..).unwrap() panics)");
   // the emit kernel's copies: one 16-byte record per alias column / per bin
   std::vector<Rec16> colrec(t.odds.size()), binrec(t.bin_low.size());
   for (size_t i = 0; i < t.odds.size(); i++) {
@@ -278,10 +278,15 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
     colrec[i] = Rec16{(uint32_t)bits, (uint32_t)(bits >> 32), t.alias[i], 0u};
   }
   for (size_t i = 0; i < t.bin_low.size(); i++) binrec[i] = Rec16{t.bin_range[i], t.bin_zone[i], t.bin_low[i], 0u};
+  // declared after the vectors, so it runs before they die: whatever path leaves this function, no copy is still reading them
+  struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{e->stream};
+  int rc;
+  if ((rc = upload_vec(e, e->c_pdfs, t.pdfs)) || (rc = upload_vec(e, e->c_odds, t.odds)) ||
+      (rc = upload_vec(e, e->c_alias, t.alias)) || (rc = upload_vec(e, e->c_low, t.bin_low)) ||
+      (rc = upload_vec(e, e->c_range, t.bin_range)) || (rc = upload_vec(e, e->c_zone, t.bin_zone)))
+    return rc;
   if ((rc = upload_vec(e, e->c_colrec, colrec)) || (rc = upload_vec(e, e->c_binrec, binrec))) return rc;
-  KmerTables kt;
   if (want_long) {  // simulate_errors only runs for long reads (simulate.rs:500)
-    if (!build_kmer_tables(m, &kt, &err)) return e->fail(SIMMR_ENOTSUP, "%s", err.c_str());
     if ((rc = upload_vec(e, e->c_kslots, kt.slots)) || (rc = upload_vec(e, e->c_krecs, kt.recs)) ||
         (rc = upload_vec(e, e->c_kdirect, kt.direct)))
       return rc;
@@ -303,9 +308,7 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
   d.custom.bin_rec = e->c_binrec.as<Rec16>();
   d.custom.n_quality = (uint32_t)m.quality.size();
   if (want_long) {
-    // get_random_read_length (custom_short.rs:286-301): Normal::new(mean, std).unwrap() needs a finite std
-    if (!std::isfinite(m.read_length_std))
-      return e->fail(SIMMR_ERANGE, "custom model: read_length_std is not finite (Normal::new(..).unwrap() panics)");
+    // get_random_read_length (custom_short.rs:286-301)
     d.read_length_std = m.read_length_std;
     d.insert_size_std = m.read_length_mean;  // k_const_length reads the mean from this slot
     d.custom.kmer_direct = e->c_kdirect.as<Rec16>();
