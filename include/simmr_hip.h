@@ -287,7 +287,11 @@ int simmr_long_emit(simmr_engine* e, uint32_t read_id_base, const simmr_reads_ou
 
 /* ---- counters / timing ---------------------------------------------------- */
 /* Copies the SIMMR_N_COUNTERS running counters to a DEVICE array (for the
- * caller's all-reduce) and/or a HOST array; either may be NULL. */
+ * caller's all-reduce) and/or a HOST array; either may be NULL.  The device
+ * copy is enqueued on the engine's stream like everything else (a collective
+ * launched from another stream has to be ordered after it by the caller; with
+ * the default null stream, as torch.distributed uses it, that is implicit);
+ * the host copy is complete on return. */
 int simmr_counters(simmr_engine* e, uint64_t* dst_device, uint64_t* dst_host);
 int simmr_counters_reset(simmr_engine* e);
 /* HIP-event time (ms) of the dominant emit kernel of the last *_emit call,
