@@ -39,9 +39,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB.exists():
+    # SIMMR_ORACLE_LIB: another build of the same sources (`make -C oracle asan` for sanitizer runs)
+    import os
+    alt = os.environ.get("SIMMR_ORACLE_LIB")
+    if not alt and not LIB.exists():
         build()
-    lib = C.CDLL(str(LIB))
+    lib = C.CDLL(alt or str(LIB))
     P = C.POINTER
     lib.orc_next_u64.restype = C.c_uint64
     lib.orc_next_u32.restype = C.c_uint32

@@ -17,7 +17,9 @@ DEFAULT_FMT = ("@{:read_id:}|{:genome_id:}/{:pair:} metadata:sid={:sequence_id:}
 @pytest.fixture(scope="module")
 def host():
     subprocess.check_call(["make", "-s", "-C", str(HOST), "libsimmr_host.so"])
-    lib = C.CDLL(str(HOST / "libsimmr_host.so"))
+    import os
+    # SIMMR_HOST_LIB: another build of the same sources (a -fsanitize=address,undefined build for sanitizer runs)
+    lib = C.CDLL(os.environ.get("SIMMR_HOST_LIB") or str(HOST / "libsimmr_host.so"))
     for f in ("simmr_host_normalize", "simmr_host_format_f64", "simmr_host_format_header",
               "simmr_host_load_fasta", "simmr_host_parse_genome_file"):
         getattr(lib, f).restype = C.c_void_p
