@@ -137,3 +137,15 @@ def test_profile_pods():
     assert MinimalLongErrorProfile().minimum_genome_size() == 20000 and MinimalLongErrorProfile().is_long_read()
     shape, scale = gamma_params(20000.0, 15000.0)
     assert abs(shape - 16 / 9) < 1e-6 and abs(scale - 11250.0) < 1e-2
+
+
+def test_integration_doc_binds_every_symbol():
+    """INTEGRATION.md's Rust block declares every function of include/simmr_hip.h."""
+    import re
+    root = Path(__file__).resolve().parent.parent
+    header = (root / "include" / "simmr_hip.h").read_text()
+    doc = (root / "INTEGRATION.md").read_text()
+    names = set(re.findall(r"^(?:int|void|const char\*|uint64_t)\s+(simmr_[a-z0-9_]+)\(", header, flags=re.M))
+    assert len(names) >= 20
+    missing = [n for n in sorted(names) if f"pub fn {n}(" not in doc]
+    assert not missing, missing
