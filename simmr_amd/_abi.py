@@ -171,7 +171,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    p = Path(path) if path else LIB_PATH
+    # SIMMR_HIP_LIB: another build of the same library (A/B timing of a kernel change on one box)
+    p = Path(path or os.environ.get("SIMMR_HIP_LIB") or LIB_PATH)
     if not p.exists():
         raise ImportError(
             f"{p} not found: build the HIP extension first "
