@@ -1512,13 +1512,20 @@ SIMMR_DEV void store_bytes(uint8_t* __restrict__ p, uint64_t v, uint32_t n) {
   }
 }
 
+SIMMR_DEV uint32_t cvt_u32_f32_sat(float f) {
+  uint32_t r;
+  asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
+}
+SIMMR_DEV uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
 struct LaneQ {
   uint32_t i;      // next base index
   uint32_t st;     // 0 FRESH, 1 WEDGE (need the f64 draw), 2 TAIL_X, 3 TAIL_Y
   uint32_t pidx;   // layer of the pending wedge
   double px;       // pending x (WEDGE) / u (TAIL) 
   double tx;       // TAIL: x_ draw waiting for its y_
-  uint64_t qsum;
+  uint32_t qsum;   // <= 65535 * 255
 };
 
 // Per-lane output staging: a 128-byte ring in LDS holding the two 64-byte
@@ -1622,8 +1629,10 @@ SIMMR_DEV void q_emit(LaneQ& s, double x, const ProfileDev& prof, const Tables* 
                       const OutRing& ring, uint32_t qoff) {
   // minimal_short.rs:90-101 / minimal_long.rs:88-98: floor(Normal<f32>(mean, 10).sample()) as u8;
   // perfect_long.rs:68-77 through the threshold table (phred_of_z)
+  // floor(..) as u8 (saturating, NaN -> 0): v_cvt_u32_f32 truncates, sends NaN and negatives to 0 and saturates
+  // upwards; below zero floor and truncation differ, but both end at 0, so the floor needs no instruction
   const uint32_t q = PL ? phred_of_z(prof, T, x)
-                        : sat_u8_f32(floorf(__fadd_rn(prof.mean_phred_f, __fmul_rn(10.0f, (float)x))));
+                        : min_u32(cvt_u32_f32_sat(__fadd_rn(prof.mean_phred_f, __fmul_rn(10.0f, (float)x))), 255u);
   s.qsum += q;
   ring_put(ring, s.i, q + qoff);
   s.i++;
@@ -1680,14 +1689,18 @@ struct LaneM {
   uint64_t qnext;   // prefetched: the following 8 qualities
   uint32_t cnext, enext;  // prefetched: the following 16 codes / exception bits
   uint32_t n_subst, n_acgt;
+  uint32_t lut;     // "ACGT", or "TGCA" for mate 2 (complemented; written back to front)
+  uint32_t wpos;    // ring position of the next output byte (mod 128); moves by wdir
+  uint32_t wdir;    // +1, or -1 for mate 2 (simulate.rs:283: reverse complement AFTER mutation)
 };
 
-SIMMR_DEV void m_emit(LaneM& s, uint32_t code, uint32_t L, uint32_t rev, const OutRing& ring) {
-  // code 0-3 = ACGT, 4 = 'N', 5 = '-'
-  const uint32_t lut_f = 0x54474341u, lut_r = 0x41434754u;  // "ACGT", "TGCA"
-  const uint32_t ch = code < 4u ? ((rev ? lut_r : lut_f) >> (8 * code)) & 0xffu : (code == 4u ? 'N' : '-');
-  // forward mate: byte i.  Mate 2 is reverse-complemented AFTER mutation (simulate.rs:283): byte L-1-i
-  ring_put(ring, rev ? (L - 1u - s.i) : s.i, ch);
+template <bool HAS_EXC>
+SIMMR_DEV void m_emit(LaneM& s, uint32_t code, const OutRing& ring) {
+  // code 0-3 = ACGT, 4 = 'N', 5 = '-' (only with an exception plane)
+  uint32_t ch = __builtin_amdgcn_perm(0u, s.lut, code | 0x0c0c0c00u);  // byte `code` of the lut
+  if (HAS_EXC && code >= 4u) ch = code == 4u ? 'N' : '-';
+  ring.ring[s.wpos & 127u] = (uint8_t)ch;
+  s.wpos += s.wdir;
   s.i++;
 }
 
@@ -1718,7 +1731,8 @@ SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const uint
       s.cnext = fetch_codes16(packed, (int64_t)(src + i + 16));
       if (HAS_EXC) { s.ereg = s.enext; s.enext = mask ? fetch_mask16(mask, (int64_t)(src + i + 16)) : 0u; }
     }
-    const uint32_t q = ((uint32_t)(s.qreg >> (8 * (i & 7u))) - qoff) & 0xffu;
+    // byte (i & 7) of qreg, zero-extended, in one v_perm_b32
+    const uint32_t q = (__builtin_amdgcn_perm((uint32_t)(s.qreg >> 32), (uint32_t)s.qreg, (i & 7u) | 0x0c0c0c00u) - qoff) & 0xffu;
     uint32_t code = (s.creg >> (2 * (i & 15u))) & 3u;
     uint32_t exc = 0;
     if (HAS_EXC) {
@@ -1730,7 +1744,7 @@ SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const uint
     if ((w >> 8) > thr[q] && !exc) {
       s.st = 1;
     } else {
-      m_emit(s, code, L, rev, ring);
+      m_emit<HAS_EXC>(s, code, ring);
     }
   } else {
     // choose(&[3 alternatives]) = gen_range(0..3u32), zone 0xBFFFFFFF
@@ -1740,7 +1754,7 @@ SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const uint
       const uint32_t c = (s.creg >> (2 * (s.i & 15u))) & 3u;
       s.st = 0;
       s.n_subst++;
-      m_emit(s, k + (k >= c ? 1u : 0u), L, rev, ring);
+      m_emit<HAS_EXC>(s, k + (k >= c ? 1u : 0u), ring);
     }
   }
 }
@@ -1817,6 +1831,9 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
       const uint8_t* qsrc = qual + off;
       OutRing ring;
       ring_init(ring, my_ring, seq + off, L, rev != 0);
+      s.lut = rev ? 0x41434754u : 0x54474341u;  // "TGCA" / "ACGT"
+      s.wpos = ring.a0 + (rev ? L - 1u : 0u);   // forward mate: byte i; mate 2: byte L-1-i
+      s.wdir = rev ? 0xffffffffu : 1u;
       s.qnext = load_q8(qsrc, 0, L);
       s.cnext = live ? fetch_codes16(packed, (int64_t)src) : 0u;
       s.enext = (HAS_EXC && mask) ? fetch_mask16(mask, (int64_t)src) : 0u;
