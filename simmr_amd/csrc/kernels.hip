@@ -1934,7 +1934,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
               const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
               uint32_t qual_offset, uint64_t first_unit, uint32_t read_id_base, OutCols o,
               unsigned long long* __restrict__ counters) {
-  // per outcome column i = q | s << 8: x = alias threshold << 10 (compared with W << 10),
+  // per outcome column i = q | s << 8: x = i << 22 | alias threshold (compared with the whole word W, whose top
+  // ten bits are i: W < x <=> its low 22 bits < threshold),
   // y = result i, z = result alias(i), both as enc(q) << 8 | s with enc(q) = (q + qual_offset) as u8
   // (util.rs:46-50)
   __shared__ uint2 jtab[1024];
@@ -1954,7 +1955,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     for (uint32_t i = t; i < 1024u; i += 256u) {
       const uint32_t e = prof.philox_phred[i];
       const uint32_t al = e >> 22;
-      jtab[i] = make_uint2((e & 0x3fffffu) << 10, ((((i + qual_offset) & 0xffu) << 8) | (i >> 8)) |
+      jtab[i] = make_uint2((i << 22) | (e & 0x3fffffu), ((((i + qual_offset) & 0xffu) << 8) | (i >> 8)) |
                                                       (((((al + qual_offset) & 0xffu) << 8) | (al >> 8)) << 16));
     }
     if (t <= 16u) {
@@ -2061,7 +2062,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           uint32_t x;
           asm("v_cmp_lt_u32_e32 vcc, %1, %2\n\t"
               "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
-              : "=v"(x) : "v"(W << 10), "v"(e.x), "v"(e.y) : "vcc");
+              : "=v"(x) : "v"(W), "v"(e.x), "v"(e.y) : "vcc");
           ss = __builtin_amdgcn_alignbit(x, ss, 2);
           // byte (j & 3) of qr[j >> 2] = enc(q) = byte 1 of x
           qr[j >> 2] = __builtin_amdgcn_perm(x, qr[j >> 2], 0x03020100u ^ ((uint32_t)((j & 3) ^ 5) << (8 * (j & 3))));
