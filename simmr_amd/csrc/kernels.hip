@@ -2065,7 +2065,10 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
               : "=v"(x) : "v"(W), "v"(e.x), "v"(e.y) : "vcc");
           ss = __builtin_amdgcn_alignbit(x, ss, 2);
           // byte (j & 3) of qr[j >> 2] = enc(q) = byte 1 of x
-          qr[j >> 2] = __builtin_amdgcn_perm(x, qr[j >> 2], 0x03020100u ^ ((uint32_t)((j & 3) ^ 5) << (8 * (j & 3))));
+          if ((j & 3) == 0) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[j >> 2]) : "v"(x));
+          else if ((j & 3) == 1) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[j >> 2]) : "v"(x));
+          else if ((j & 3) == 2) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[j >> 2]) : "v"(x));
+          else asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[j >> 2]) : "v"(x));
         }
       }
       // only live ACGT bases mutate (minimal_short.rs:120-128)
