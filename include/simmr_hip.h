@@ -276,10 +276,11 @@ int simmr_pe_emit(simmr_engine* e, uint32_t read_id_base, const simmr_reads_out*
  * is_long flag is set (custom_short.rs:540-542): then the run-wide length is
  * floor(Normal(read_length_mean, read_length_std)) (custom_short.rs:286-301),
  * qualities come from the per-position PDFs (:332-353) and simmr_long_emit
- * applies simulate_errors, the k-mer splice (:455-516).  A custom model needs
- * a seed and SIMMR_LEN_REFERENCE (else SIMMR_ENOTSUP) and kmer_size <= 10; an
- * alternate k-mer that deletes bases makes the reference panic and
- * simmr_long_emit return SIMMR_ERANGE. */
+ * applies simulate_errors, the k-mer splice (:455-516); with
+ * SIMMR_LEN_PER_READ every read draws its own length from that Normal law.
+ * A custom model needs kmer_size <= 10 (else SIMMR_ENOTSUP); an alternate
+ * k-mer that deletes bases makes the reference panic and simmr_long_emit
+ * return SIMMR_ERANGE. */
 int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_idx,
                     const uint64_t* genome_reads, const simmr_error_profile* profile, int has_seed,
                     uint64_t seed, simmr_range shard, simmr_plan_info* info);

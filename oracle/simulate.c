@@ -519,7 +519,6 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
   if (count > total - first) count = total - first;
   if (out->reads_capacity < count) FAIL(SIMMR_ERANGE, "reads_capacity too small");
   int per_read = (!has_seed) || p->length_mode == SIMMR_LEN_PER_READ;
-  if (per_read && p->kind == SIMMR_CUSTOM) FAIL(SIMMR_ENOTSUP, "custom model on the long-read path: seed and SIMMR_LEN_REFERENCE only");
   if (p->kind == SIMMR_CUSTOM && !orc_profile_is_long_read(p)) FAIL(SIMMR_EINVAL, "a short-read custom model on the long-read path");
   long_unit* units = (long_unit*)calloc(count ? count : 1, sizeof(long_unit));
   if (!units) FAIL(SIMMR_ENOMEM, "oom");
@@ -574,9 +573,15 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
         orc_rng r; orc_rng_seed_from_u64(&r, orc_per_read_seed(seed, gi));
         long_unit* u = &units[gi - first];
         for (int tries = 0;; tries++) {
-          float gl;
-          if (orc_gamma_f32(&r, p->gamma_shape, p->gamma_scale, &gl)) { rc = SIMMR_EINVAL; break; }
-          uint32_t L = sat_u16_f32(floorf(gl));
+          uint32_t L;
+          if (p->kind == SIMMR_CUSTOM) { /* get_random_read_length of the custom profile (custom_short.rs:286-301) */
+            const orc_model* m = orc_custom_model(custom_of(p));
+            L = sat_u16_f64(floor(orc_normal_f64(&r, m->read_length_mean, m->read_length_std)));
+          } else {
+            float gl;
+            if (orc_gamma_f32(&r, p->gamma_shape, p->gamma_scale, &gl)) { rc = SIMMR_EINVAL; break; }
+            L = sat_u16_f32(floorf(gl));
+          }
           if (L == 0 || maxsz <= L) {
             if (tries > 1000) { rc = SIMMR_EGENOME; snprintf(g_err, sizeof g_err, "no usable sequence"); break; }
             continue; /* :370-372 try a new length */

@@ -1236,8 +1236,6 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   uint64_t first = std::min(shard.first, total_reads);
   uint64_t count = std::min(shard.count, total_reads - first);
   const bool per_read = !has_seed || profile->length_mode == SIMMR_LEN_PER_READ;
-  if (per_read && prof.kind == SIMMR_K_CUSTOM)
-    return e->fail(SIMMR_ENOTSUP, "a custom model on the long-read path needs a seed and SIMMR_LEN_REFERENCE (the per-read length extension draws from the gamma law)");
   if (!has_seed) seed = os_entropy_u64();
   if ((rc = ensure_plan_arrays(e, count, false, true))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_a, e->stream));

@@ -657,7 +657,10 @@ k_plan_long_per_read(ProfileDev prof, const GenomeDev* __restrict__ genomes,
   uint32_t L = 0, contig = 0;
   uint64_t read_seed = 0;
   for (int tries = 0;; tries++) {
-    L = sat_u16_f32(floorf(rng.gamma_f32(T, prof.gamma_shape, prof.gamma_scale)));
+    if (prof.kind == SIMMR_K_CUSTOM)  // custom_short.rs:286-301 (the model's mean rides in insert_size_std, see k_const_length)
+      L = sat_u16_f64(floor(__dadd_rn(prof.insert_size_std, __dmul_rn(prof.read_length_std, rng.standard_normal(T)))));
+    else
+      L = sat_u16_f32(floorf(rng.gamma_f32(T, prof.gamma_shape, prof.gamma_scale)));
     if (L == 0 || run.max_size <= L) {
       if (tries > 1000) { atomicOr(err, SIMMR_ERRBIT_GENOME); L = 0; break; }
       continue;

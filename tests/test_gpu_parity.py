@@ -454,6 +454,31 @@ def test_custom_long_exceptions_and_sharding(engine, oracle):
         assert np.array_equal(part["qual"], whole["qual"][base:whole["seq_off"][first + n]])
 
 
+def test_custom_long_per_read_lengths(engine, oracle, genome_multi, genome_1m):
+    """SIMMR_LEN_PER_READ with a custom model: every read draws floor(Normal(read_length_mean, read_length_std))
+    from its own StdRng, as the reference does without --seed (custom_short.rs:286-301, simulate.rs:358)."""
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    prof = CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=6, n_positions=2500, seed=12, n_kmers=4 ** 6,
+                                                               lengths=(800, 5200, 100)))
+    pod = prof.pod()
+    pod.length_mode = _abi.LEN_PER_READ
+    engine.stage_genome(4, genome_1m.contigs)
+    reads = [150, 100]
+    dev = engine.simulate_long_reads([1, 4], reads, pod, 23, qual_offset=33)
+    ora = _oracle.simulate_long(oracle, [genome_multi, genome_1m], reads, pod, 23, qual_offset=33)
+    d, o = dev.to_host(), ora.trimmed()
+    o["genome"] = np.array([1, 4], dtype=np.uint32)[o["genome"]]
+    assert_same(d, o, cols=COLS + ("genome",))
+    lens = np.diff(d["seq_off"].astype(np.int64))
+    assert lens.std() > 300 and abs(lens.mean() - 3000) < 250  # N(3000, 880)
+    # a shard of the same run
+    part = engine.simulate_long_reads([1, 4], reads, pod, 23, first=140, count=30, qual_offset=33).to_host()
+    base = int(d["seq_off"][140])
+    assert np.array_equal(part["seq"], d["seq"][base:int(d["seq_off"][170])])
+    assert np.array_equal(part["qual"], d["qual"][base:int(d["seq_off"][170])])
+
+
 def test_custom_long_error_paths(engine, oracle, genome_multi):
     from simmr_amd import CustomShortErrorProfile, SimmrError
     from tests import _model
@@ -467,12 +492,6 @@ def test_custom_long_error_paths(engine, oracle, genome_multi):
         _oracle.simulate_long(oracle, [genome_multi], [50], pod, 3)
     assert f"oracle error {_abi.ERANGE}" in str(oi.value)
     good = CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=5, n_positions=20, seed=1, n_kmers=100))
-    # the per-read length extension draws from the gamma law: not defined for a custom model
-    pr = good.pod()
-    pr.length_mode = _abi.LEN_PER_READ
-    with pytest.raises(SimmrError) as ei:
-        engine.long_plan([1], [10], pr, 3)
-    assert ei.value.code == _abi.ENOTSUP
     # a short-read model has is_long_read() == false and never reaches simulate_long_reads
     with pytest.raises(SimmrError) as ei:
         engine.long_plan([1], [10], CustomShortErrorProfile(_model.synthetic_short_model()).pod(), 3)

@@ -129,8 +129,9 @@ def test_long_path_with_a_custom_model(oracle):
         assert got.tobytes() == bytes(seq), r
         q = out["qual"][out["seq_off"][r]:out["seq_off"][r + 1]]
         assert (q[24:] == q[24]).all() and set(np.unique(q)) <= set(range(10, 34))
-    # the per-read length extension is not defined for a custom model
+    # the per-read length extension: every read draws its own floor(Normal(mean, std)) length
     pod = prof.pod()
     pod.length_mode = 1
-    with pytest.raises(RuntimeError):
-        _oracle.simulate_long(oracle, [g], [5], pod, 11)
+    per = _oracle.simulate_long(oracle, [g], [40], pod, 11).trimmed()
+    lens = np.diff(per["seq_off"].astype(np.int64))
+    assert len(set(lens.tolist())) > 10 and 500 < lens.mean() < 1000  # reads on the 1200 nt sequence are re-cut at its end
