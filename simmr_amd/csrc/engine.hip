@@ -311,6 +311,8 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
     // get_random_read_length (custom_short.rs:286-301)
     d.read_length_std = m.read_length_std;
     d.insert_size_std = m.read_length_mean;  // k_const_length reads the mean from this slot
+    if (p->long_start_mode > SIMMR_START_UNIFORM) return e->fail(SIMMR_EINVAL, "unknown long_start_mode %u", p->long_start_mode);
+    d.long_start_uniform = p->long_start_mode == SIMMR_START_UNIFORM ? 1u : 0u;
     d.custom.kmer_direct = e->c_kdirect.as<Rec16>();
     d.custom.kmer_slots = e->c_kslots.as<Rec16>();
     d.custom.kmer_recs = e->c_krecs.as<Rec16>();

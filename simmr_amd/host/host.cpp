@@ -324,6 +324,8 @@ simmr_error_profile CustomShortErrorProfile::pod() const {
   p.kind = SIMMR_CUSTOM;
   p.custom_model = model.data();
   p.custom_model_bytes = model.size();
+  p.length_mode = length_mode;          // long-read models only (extensions --per-read-lengths / --uniform-start)
+  p.long_start_mode = long_start_mode;
   return p;
 }
 uint16_t CustomShortErrorProfile::minimum_genome_size() const {
@@ -499,6 +501,10 @@ std::unique_ptr<ErrorProfile> determine_error_profile(const CliArgs& args, std::
       std::string e2;
       auto p = CustomShortErrorProfile::from_path(*args.custom_profile, &e2);
       if (!p) { *err = "Error parsing custom error profile: " + e2; return nullptr; }
+      if (args.error_profile == ErrorProfileKind::CustomLong) {
+        if (args.per_read_lengths) p->length_mode = SIMMR_LEN_PER_READ;
+        if (args.uniform_start) p->long_start_mode = SIMMR_START_UNIFORM;
+      }
       return p;
     }
   }

@@ -132,6 +132,8 @@ struct CustomShortErrorProfile : ErrorProfile {  // custom_short.rs (model read 
   std::vector<uint8_t> model;  // bincode ErrorModelParams, handed to the library as is
   double read_length_mean = 0, insert_size_mean = 0;
   bool is_long = false;
+  uint32_t length_mode = SIMMR_LEN_REFERENCE;       // custom-long only
+  uint8_t long_start_mode = SIMMR_START_REFERENCE;  // custom-long only
   // shared/src/encoding.rs:268-281 deserialize_model_from_path
   static std::unique_ptr<CustomShortErrorProfile> from_path(const std::string& path, std::string* err);
   simmr_error_profile pod() const override;

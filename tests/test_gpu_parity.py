@@ -454,7 +454,8 @@ def test_custom_long_exceptions_and_sharding(engine, oracle):
         assert np.array_equal(part["qual"], whole["qual"][base:whole["seq_off"][first + n]])
 
 
-def test_custom_long_per_read_lengths(engine, oracle, genome_multi, genome_1m):
+@pytest.mark.parametrize("uniform_start", [False, True])
+def test_custom_long_per_read_lengths(engine, oracle, genome_multi, genome_1m, uniform_start):
     """SIMMR_LEN_PER_READ with a custom model: every read draws floor(Normal(read_length_mean, read_length_std))
     from its own StdRng, as the reference does without --seed (custom_short.rs:286-301, simulate.rs:358)."""
     from simmr_amd import CustomShortErrorProfile
@@ -463,6 +464,7 @@ def test_custom_long_per_read_lengths(engine, oracle, genome_multi, genome_1m):
                                                                lengths=(800, 5200, 100)))
     pod = prof.pod()
     pod.length_mode = _abi.LEN_PER_READ
+    pod.long_start_mode = _abi.START_UNIFORM if uniform_start else _abi.START_REFERENCE
     engine.stage_genome(4, genome_1m.contigs)
     reads = [150, 100]
     dev = engine.simulate_long_reads([1, 4], reads, pod, 23, qual_offset=33)
@@ -472,6 +474,10 @@ def test_custom_long_per_read_lengths(engine, oracle, genome_multi, genome_1m):
     assert_same(d, o, cols=COLS + ("genome",))
     lens = np.diff(d["seq_off"].astype(np.int64))
     assert lens.std() > 300 and abs(lens.mean() - 3000) < 250  # N(3000, 880)
+    if uniform_start:  # starts spread over the sequences instead of their first read_length bases (quirk Q6)
+        assert (d["start"].astype(np.int64) > 10_000).mean() > 0.5
+    else:
+        assert (d["start"].astype(np.int64) < lens).all()
     # a shard of the same run
     part = engine.simulate_long_reads([1, 4], reads, pod, 23, first=140, count=30, qual_offset=33).to_host()
     base = int(d["seq_off"][140])
