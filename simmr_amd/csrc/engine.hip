@@ -1145,12 +1145,13 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
       const uint64_t blocks = (n_reads + 255) / 256;
       const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
-      hipLaunchKernelGGL(k_custom_long_qual, dim3(grid), dim3(256), 0, e->stream, e->prof, n_units, pl,
+      const uint32_t* order = e->plan_sorted ? e->u_order.as<uint32_t>() : (const uint32_t*)nullptr;
+      hipLaunchKernelGGL(k_custom_long_qual, dim3(grid), dim3(256), 0, e->stream, e->prof, n_units, order, pl,
                          e->u_off.as<uint64_t>(), e->u_seed.as<uint64_t>(), out->qual, out->qual_offset, counters,
                          e->d_err.as<uint32_t>());
       auto kern = exc ? k_custom_long_splice<true> : k_custom_long_splice<false>;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), n_units, pl,
-                         e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), n_units, order,
+                         pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
                          e->u_seed.as<uint64_t>(), out->seq, counters, e->d_err.as<uint32_t>());
     } else if (e->prof.kind == SIMMR_K_CUSTOM) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));

@@ -2324,7 +2324,8 @@ __device__ __attribute__((noinline)) void refill_words(const Key key, uint32_t b
 
 // qualities of the long reads (simulate_phred_scores, custom_short.rs:332-353): one lane per read
 extern "C" __global__ void __launch_bounds__(256)
-k_custom_long_qual(ProfileDev prof, uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
+k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict__ order, PlanArrays pl,
+                   const uint64_t* __restrict__ u_off,
                    const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ qual, uint32_t qual_offset,
                    unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
   __shared__ uint32_t words[256][CUSTOM2_WORDS + 1];
@@ -2334,7 +2335,9 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, PlanArrays pl, const uint6
   const uint32_t qoff = qual_offset & 0xffu;
   uint32_t* const row = words[threadIdx.x];
   for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n_units; r0 += (uint64_t)gridDim.x * 256) {
-    const uint64_t u = r0 + threadIdx.x;
+    // reads in order of length (k_len_*), longest first: the lanes of a wave then finish together
+    const uint64_t ti = r0 + threadIdx.x;
+    const uint64_t u = ti < n_units ? (order ? (uint64_t)order[n_units - 1 - ti] : ti) : n_units;
     uint32_t n = 0;
     uint64_t off = 0, seed = 0;
     if (u < n_units) { n = pl.len[u]; off = u_off[u]; seed = u_seed[u]; }  // read_seed (simulate.rs:497)
@@ -2410,7 +2413,8 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, PlanArrays pl, const uint6
 // bases of the long reads (simulate_errors, custom_short.rs:455-516): one lane per read
 template <bool HAS_EXC>
 __global__ void __launch_bounds__(256)
-k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint64_t n_units, PlanArrays pl,
+k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint64_t n_units,
+                     const uint32_t* __restrict__ order, PlanArrays pl,
                      const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
                      const uint32_t* __restrict__ u_genome, const uint64_t* __restrict__ u_seed,
                      uint8_t* __restrict__ seq, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
@@ -2421,7 +2425,8 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
   bool bad_kmer = false;
   uint32_t* const row = words[threadIdx.x];
   for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n_units; r0 += (uint64_t)gridDim.x * 256) {
-    const uint64_t u = r0 + threadIdx.x;
+    const uint64_t ti = r0 + threadIdx.x;
+    const uint64_t u = ti < n_units ? (order ? (uint64_t)order[n_units - 1 - ti] : ti) : n_units;
     uint32_t n = 0;
     uint64_t off = 0, src0 = 0, seed = 0;
     const uint32_t* packed = nullptr;
