@@ -13,8 +13,8 @@ job is N x 100 M reads of ONE run (same seed): rank r simulates pair-index range
 the 8 run counters at the end of every step (RCCL over xGMI).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
-(k_emit_stream): algorithmic bytes per launch / its HIP-event duration measured
-on the engine's stream.  `cpu_baseline` is the CPU oracle (a port of the
+(k_emit_philox in the default counter mode): algorithmic bytes per launch / its
+HIP-event duration measured on the engine's stream.  `cpu_baseline` is the CPU oracle (a port of the
 reference algorithm; the Rust reference cannot be built here) timed on this
 host on a bounded sample of the same workload.
 """
@@ -38,7 +38,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU per step")
     ap.add_argument("--genome-bases", type=int, default=100_000_000)
-    ap.add_argument("--profile", default="minimal-short", choices=["minimal-short", "perfect-short", "minimal-long"])
+    ap.add_argument("--profile", default="minimal-short", choices=["minimal-short", "perfect-short", "minimal-long", "custom-long"],
+                    help="custom-long: a synthetic simmrd-shaped long-read model (k = 7, every 7-mer listed, 1000 modelled "
+                         "positions) through the long-read path with per-read lengths (BASELINE config 5's profile)")
+    ap.add_argument("--length-normal", default="20000,4000", help="custom-long: read_length_mean,read_length_std of the model")
     ap.add_argument("--gamma", default="8000,6000", help="minimal-long: gamma mean,std of the read length (BASELINE config 3)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--rng", default="philox", choices=["reference", "philox"],
@@ -76,8 +79,19 @@ def main():
 
     eng = Engine(local_rank)
     eng.stage_synthetic(0, [args.genome_bases], 2)  # SplitMix64(seed=2)
-    long_mode = args.profile == "minimal-long"
-    if long_mode:
+    long_mode = args.profile in ("minimal-long", "custom-long")
+    custom = None
+    if args.profile == "custom-long":
+        from simmr_amd import CustomShortErrorProfile, model_io
+        lm, ls = (float(x) for x in args.length_normal.split(","))
+        custom = CustomShortErrorProfile(model_io.synthetic_long_model(kmer_size=7, n_positions=1000, seed=1, n_kmers=4 ** 7,
+                                                                       read_length_mean=lm, read_length_std=ls))
+        prof = custom.pod()  # `custom` owns the model bytes the POD points to
+        prof.length_mode = _abi.LEN_PER_READ
+        prof.long_start_mode = _abi.START_UNIFORM
+        args.rng = "reference"  # the empirical model has no counter mode
+        args.no_other_mode = True
+    elif long_mode:
         gm, gs = (float(x) for x in args.gamma.split(","))
         prof = MinimalLongErrorProfile(gamma_mean=gm, gamma_std=gs, length_mode=_abi.LEN_PER_READ).pod()
     else:
@@ -200,7 +214,9 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": (f"{args.profile} gamma({args.gamma}) long reads" if long_mode else f"{args.profile} 150 bp PE")
+                "workload": (f"custom-long (synthetic simmrd-shaped model, k = 7, N({args.length_normal}) per-read lengths, uniform starts)"
+                             if custom is not None else
+                             f"{args.profile} gamma({args.gamma}) long reads" if long_mode else f"{args.profile} 150 bp PE")
                             + f", 1 genome ({args.genome_bases} bp synthetic SplitMix64 seed 2), "
                             f"{2 * pairs_per_gpu} reads per GPU per step, seed {args.seed}",
                 "rng": ("reference StdRng streams (ChaCha12), bit-exact mode" if args.rng == "reference" else
@@ -215,6 +231,7 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("k_emit_perfect_pe" if args.profile == "perfect-short" else
+                           "k_custom_long_qual + k_custom_long_splice" if custom is not None else
                            "k_emit_lanes" if args.rng == "reference" else "k_emit_philox"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
