@@ -2377,14 +2377,14 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
       uint32_t q_last = 0;  // the value of every position >= n_quality - 1 (custom_short.rs:339-350)
       if (n >= C.n_quality) q_last = sample(C.pdfs[2 + C.n_quality - 1]);
       const uint64_t fill = ((q_last + qoff) & 0xffu) * 0x0101010101010101ULL;
-      for (uint32_t b0 = 0; __any(b0 < n); b0 += 16) {
+      // positions below b_fill (the first 16-group that lies entirely at or after n_quality - 1) are sampled one by
+      // one, lane per read; the constant rest of every read is then written by the whole wave, 1 KB per store
+      const uint32_t b_fill = (C.n_quality - 1u + 15u) & ~15u;
+      for (uint32_t b0 = 0; b0 < b_fill && __any(b0 < n); b0 += 16) {
         if (b0 >= n) continue;
         const uint32_t cnt = (n - b0) < 16u ? (n - b0) : 16u;
-        uint64_t q_lo = fill, q_hi = fill;
-        if (b0 + 1u >= C.n_quality) {  // wave-uniform
-          qsum += (uint64_t)q_last * cnt;
-        } else {
-          q_lo = 0; q_hi = 0;
+        uint64_t q_lo = 0, q_hi = 0;
+        {
           for (uint32_t j = 0; j < 16; j++) {
             const uint32_t p = b0 + j;
             const PdfDev pdf = C.pdfs[2 + (p < C.n_quality ? p : C.n_quality - 1)];
@@ -2401,6 +2401,22 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
           *reinterpret_cast<u64_unaligned*>(qd + 8) = q_hi;
         } else {
           store_tail(qd, q_lo, q_hi, cnt);
+        }
+      }
+      if (n > b_fill) qsum += (uint64_t)q_last * (n - b_fill);
+      const uint32_t lane = threadIdx.x & 63u;
+      for (uint32_t src = 0; src < 64u; src++) {
+        const uint32_t n_s = __shfl(n, (int)src, 64);
+        if (n_s <= b_fill) continue;  // wave-uniform
+        const uint64_t off_s = __shfl(off, (int)src, 64), fill_s = __shfl(fill, (int)src, 64);
+        for (uint32_t p = b_fill + lane * 16u; p < n_s; p += 1024u) {
+          uint8_t* qd = qual + off_s + p;
+          if (p + 16u <= n_s) {
+            *reinterpret_cast<u64_unaligned*>(qd) = fill_s;
+            *reinterpret_cast<u64_unaligned*>(qd + 8) = fill_s;
+          } else {
+            store_tail(qd, fill_s, fill_s, n_s - p);
+          }
         }
       }
     }
