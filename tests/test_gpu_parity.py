@@ -485,6 +485,28 @@ def test_custom_long_per_read_lengths(engine, oracle, genome_multi, genome_1m, u
     assert np.array_equal(part["qual"], d["qual"][base:int(d["seq_off"][170])])
 
 
+def test_custom_long_reads_shorter_than_a_kmer(engine, oracle):
+    """Reads re-cut at the end of a tiny sequence can be shorter than k (even empty): simulate_errors then visits
+    no k-mer (custom_short.rs:475-477) and the read is a plain copy."""
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    rng = np.random.default_rng(5)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 47)].copy()
+    seq[11] = ord("N")
+    engine.stage_genome(3, [seq])
+    g = _oracle.HostGenome([seq])
+    blob = _model.synthetic_long_model(kmer_size=7, n_positions=12, seed=3, n_kmers=4 ** 7, read_length_mean=40.0,
+                                       read_length_std=2.0)
+    pod = CustomShortErrorProfile(blob).pod()
+    for seed in (1, 2, 3):
+        dev = engine.simulate_long_reads([3], [300], pod, seed, qual_offset=33).to_host()
+        ora = _oracle.simulate_long(oracle, [g], [300], pod, seed, qual_offset=33).trimmed()
+        ora["genome"][:] = 3
+        assert_same(dev, ora, cols=COLS + ("genome",))
+        lens = np.diff(dev["seq_off"].astype(np.int64))
+        assert (lens < 7).any() and (lens >= 7).any()
+
+
 def test_custom_long_error_paths(engine, oracle, genome_multi):
     from simmr_amd import CustomShortErrorProfile, SimmrError
     from tests import _model
