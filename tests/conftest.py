@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _hip_library_is_built():
+    """A fresh checkout has no binaries (they are git-ignored): build the C-ABI library once, as
+    __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU).  The product itself never
+    builds or falls back: simmr_amd._abi.load() raises when the library is missing."""
+    import subprocess
+    if not (ROOT / "simmr_amd" / "csrc" / "libsimmr_hip.so").exists():
+        subprocess.check_call(["make", "-s", "-C", str(ROOT / "simmr_amd" / "csrc")])
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from tests import _oracle
