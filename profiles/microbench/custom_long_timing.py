@@ -7,7 +7,7 @@ import time
 import torch
 
 from simmr_amd import CustomShortErrorProfile, Engine
-from tests import _model
+from simmr_amd import model_io as _model
 
 
 def main():
