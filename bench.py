@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU per step")
     ap.add_argument("--genome-bases", type=int, default=100_000_000)
-    ap.add_argument("--profile", default="minimal-short", choices=["minimal-short", "perfect-short", "minimal-long", "custom-long"],
+    ap.add_argument("--profile", default="minimal-short", choices=["minimal-short", "perfect-short", "minimal-long", "custom-short", "custom-long"],
                     help="custom-long: a synthetic simmrd-shaped long-read model (k = 7, every 7-mer listed, 1000 modelled "
                          "positions) through the long-read path with per-read lengths (BASELINE config 5's profile)")
     ap.add_argument("--length-normal", default="20000,4000", help="custom-long: read_length_mean,read_length_std of the model")
@@ -90,6 +90,12 @@ def main():
         prof.length_mode = _abi.LEN_PER_READ
         prof.long_start_mode = _abi.START_UNIFORM
         args.rng = "reference"  # the empirical model has no counter mode
+        args.no_other_mode = True
+    elif args.profile == "custom-short":
+        from simmr_amd import CustomShortErrorProfile, model_io
+        custom = CustomShortErrorProfile(model_io.synthetic_short_model())  # 120 modelled positions, lengths ~ N(140, 12)
+        prof = custom.pod()
+        args.rng = "reference"
         args.no_other_mode = True
     elif long_mode:
         gm, gs = (float(x) for x in args.gamma.split(","))
@@ -214,7 +220,9 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": (f"custom-long (synthetic simmrd-shaped model, k = 7, N({args.length_normal}) per-read lengths, uniform starts)"
+                "workload": ("custom-short (synthetic simmrd-shaped model: 120 modelled positions, lengths ~ N(140, 12), inserts ~ N(200, 40)) PE"
+                             if args.profile == "custom-short" else
+                             f"custom-long (synthetic simmrd-shaped model, k = 7, N({args.length_normal}) per-read lengths, uniform starts)"
                              if custom is not None else
                              f"{args.profile} gamma({args.gamma}) long reads" if long_mode else f"{args.profile} 150 bp PE")
                             + f", 1 genome ({args.genome_bases} bp synthetic SplitMix64 seed 2), "
@@ -231,6 +239,7 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("k_emit_perfect_pe" if args.profile == "perfect-short" else
+                           "k_emit_custom_pe" if args.profile == "custom-short" else
                            "k_custom_long_qual + k_custom_long_splice" if custom is not None else
                            "k_emit_lanes" if args.rng == "reference" else "k_emit_philox"),
                 "achieved": achieved,

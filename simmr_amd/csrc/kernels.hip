@@ -2166,6 +2166,22 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 // result is exact in every case.
 // ===========================================================================
 #define CUSTOM2_WORDS 16u
+#define CUSTOM_LDS_PDFS 512u /* PDF headers kept in LDS (32 bytes each); later positions are read from memory */
+
+// All lanes of a wave are at the same read position, so the header of that position's PDF is one value
+// per wave.  Through the vector memory path it still costs a full load per field group (the compiler cannot
+// use scalar loads next to the kernel's byte stores), and those loads kept the address unit busy for the
+// whole kernel; from LDS it is a broadcast read.
+SIMMR_DEV void stage_pdf_headers(const CustomDev& C, PdfDev* __restrict__ s_pdfs) {
+  const uint32_t n = (2u + C.n_quality) < CUSTOM_LDS_PDFS ? (2u + C.n_quality) : CUSTOM_LDS_PDFS;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_pdfs[i] = C.pdfs[i];
+  __syncthreads();
+}
+// the PDF of read position p: min(p, n_quality - 1) (custom_short.rs:339-345)
+SIMMR_DEV PdfDev quality_pdf(const CustomDev& C, const PdfDev* __restrict__ s_pdfs, uint32_t p) {
+  const uint32_t pi = 2u + (p < C.n_quality ? p : C.n_quality - 1u);
+  return pi < CUSTOM_LDS_PDFS ? s_pdfs[pi] : C.pdfs[pi];
+}
 
 template <bool HAS_EXC>
 __global__ void __launch_bounds__(256)
@@ -2175,8 +2191,10 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
                  uint32_t qual_offset, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
   __shared__ uint32_t asc[256];  // four 2-bit codes -> four ASCII bytes
   __shared__ uint32_t words[256][CUSTOM2_WORDS + 1];  // per lane: first block of its stream (general routine only)
+  __shared__ PdfDev s_pdfs[CUSTOM_LDS_PDFS];  // PDF headers: wave-uniform reads from LDS instead of the vector memory path
   const GenomeDev G = genomes[genome];
   const CustomDev C = prof.custom;
+  stage_pdf_headers(C, s_pdfs);
   {
     const uint32_t t = threadIdx.x;
     const uint32_t acgt = 0x54474341u;  // "ACGT"
@@ -2217,7 +2235,7 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
       for (uint32_t j = 0; j < 16; j++) {
         // wave-uniform: position b0 + j samples PDF min(position, n_quality - 1) (custom_short.rs:339-350)
         const uint32_t p = b0 + j;
-        const PdfDev pdf = C.pdfs[2 + (p < C.n_quality ? p : C.n_quality - 1)];
+        const PdfDev pdf = quality_pdf(C, s_pdfs, p);
         if (j >= n) continue;
         const uint64_t m = (uint64_t)w0 * pdf.n;
         uint32_t q = 0;
@@ -2329,7 +2347,9 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
                    const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ qual, uint32_t qual_offset,
                    unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
   __shared__ uint32_t words[256][CUSTOM2_WORDS + 1];
+  __shared__ PdfDev s_pdfs[CUSTOM_LDS_PDFS];
   const CustomDev C = prof.custom;
+  stage_pdf_headers(C, s_pdfs);
   uint64_t qsum = 0;
   bool bad = false;
   const uint32_t qoff = qual_offset & 0xffu;
@@ -2375,7 +2395,7 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
         return q & 0xffu;  // `as u8`
       };
       uint32_t q_last = 0;  // the value of every position >= n_quality - 1 (custom_short.rs:339-350)
-      if (n >= C.n_quality) q_last = sample(C.pdfs[2 + C.n_quality - 1]);
+      if (n >= C.n_quality) q_last = sample(quality_pdf(C, s_pdfs, C.n_quality - 1u));
       const uint64_t fill = ((q_last + qoff) & 0xffu) * 0x0101010101010101ULL;
       // positions below b_fill (the first 16-group that lies entirely at or after n_quality - 1) are sampled one by
       // one, lane per read; the constant rest of every read is then written by the whole wave, 1 KB per store
@@ -2387,7 +2407,7 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
         {
           for (uint32_t j = 0; j < 16; j++) {
             const uint32_t p = b0 + j;
-            const PdfDev pdf = C.pdfs[2 + (p < C.n_quality ? p : C.n_quality - 1)];
+            const PdfDev pdf = quality_pdf(C, s_pdfs, p);
             if (j >= cnt) continue;
             const uint32_t q = sample(pdf);
             qsum += q;
