@@ -1155,7 +1155,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->u_seed.as<uint64_t>(), out->seq, counters, e->d_err.as<uint32_t>());
     } else if (e->prof.kind == SIMMR_K_CUSTOM) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
-      const uint64_t blocks = (n_reads + 255) / 256;
+      const uint64_t blocks = (n_units + 255) / 256;  // one lane per pair
       const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
       auto kern = e->plan_any_exc ? k_emit_custom_pe<true> : k_emit_custom_pe<false>;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),

@@ -1919,6 +1919,14 @@ SIMMR_DEV uint32_t add_bytes(uint32_t a, uint32_t b) {
 SIMMR_DEV uint32_t low_bytes(uint32_t x, int nb) {
   return nb >= 4 ? x : (nb <= 0 ? 0u : (x & ((1u << (8 * nb)) - 1u)));
 }
+// one 16-byte store at any byte address (global_store_dwordx4; one address-unit access per lane instead of two)
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef v4u32 __attribute__((aligned(1))) v4u32_unaligned;
+SIMMR_DEV void store16(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi) {
+  v4u32 v;
+  v.x = (uint32_t)lo; v.y = (uint32_t)(lo >> 32); v.z = (uint32_t)hi; v.w = (uint32_t)(hi >> 32);
+  *reinterpret_cast<v4u32_unaligned*>(d) = v;
+}
 // store the low n (< 16) bytes of the 128-bit value (lo, hi)
 SIMMR_DEV void store_tail(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi, uint32_t n) {
   uint64_t v = lo;
@@ -2190,7 +2198,6 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
                  const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
                  uint32_t qual_offset, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
   __shared__ uint32_t asc[256];  // four 2-bit codes -> four ASCII bytes
-  __shared__ uint32_t words[256][CUSTOM2_WORDS + 1];  // per lane: first block of its stream (general routine only)
   __shared__ PdfDev s_pdfs[CUSTOM_LDS_PDFS];  // PDF headers: wave-uniform reads from LDS instead of the vector memory path
   const GenomeDev G = genomes[genome];
   const CustomDev C = prof.custom;
@@ -2206,97 +2213,140 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
   uint32_t n_acgt = 0;
   bool bad = false;
   const uint32_t qoff = qual_offset & 0xffu;
-  const uint64_t n_reads = 2 * n_units;
-  uint32_t* const row = words[threadIdx.x];
-  for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n_reads; r0 += (uint64_t)gridDim.x * 256) {
-    const uint64_t r = r0 + threadIdx.x;
-    const bool live_read = r < n_reads;
-    uint32_t L = 0, rev = 0;
-    uint64_t off = 0, src0 = 0, key = 0;
-    if (live_read) {
-      const uint64_t u = r >> 1;
-      rev = (uint32_t)(r & 1u);
+  const uint32_t lane = threadIdx.x & 63u;
+  // One lane per PAIR: both mates have the same length, so they are at the same position, i.e. the same PDF, at
+  // the same time, and one read of the PDF's tables serves 128 reads.
+  for (uint64_t u0 = (uint64_t)blockIdx.x * 256; u0 < n_units; u0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t u = u0 + threadIdx.x;
+    uint32_t L = 0;
+    uint64_t off = 0, src0[2] = {0, 0}, key[2] = {0, 0};
+    if (u < n_units) {
       L = pl.len[u];
-      off = u_off[u] + (rev ? L : 0u);
-      src0 = G.contigs[u_contig[u]].base + (rev ? pl.b[u] : pl.a[u]);
-      key = rev ? pl.qs2[u] : u_seed[u];  // simulate.rs:262,266: StdRng(pe_seed) / StdRng(drawn seed)
+      off = u_off[u];  // mate 1 at off, mate 2 at off + L
+      const uint64_t base = G.contigs[u_contig[u]].base;
+      src0[0] = base + pl.a[u];
+      src0[1] = base + pl.b[u];
+      key[0] = u_seed[u];   // simulate.rs:262: StdRng(pe_seed)
+      key[1] = pl.qs2[u];   // simulate.rs:266: StdRng(the drawn seed)
     }
-    uint32_t o[16];
-    chacha12_block(pcg32_expand(key), 0, o);
+    uint32_t w0[2], w3[2];
+    double v01[2];
 #pragma unroll
-    for (int i = 0; i < 16; i++) row[i] = o[i];
-    const uint32_t w0 = o[0], w3 = o[3];
-    const double v01 = __longlong_as_double((long long)(((((uint64_t)o[2] << 32) | o[1]) >> 12) | 0x3FF0000000000000ULL)) - 1.0;
+    for (int m = 0; m < 2; m++) {
+      uint32_t o[16];
+      chacha12_block(pcg32_expand(key[m]), 0, o);
+      w0[m] = o[0]; w3[m] = o[3];
+      v01[m] = __longlong_as_double((long long)(((((uint64_t)o[2] << 32) | o[1]) >> 12) | 0x3FF0000000000000ULL)) - 1.0;
+    }
     for (uint32_t b0 = 0; __any(b0 < L); b0 += 16) {
-      if (b0 >= L) continue;
-      const uint32_t n = (L - b0) < 16u ? (L - b0) : 16u;
-      uint64_t q_lo = 0, q_hi = 0;
-#pragma unroll 4
+      // no lane leaves the position loop early: every lane holds a slice of the current PDF's tables
+      const uint32_t n = b0 >= L ? 0u : ((L - b0) < 16u ? (L - b0) : 16u);
+      uint64_t q_lo[2] = {0, 0}, q_hi[2] = {0, 0};
+#pragma unroll 2
       for (uint32_t j = 0; j < 16; j++) {
+        if (!__any(j < n)) break;
         // wave-uniform: position b0 + j samples PDF min(position, n_quality - 1) (custom_short.rs:339-350)
-        const uint32_t p = b0 + j;
-        const PdfDev pdf = quality_pdf(C, s_pdfs, p);
-        if (j >= n) continue;
-        const uint64_t m = (uint64_t)w0 * pdf.n;
-        uint32_t q = 0;
-        bool fast = (uint32_t)m <= pdf.idx_zone;
-        if (fast) {
-          const uint32_t col = (uint32_t)(m >> 32);
-          const Rec16 cr = C.col_rec[pdf.off + col];  // {odds, alias}
-          const double odds = __longlong_as_double((long long)(((uint64_t)cr.y << 32) | cr.x));
-          const uint32_t bin = (__dmul_rn(v01, pdf.w_scale) < odds) ? col : cr.z;
-          fast = bin < pdf.n_bins;
-          if (fast) {
-            const Rec16 br = C.bin_rec[pdf.off_bins + bin];  // {range, zone, low}
-            const uint64_t m2 = (uint64_t)w3 * br.x;
-            if (br.x == 0) q = w3;
-            else if ((uint32_t)m2 <= br.y) q = br.z + (uint32_t)(m2 >> 32);
+        const PdfDev pdf = quality_pdf(C, s_pdfs, b0 + j);
+        const bool narrow = pdf.n <= 128u && pdf.n_bins <= 128u;  // wave-uniform
+        // The PDF's tables are read ONCE per wave, lane l taking entries l and 64 + l (coalesced), and every lane
+        // then fetches its own column / bin from the lane that holds it (ds_bpermute): a 64-lane gather costs the
+        // address unit one access per lane, and two of them per position and read were what bounded this kernel.
+        Rec16 c0 = {0u, 0u, 0u, 0u}, c1 = c0, k0 = c0, k1 = c0;
+        if (narrow) {
+          if (lane < pdf.n) c0 = C.col_rec[pdf.off + lane];
+          if (lane + 64u < pdf.n) c1 = C.col_rec[pdf.off + 64u + lane];
+          if (lane < pdf.n_bins) k0 = C.bin_rec[pdf.off_bins + lane];
+          if (lane + 64u < pdf.n_bins) k1 = C.bin_rec[pdf.off_bins + 64u + lane];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          const uint64_t mm = (uint64_t)w0[m] * pdf.n;
+          const uint32_t col = (uint32_t)(mm >> 32);  // < pdf.n
+          uint32_t q = 0;
+          bool fast = (uint32_t)mm <= pdf.idx_zone;
+          if (narrow) {
+            const int sc = (int)((col & 63u) << 2);
+            uint32_t ox = (uint32_t)__builtin_amdgcn_ds_bpermute(sc, (int)c0.x), oy = (uint32_t)__builtin_amdgcn_ds_bpermute(sc, (int)c0.y),
+                     oz = (uint32_t)__builtin_amdgcn_ds_bpermute(sc, (int)c0.z);
+            if (pdf.n > 64u) {  // wave-uniform
+              const uint32_t x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sc, (int)c1.x), y1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sc, (int)c1.y),
+                             z1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sc, (int)c1.z);
+              if (col >= 64u) { ox = x1; oy = y1; oz = z1; }
+            }
+            const double odds = __longlong_as_double((long long)(((uint64_t)oy << 32) | ox));  // {odds, alias}
+            const uint32_t bin = (__dmul_rn(v01[m], pdf.w_scale) < odds) ? col : oz;
+            fast = fast && bin < pdf.n_bins;
+            const int sk = (int)((bin & 63u) << 2);
+            uint32_t rx = (uint32_t)__builtin_amdgcn_ds_bpermute(sk, (int)k0.x), ry = (uint32_t)__builtin_amdgcn_ds_bpermute(sk, (int)k0.y),
+                     rz = (uint32_t)__builtin_amdgcn_ds_bpermute(sk, (int)k0.z);
+            if (pdf.n_bins > 64u) {  // wave-uniform
+              const uint32_t x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sk, (int)k1.x), y1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sk, (int)k1.y),
+                             z1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sk, (int)k1.z);
+              if ((bin & 127u) >= 64u) { rx = x1; ry = y1; rz = z1; }
+            }
+            const uint64_t m2 = (uint64_t)w3[m] * rx;  // {range, zone, low}
+            if (rx == 0) q = w3[m];
+            else if ((uint32_t)m2 <= ry) q = rz + (uint32_t)(m2 >> 32);
             else fast = false;
+          } else if (fast) {  // tables wider than two entries per lane: gather
+            const Rec16 cr = C.col_rec[pdf.off + col];
+            const double odds = __longlong_as_double((long long)(((uint64_t)cr.y << 32) | cr.x));
+            const uint32_t bin = (__dmul_rn(v01[m], pdf.w_scale) < odds) ? col : cr.z;
+            fast = bin < pdf.n_bins;
+            if (fast) {
+              const Rec16 br = C.bin_rec[pdf.off_bins + bin];
+              const uint64_t m2 = (uint64_t)w3[m] * br.x;
+              if (br.x == 0) q = w3[m];
+              else if ((uint32_t)m2 <= br.y) q = br.z + (uint32_t)(m2 >> 32);
+              else fast = false;
+            }
+          }
+          if (j < n) {
+            // a rejected word or a bin without a range: the general routine on the stream itself (and its error reporting)
+            if (!fast) q = pdf_sample_stream(key[m], C, pdf, &bad);
+            q &= 0xffu;  // `as u8`
+            qsum += q;
+            const uint64_t enc = (q + qoff) & 0xffu;
+            if (j < 8u) q_lo[m] |= enc << (8u * j); else q_hi[m] |= enc << (8u * (j - 8u));
           }
         }
-        if (!fast) {  // a rejected word or a bin without a range: the general routine (and its error reporting)
-          bool ovf = false;
-          q = pdf_sample_words(row, CUSTOM2_WORDS, C, pdf, &bad, &ovf);
-          if (ovf) q = pdf_sample_stream(key, C, pdf, &bad);
-        }
-        q &= 0xffu;  // `as u8`
-        qsum += q;
-        const uint64_t enc = (q + qoff) & 0xffu;
-        if (j < 8u) q_lo |= enc << (8u * j); else q_hi |= enc << (8u * (j - 8u));
       }
+      if (n == 0u) continue;
       // bases: a plain copy (simulate_point_mutations is the identity, custom_short.rs:522-529), mate 2
       // reverse-complemented (simulate.rs:283)
-      const uint64_t src = src0 + b0;
-      uint32_t codes = fetch_codes16(G.packed, (int64_t)src);
-      uint32_t exc = 0u;
-      if (HAS_EXC) exc = fetch_mask16(G.mask, (int64_t)src);
-      const uint32_t live = n >= 16u ? 0xffffu : ((1u << n) - 1u);
-      n_acgt += __builtin_popcount(~exc & live);
-      uint8_t* qd = qual + off + b0;
-      uint8_t* sd = seq + off + b0;
-      if (rev) {
-        codes = ~reverse_groups16(codes);
-        if (HAS_EXC) { exc = __builtin_bitreverse32(exc) >> 16; codes ^= spread16(exc); }
-        const uint32_t dead = 16u - n;
-        if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
-        sd = seq + off + (L - b0 - n);
-      }
-      uint32_t s0, s1, s2, s3;
-      if (HAS_EXC) {
-        s0 = expand4(codes & 0xffu, exc & 0xfu); s1 = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
-        s2 = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu); s3 = expand4(codes >> 24, (exc >> 12) & 0xfu);
-      } else {
-        s0 = asc[codes & 0xffu]; s1 = asc[(codes >> 8) & 0xffu]; s2 = asc[(codes >> 16) & 0xffu]; s3 = asc[codes >> 24];
-      }
-      const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
-      if (n == 16u) {
-        *reinterpret_cast<u64_unaligned*>(qd) = q_lo;
-        *reinterpret_cast<u64_unaligned*>(qd + 8) = q_hi;
-        *reinterpret_cast<u64_unaligned*>(sd) = s_lo;
-        *reinterpret_cast<u64_unaligned*>(sd + 8) = s_hi;
-      } else {
-        store_tail(qd, q_lo, q_hi, n);
-        store_tail(sd, s_lo, s_hi, n);
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        const uint64_t src = src0[m] + b0;
+        uint32_t codes = fetch_codes16(G.packed, (int64_t)src);
+        uint32_t exc = 0u;
+        if (HAS_EXC) exc = fetch_mask16(G.mask, (int64_t)src);
+        const uint32_t live = n >= 16u ? 0xffffu : ((1u << n) - 1u);
+        n_acgt += __builtin_popcount(~exc & live);
+        const uint64_t roff = off + (m ? L : 0u);
+        uint8_t* qd = qual + roff + b0;
+        uint8_t* sd = seq + roff + b0;
+        if (m) {
+          codes = ~reverse_groups16(codes);
+          if (HAS_EXC) { exc = __builtin_bitreverse32(exc) >> 16; codes ^= spread16(exc); }
+          const uint32_t dead = 16u - n;
+          if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
+          sd = seq + roff + (L - b0 - n);
+        }
+        uint32_t s0, s1, s2, s3;
+        if (HAS_EXC) {
+          s0 = expand4(codes & 0xffu, exc & 0xfu); s1 = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
+          s2 = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu); s3 = expand4(codes >> 24, (exc >> 12) & 0xfu);
+        } else {
+          s0 = asc[codes & 0xffu]; s1 = asc[(codes >> 8) & 0xffu]; s2 = asc[(codes >> 16) & 0xffu]; s3 = asc[codes >> 24];
+        }
+        const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
+        if (n == 16u) {
+          store16(qd, q_lo[m], q_hi[m]);
+          store16(sd, s_lo, s_hi);
+        } else {
+          store_tail(qd, q_lo[m], q_hi[m], n);
+          store_tail(sd, s_lo, s_hi, n);
+        }
       }
     }
   }
