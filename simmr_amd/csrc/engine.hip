@@ -1134,7 +1134,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       bool exc = false;
       if (paired) exc = e->plan_any_exc;
       else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
-      auto kern = exc ? k_emit_philox<true> : k_emit_philox<false>;
+      auto kern = exc ? k_emit_philox<true, false> : k_emit_philox<false, false>;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
                          e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                          e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
@@ -1157,11 +1157,18 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
       const uint64_t blocks = (n_units + 255) / 256;  // one lane per pair
       const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
-      auto kern = e->plan_any_exc ? k_emit_custom_pe<true> : k_emit_custom_pe<false>;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
+      // qualities: one lane per pair (k_emit_custom_pe); bases: the item kernel without draws (coalesced stores)
+      hipLaunchKernelGGL(k_emit_custom_pe<false>, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
                          e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset, counters,
                          e->d_err.as<uint32_t>());
+      const uint64_t cblocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
+      const uint32_t cgrid = (uint32_t)std::min<uint64_t>(cblocks, (uint64_t)e->n_cu * 8);
+      auto copy = e->plan_any_exc ? k_emit_philox<true, true> : k_emit_philox<false, true>;
+      hipLaunchKernelGGL(copy, dim3(cgrid), dim3(256), 0, e->stream, e->prof, 1u, e->d_genomes.as<GenomeDev>(),
+                         e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
+                         (const uint32_t*)nullptr, e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset,
+                         e->plan_first, read_id_base, out_cols(out), counters);
     } else if (e->emit_variant == 0) {
       // lane-per-read kernel: template on (exception plane present, paired, perfect-long Phred)
       bool exc = false;

@@ -1937,7 +1937,9 @@ SIMMR_DEV void store_tail(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi, uin
   if (n & 1u) d[p] = (uint8_t)v;
 }
 
-template <bool HAS_EXC>
+// COPY_ONLY: the same item machinery without the draws: bases of the planned reads (mate 2 reverse-complemented)
+// with coalesced stores, for the profiles whose qualities another kernel writes (custom-short).
+template <bool HAS_EXC, bool COPY_ONLY>
 __global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
@@ -1963,7 +1965,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   {
     const uint32_t t = threadIdx.x;
 #pragma unroll
-    for (uint32_t i = t; i < 1024u; i += 256u) {
+    for (uint32_t i = t; !COPY_ONLY && i < 1024u; i += 256u) {
       const uint32_t e = prof.philox_phred[i];
       const uint32_t al = e >> 22;
       jtab[i] = make_uint2((i << 22) | (e & 0x3fffffu), ((((i + qual_offset) & 0xffu) << 8) | (i >> 8)) |
@@ -2009,26 +2011,28 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       r_len[t] = L | (rev << 31);
       r_packed[t] = G->packed;
       r_mask[t] = (HAS_EXC && G->has_exc) ? G->mask : nullptr;
-      // metadata columns of this read (the other emit kernels leave them to k_write_meta)
-      const uint64_t rd = paired ? 2 * u + rev : u;
-      const uint32_t fl = pl.flags[u];
-      o.seq_off[rd] = dst;
-      if (rd + 1 == n_reads) o.seq_off[n_reads] = u_off[n_units];  // closing CSR offset
-      if (paired) {
-        if (o.start) o.start[rd] = rev ? pos + L : pos;  // simulate.rs:289,295
-        if (o.end) o.end[rd] = rev ? pos : pos + L;      // simulate.rs:290,296
-      } else {
-        if (o.start) o.start[rd] = pos;                  // simulate.rs:515
-        if (o.end) o.end[rd] = pl.b[u];                  // simulate.rs:516
-      }
-      if (o.contig) o.contig[rd] = contig;
-      if (o.genome) o.genome[rd] = u_genome ? u_genome[u] : genome_const;
-      if (o.read_id) o.read_id[rd] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
-      if (o.flags) o.flags[rd] = (paired && !rev) ? 0 : (uint8_t)fl;
-      if (!rev) {
-        p_bases += pl.bytes[u];
-        p_redrawn += (fl & SIMMR_FLAG_REDRAWN) ? 1u : 0u;
-        p_seedsubst += ((fl & SIMMR_FLAG_QSEED_SUBST) ? 1u : 0u) + ((fl & SIMMR_FLAG_MSEED_SUBST) ? 1u : 0u);
+      if (!COPY_ONLY) {
+        // metadata columns of this read (the other emit kernels leave them to k_write_meta)
+        const uint64_t rd = paired ? 2 * u + rev : u;
+        const uint32_t fl = pl.flags[u];
+        o.seq_off[rd] = dst;
+        if (rd + 1 == n_reads) o.seq_off[n_reads] = u_off[n_units];  // closing CSR offset
+        if (paired) {
+          if (o.start) o.start[rd] = rev ? pos + L : pos;  // simulate.rs:289,295
+          if (o.end) o.end[rd] = rev ? pos : pos + L;      // simulate.rs:290,296
+        } else {
+          if (o.start) o.start[rd] = pos;                  // simulate.rs:515
+          if (o.end) o.end[rd] = pl.b[u];                  // simulate.rs:516
+        }
+        if (o.contig) o.contig[rd] = contig;
+        if (o.genome) o.genome[rd] = u_genome ? u_genome[u] : genome_const;
+        if (o.read_id) o.read_id[rd] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
+        if (o.flags) o.flags[rd] = (paired && !rev) ? 0 : (uint8_t)fl;
+        if (!rev) {
+          p_bases += pl.bytes[u];
+          p_redrawn += (fl & SIMMR_FLAG_REDRAWN) ? 1u : 0u;
+          p_seedsubst += ((fl & SIMMR_FLAG_QSEED_SUBST) ? 1u : 0u) + ((fl & SIMMR_FLAG_MSEED_SUBST) ? 1u : 0u);
+        }
       }
     }
     uint32_t n_items;
@@ -2061,7 +2065,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       // per base: one word -> (Phred, substitution shift s); qualities packed as bytes, s as 2-bit fields
       uint32_t qr[4] = {0, 0, 0, 0}, ss = 0;
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
+      for (int c = 0; !COPY_ONLY && c < 4; c++) {
         uint32_t w[4];
         philox4x32_10((b0 >> 2) + (uint32_t)c, (uint32_t)key, (uint32_t)(key >> 32), w);
 #pragma unroll
@@ -2090,13 +2094,15 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       ss &= live2;
       n_subst += __builtin_popcount((ss | (ss >> 1)) & 0x55555555u);
       n_acgt += HAS_EXC ? __builtin_popcount(~spread16(exc) & live2 & 0x55555555u) : n;
-      uint32_t qs = __builtin_amdgcn_sad_u8(qr[0] & bm.x, 0u, 0u);
-      qs = __builtin_amdgcn_sad_u8(qr[1] & bm.y, 0u, qs);
-      qs = __builtin_amdgcn_sad_u8(qr[2] & bm.z, 0u, qs);
-      qs = __builtin_amdgcn_sad_u8(qr[3] & bm.w, 0u, qs);
-      qsum += qs;
-      n_live += n;
-      if (!q_nowrap) {
+      if (!COPY_ONLY) {
+        uint32_t qs = __builtin_amdgcn_sad_u8(qr[0] & bm.x, 0u, 0u);
+        qs = __builtin_amdgcn_sad_u8(qr[1] & bm.y, 0u, qs);
+        qs = __builtin_amdgcn_sad_u8(qr[2] & bm.z, 0u, qs);
+        qs = __builtin_amdgcn_sad_u8(qr[3] & bm.w, 0u, qs);
+        qsum += qs;
+        n_live += n;
+      }
+      if (!COPY_ONLY && !q_nowrap) {
         for (uint32_t j = 0; j < n; j++) n_wrap += ((qr[j >> 2] >> (8 * (j & 3u))) & 0xffu) < qoff ? 1u : 0u;
       }
       // substitutions in the 2-bit code domain: code' = (code + s) mod 4, 16 bases at once
@@ -2124,12 +2130,14 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       }
       const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
       if (n == 16u) {
-        *reinterpret_cast<u64_unaligned*>(qd) = q_lo;
-        *reinterpret_cast<u64_unaligned*>(qd + 8) = q_hi;
+        if (!COPY_ONLY) {
+          *reinterpret_cast<u64_unaligned*>(qd) = q_lo;
+          *reinterpret_cast<u64_unaligned*>(qd + 8) = q_hi;
+        }
         *reinterpret_cast<u64_unaligned*>(sd) = s_lo;
         *reinterpret_cast<u64_unaligned*>(sd + 8) = s_hi;
       } else {
-        store_tail(qd, q_lo, q_hi, n);
+        if (!COPY_ONLY) store_tail(qd, q_lo, q_hi, n);
         store_tail(sd, s_lo, s_hi, n);
       }
     }
@@ -2142,6 +2150,10 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     p_bases += __shfl_down(p_bases, d, 64);
     p_redrawn += __shfl_down(p_redrawn, d, 64);
     p_seedsubst += __shfl_down(p_seedsubst, d, 64);
+  }
+  if (COPY_ONLY) {
+    if ((threadIdx.x & 63u) == 0 && counters) atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
+    return;
   }
   if ((threadIdx.x & 63u) == 0 && counters) {
     atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
@@ -2210,7 +2222,6 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
   }
   __syncthreads();
   uint64_t qsum = 0;
-  uint32_t n_acgt = 0;
   bool bad = false;
   const uint32_t qoff = qual_offset & 0xffu;
   const uint32_t lane = threadIdx.x & 63u;
@@ -2312,53 +2323,19 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
         }
       }
       if (n == 0u) continue;
-      // bases: a plain copy (simulate_point_mutations is the identity, custom_short.rs:522-529), mate 2
-      // reverse-complemented (simulate.rs:283)
+      // the bases (a plain copy, mate 2 reverse-complemented: custom_short.rs:522-529, simulate.rs:283) are written by
+      // k_emit_philox<.., COPY_ONLY>, whose lanes are consecutive 16-byte pieces of the output
 #pragma unroll
       for (int m = 0; m < 2; m++) {
-        const uint64_t src = src0[m] + b0;
-        uint32_t codes = fetch_codes16(G.packed, (int64_t)src);
-        uint32_t exc = 0u;
-        if (HAS_EXC) exc = fetch_mask16(G.mask, (int64_t)src);
-        const uint32_t live = n >= 16u ? 0xffffu : ((1u << n) - 1u);
-        n_acgt += __builtin_popcount(~exc & live);
-        const uint64_t roff = off + (m ? L : 0u);
-        uint8_t* qd = qual + roff + b0;
-        uint8_t* sd = seq + roff + b0;
-        if (m) {
-          codes = ~reverse_groups16(codes);
-          if (HAS_EXC) { exc = __builtin_bitreverse32(exc) >> 16; codes ^= spread16(exc); }
-          const uint32_t dead = 16u - n;
-          if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
-          sd = seq + roff + (L - b0 - n);
-        }
-        uint32_t s0, s1, s2, s3;
-        if (HAS_EXC) {
-          s0 = expand4(codes & 0xffu, exc & 0xfu); s1 = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
-          s2 = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu); s3 = expand4(codes >> 24, (exc >> 12) & 0xfu);
-        } else {
-          s0 = asc[codes & 0xffu]; s1 = asc[(codes >> 8) & 0xffu]; s2 = asc[(codes >> 16) & 0xffu]; s3 = asc[codes >> 24];
-        }
-        const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
-        if (n == 16u) {
-          store16(qd, q_lo[m], q_hi[m]);
-          store16(sd, s_lo, s_hi);
-        } else {
-          store_tail(qd, q_lo[m], q_hi[m], n);
-          store_tail(sd, s_lo, s_hi, n);
-        }
+        uint8_t* qd = qual + off + (m ? L : 0u) + b0;
+        if (n == 16u) store16(qd, q_lo[m], q_hi[m]);
+        else store_tail(qd, q_lo[m], q_hi[m], n);
       }
     }
   }
   if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
-  for (int d = 32; d > 0; d >>= 1) {
-    n_acgt += __shfl_down(n_acgt, d, 64);
-    qsum += __shfl_down(qsum, d, 64);
-  }
-  if ((threadIdx.x & 63u) == 0 && counters) {
-    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
-    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
-  }
+  for (int d = 32; d > 0; d >>= 1) qsum += __shfl_down(qsum, d, 64);
+  if ((threadIdx.x & 63u) == 0 && counters) atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
 }
 
 // ===========================================================================
