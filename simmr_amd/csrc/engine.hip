@@ -1158,7 +1158,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       const uint64_t blocks = (n_units + 255) / 256;  // one lane per pair
       const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
       // qualities: one lane per pair (k_emit_custom_pe); bases: the item kernel without draws (coalesced stores)
-      hipLaunchKernelGGL(k_emit_custom_pe<false>, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
+      hipLaunchKernelGGL(k_emit_custom_pe, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
                          e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset, counters,
                          e->d_err.as<uint32_t>());

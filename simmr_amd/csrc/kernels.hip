@@ -2172,17 +2172,19 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 // simulate_phred_scores re-seeds the SAME StdRng at every position, so every
 // quality of a read is a function of the first few words of one stream (w0 picks
 // the alias column, (w1, w2) the f64 against the column's odds, w3 the score
-// inside the bin) and of the position's PDF.  One lane per read (mate): it
-// generates the first ChaCha12 block of its stream once and then walks its read
-// in groups of 16 positions.  All lanes of a wave are at the same group, i.e.
-// at the same 16 PDFs: the PDF headers are wave-uniform loads and the alias /
-// bin tables of one PDF are a few cache lines, instead of 64 different lines
-// per load (the item form dealt "16 positions of one read" to lanes like
-// k_emit_philox and was bound by exactly those scattered table loads: 26 ms
-// per 20 M reads).  Bases are copied in the code domain (mate 2 complement-
-// reversed) and both streams leave as 16-byte stores.  A sample whose words
-// are rejected (rare) goes through the general routine, and one that would run
-// past the 16 staged words is drawn again from the stream itself, so the
+// inside the bin) and of the position's PDF.  One lane per PAIR: it generates
+// the first ChaCha12 block of both mates' streams once and then walks the two
+// reads (same length, hence the same position at the same time) in groups of
+// 16 positions.  All lanes of a wave are at the same position, i.e. the same
+// PDF: its header comes from LDS, its tables are read once per wave (lane l
+// holds entries l and 64 + l) and every lane fetches its column / bin with
+// ds_bpermute.  (The item form dealt "16 positions of one read" to lanes like
+// k_emit_philox and was bound by scattered table loads, 26 ms per 20 M reads;
+// one lane per read with two 64-lane gathers per position kept the address
+// unit busy for the whole kernel, 14.4 ms.)  The kernel writes qualities only:
+// the bases are a plain copy (mate 2 complement-reversed) and come from
+// k_emit_philox<.., COPY_ONLY>, whose stores are coalesced.  A sample whose
+// words are rejected (rare) is drawn again from the stream itself, so the
 // result is exact in every case.
 // ===========================================================================
 #define CUSTOM2_WORDS 16u
@@ -2203,24 +2205,15 @@ SIMMR_DEV PdfDev quality_pdf(const CustomDev& C, const PdfDev* __restrict__ s_pd
   return pi < CUSTOM_LDS_PDFS ? s_pdfs[pi] : C.pdfs[pi];
 }
 
-template <bool HAS_EXC>
-__global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256)
 k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
                  PlanArrays pl, const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
                  const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
                  uint32_t qual_offset, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
-  __shared__ uint32_t asc[256];  // four 2-bit codes -> four ASCII bytes
   __shared__ PdfDev s_pdfs[CUSTOM_LDS_PDFS];  // PDF headers: wave-uniform reads from LDS instead of the vector memory path
   const GenomeDev G = genomes[genome];
   const CustomDev C = prof.custom;
   stage_pdf_headers(C, s_pdfs);
-  {
-    const uint32_t t = threadIdx.x;
-    const uint32_t acgt = 0x54474341u;  // "ACGT"
-    asc[t] = ((acgt >> (8 * (t & 3u))) & 0xffu) | (((acgt >> (8 * ((t >> 2) & 3u))) & 0xffu) << 8) |
-             (((acgt >> (8 * ((t >> 4) & 3u))) & 0xffu) << 16) | (((acgt >> (8 * (t >> 6))) & 0xffu) << 24);
-  }
-  __syncthreads();
   uint64_t qsum = 0;
   bool bad = false;
   const uint32_t qoff = qual_offset & 0xffu;
