@@ -844,6 +844,8 @@ k_write_meta(uint32_t paired, uint64_t n_units, uint64_t first_unit, uint32_t re
 // The planes live in device memory: say so (a pointer that came out of a struct or out of LDS is a
 // generic pointer, and a flat load is slower than a global one).
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef v4u32 __attribute__((aligned(1))) v4u32_unaligned;
 typedef const __attribute__((address_space(1))) u64_unaligned* global_u64_unaligned_ptr;
 SIMMR_DEV uint64_t load_plane_u64(const uint32_t* __restrict__ plane, int64_t word) {
   return *(global_u64_unaligned_ptr)(plane + word);  // words `word` and `word + 1`, 4-byte aligned
@@ -1688,8 +1690,8 @@ struct LaneM {
   uint32_t st;      // 0 FRESH, 1 CHOOSE (base i mutates, waiting for an accepted u32)
   uint32_t creg;    // 16 reference codes of bases (i & ~15) ..
   uint32_t ereg;    // their exception bits
-  uint64_t qreg;    // 8 qualities of bases (i & ~7) ..
-  uint64_t qnext;   // prefetched: the following 8 qualities
+  uint64_t qreg, qreg2;    // 16 qualities of bases (i & ~15) ..
+  uint64_t qnext, qnext2;  // prefetched: the following 16 qualities
   uint32_t cnext, enext;  // prefetched: the following 16 codes / exception bits
   uint32_t n_subst, n_acgt;
   uint32_t lut;     // "ACGT", or "TGCA" for mate 2 (complemented; written back to front)
@@ -1720,6 +1722,18 @@ SIMMR_DEV uint64_t load_q8(const uint8_t* __restrict__ qsrc, uint32_t i, uint32_
   return load_q_tail(qsrc, i, L);
 }
 
+// 16 qualities from byte i on: one 16-byte load (global_load_dwordx4 at any byte address) away from the read's end
+SIMMR_DEV void load_q16(const uint8_t* __restrict__ qsrc, uint32_t i, uint32_t L, uint64_t& lo, uint64_t& hi) {
+  if (i + 16u <= L) {
+    const v4u32 v = *reinterpret_cast<const v4u32_unaligned*>(qsrc + i);
+    lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+  } else {
+    lo = load_q8(qsrc, i, L);
+    hi = load_q8(qsrc, i + 8u, L);
+  }
+}
+
 template <bool HAS_EXC>
 SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const uint32_t* __restrict__ packed,
                       const uint32_t* __restrict__ mask, uint64_t src,
@@ -1728,14 +1742,16 @@ SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const uint
   if (s.st == 0) {
     const uint32_t i = s.i;
     // registers are refilled one chunk ahead so the loads overlap the steps
-    if ((i & 7u) == 0) { s.qreg = s.qnext; s.qnext = load_q8(qsrc, i + 8, L); }
     if ((i & 15u) == 0) {
+      s.qreg = s.qnext; s.qreg2 = s.qnext2;
+      load_q16(qsrc, i + 16, L, s.qnext, s.qnext2);
       s.creg = s.cnext;
       s.cnext = fetch_codes16(packed, (int64_t)(src + i + 16));
       if (HAS_EXC) { s.ereg = s.enext; s.enext = mask ? fetch_mask16(mask, (int64_t)(src + i + 16)) : 0u; }
     }
     // byte (i & 7) of qreg, zero-extended, in one v_perm_b32
-    const uint32_t q = (__builtin_amdgcn_perm((uint32_t)(s.qreg >> 32), (uint32_t)s.qreg, (i & 7u) | 0x0c0c0c00u) - qoff) & 0xffu;
+    const uint64_t qh = (i & 8u) ? s.qreg2 : s.qreg;
+    const uint32_t q = (__builtin_amdgcn_perm((uint32_t)(qh >> 32), (uint32_t)qh, (i & 7u) | 0x0c0c0c00u) - qoff) & 0xffu;
     uint32_t code = (s.creg >> (2 * (i & 15u))) & 3u;
     uint32_t exc = 0;
     if (HAS_EXC) {
@@ -1830,14 +1846,14 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
     {
       const Key key = pcg32_expand(seed_m);
       LaneM s;
-      s.i = 0; s.st = 0; s.creg = 0; s.ereg = 0; s.qreg = 0; s.n_subst = 0; s.n_acgt = 0;
+      s.i = 0; s.st = 0; s.creg = 0; s.ereg = 0; s.qreg = 0; s.qreg2 = 0; s.n_subst = 0; s.n_acgt = 0;
       const uint8_t* qsrc = qual + off;
       OutRing ring;
       ring_init(ring, my_ring, seq + off, L, rev != 0);
       s.lut = rev ? 0x41434754u : 0x54474341u;  // "TGCA" / "ACGT"
       s.wpos = ring.a0 + (rev ? L - 1u : 0u);   // forward mate: byte i; mate 2: byte L-1-i
       s.wdir = rev ? 0xffffffffu : 1u;
-      s.qnext = load_q8(qsrc, 0, L);
+      load_q16(qsrc, 0, L, s.qnext, s.qnext2);
       s.cnext = live ? fetch_codes16(packed, (int64_t)src) : 0u;
       s.enext = (HAS_EXC && mask) ? fetch_mask16(mask, (int64_t)src) : 0u;
       for (uint32_t blk = 0; __any(s.i < L); blk++) {
@@ -1920,8 +1936,6 @@ SIMMR_DEV uint32_t low_bytes(uint32_t x, int nb) {
   return nb >= 4 ? x : (nb <= 0 ? 0u : (x & ((1u << (8 * nb)) - 1u)));
 }
 // one 16-byte store at any byte address (global_store_dwordx4; one address-unit access per lane instead of two)
-typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
-typedef v4u32 __attribute__((aligned(1))) v4u32_unaligned;
 SIMMR_DEV void store16(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi) {
   v4u32 v;
   v.x = (uint32_t)lo; v.y = (uint32_t)(lo >> 32); v.z = (uint32_t)hi; v.w = (uint32_t)(hi >> 32);
