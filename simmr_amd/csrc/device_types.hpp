@@ -113,10 +113,9 @@ struct OuterScanResult {
 
 // Per-unit plan columns (unit = pair or long read).
 struct PlanArrays {
-  uint32_t* len;    // read length L (both mates) / long-read length
+  uint32_t* len;    // read length L (both mates) / long-read length; the unit writes 2L resp. L bytes to seq[]
   uint64_t* a;      // fwd_start / read_start
   uint64_t* b;      // rev_end (mate-2 slice start) / read_end
-  uint64_t* bytes;  // bytes this unit writes to seq[] (2L or end-start)
   uint64_t* qs2;    // mate-2 Phred seed   (nullptr when unused)
   uint64_t* ms2;    // mate-2 mutation seed
   uint8_t* flags;

@@ -80,7 +80,7 @@ struct simmr_engine {
   bool plan_multi = false;    // paired-end plan over several genomes (u_genome per pair)
   bool plan_any_exc = false;  // some genome of the plan has an exception plane
   DevBuf m_genomes, m_contig, m_seed;
-  DevBuf u_contig, u_genome, u_seed, u_len, u_a, u_b, u_bytes, u_qs2, u_ms2, u_flags, u_off;
+  DevBuf u_contig, u_genome, u_seed, u_len, u_a, u_b, u_qs2, u_ms2, u_flags, u_off;
   DevBuf scan_tmp, u_order, len_hist;
   bool plan_sorted = false;
   int emit_variant = 0;  // 0 = lane-per-read kernel for short reads, 1 = wave-per-unit kernel
@@ -520,8 +520,9 @@ int sort_by_length(simmr_engine* e, uint64_t count, uint32_t shift) {
   return SIMMR_OK;
 }
 
-// exclusive scan of `in` (n u64) -> `out` (n + 1 entries); returns the total
-int scan_u64(simmr_engine* e, DevBuf& in, uint64_t n, DevBuf& out, uint64_t* total) {
+// exclusive scan of scale * in[i] (n entries of type T) -> `out` (n + 1 u64 entries); returns the total
+template <typename T>
+int scan_scaled(simmr_engine* e, DevBuf& in, uint64_t n, uint32_t scale, DevBuf& out, uint64_t* total) {
   if (!out.ensure((n + 1) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
   if (n == 0) {
     HIP_TRY(e, hipMemsetAsync(out.p, 0, 8, e->stream));
@@ -533,21 +534,24 @@ int scan_u64(simmr_engine* e, DevBuf& in, uint64_t n, DevBuf& out, uint64_t* tot
   if (!e->scan_tmp.ensure((n_wg + 2) * 8)) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
   uint64_t* wg_tot = e->scan_tmp.as<uint64_t>();
   uint64_t* grand = wg_tot + n_wg;
-  hipLaunchKernelGGL(k_scan_reduce, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
-                     in.as<uint64_t>(), n, wg_tot);
+  hipLaunchKernelGGL(k_scan_reduce<T>, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
+                     (const T*)in.as<T>(), n, scale, wg_tot);
   hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_THREADS), 0, e->stream, wg_tot, n_wg, grand);
-  hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
-                     in.as<uint64_t>(), n, wg_tot, out.as<uint64_t>());
+  hipLaunchKernelGGL(k_scan_apply<T>, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
+                     (const T*)in.as<T>(), n, scale, (const uint64_t*)wg_tot, out.as<uint64_t>());
   HIP_TRY(e, hipMemcpyAsync(total, grand, 8, hipMemcpyDeviceToHost, e->stream));
   return sync_check(e, "offset scan");
 }
-// exclusive scan of u_bytes -> u_off
-int scan_offsets(simmr_engine* e, uint64_t n, uint64_t* total) { return scan_u64(e, e->u_bytes, n, e->u_off, total); }
+int scan_u64(simmr_engine* e, DevBuf& in, uint64_t n, DevBuf& out, uint64_t* total) { return scan_scaled<uint64_t>(e, in, n, 1u, out, total); }
+// exclusive scan of the bytes each unit writes (reads_per_unit * u_len) -> u_off
+int scan_offsets(simmr_engine* e, uint64_t n, uint32_t reads_per_unit, uint64_t* total) {
+  return scan_scaled<uint32_t>(e, e->u_len, n, reads_per_unit, e->u_off, total);
+}
 
 int ensure_plan_arrays(simmr_engine* e, uint64_t n, bool need_seeds2, bool need_genome) {
   const uint64_t m = std::max<uint64_t>(n, 1);
   bool ok = e->u_contig.ensure(m * 4) && e->u_seed.ensure(m * 8) && e->u_len.ensure(m * 4) &&
-            e->u_a.ensure(m * 8) && e->u_b.ensure(m * 8) && e->u_bytes.ensure(m * 8) &&
+            e->u_a.ensure(m * 8) && e->u_b.ensure(m * 8) &&
             e->u_flags.ensure(m);
   if (need_seeds2) ok = ok && e->u_qs2.ensure(m * 8) && e->u_ms2.ensure(m * 8);
   if (need_genome) ok = ok && e->u_genome.ensure(m * 4);
@@ -560,7 +564,6 @@ PlanArrays plan_arrays(simmr_engine* e, bool seeds2) {
   pl.len = e->u_len.as<uint32_t>();
   pl.a = e->u_a.as<uint64_t>();
   pl.b = e->u_b.as<uint64_t>();
-  pl.bytes = e->u_bytes.as<uint64_t>();
   pl.qs2 = seeds2 ? e->u_qs2.as<uint64_t>() : nullptr;
   pl.ms2 = seeds2 ? e->u_ms2.as<uint64_t>() : nullptr;
   pl.flags = e->u_flags.as<uint8_t>();
@@ -673,7 +676,7 @@ void simmr_engine_destroy(simmr_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   for (auto& g : e->genomes) { g.packed.release(); g.mask.release(); g.d_contigs.release(); }
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
-                    &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_bytes, &e->u_qs2,
+                    &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_qs2,
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
                     &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->c_kslots, &e->c_krecs, &e->c_kdirect, &e->ph_table,
                     &e->fq_blob, &e->fq_gid_off, &e->fq_gid_len, &e->fq_cbase, &e->fq_ncontig, &e->fq_coff, &e->fq_clen,
@@ -951,9 +954,12 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     rc = run_outer(e, seed, g.contigs.size(), start_slot, first - start_unit + count, first - start_unit, count,
                    e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(), &end_slot);
     if (rc) return rc;
+    PlanArrays pw = plan_arrays(e, seeds2);
+    // the mutation seed of mate 2 is only read by the kernels that walk the reference's mutation stream
+    if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode == SIMMR_RNG_PHILOX) pw.ms2 = nullptr;
     hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                        e->d_genomes.as<GenomeDev>(), genome_idx, count, e->u_contig.as<uint32_t>(),
-                       e->u_seed.as<uint64_t>(), (const uint32_t*)nullptr, plan_arrays(e, seeds2),
+                       e->u_seed.as<uint64_t>(), (const uint32_t*)nullptr, pw,
                        e->d_tables.as<Tables>(), e->d_err.as<uint32_t>());
   }
   e->plan_sorted = false;
@@ -962,7 +968,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     return rc;
   if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
     total = count * 2ull * prof.read_length;  // constant lengths (perfect_short.rs:22-40): read r starts at r * L
-  } else if ((rc = scan_offsets(e, count, &total))) {
+  } else if ((rc = scan_offsets(e, count, 2u, &total))) {
     return rc;
   }
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
@@ -1061,9 +1067,11 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
     hipLaunchKernelGGL(k_multi_units, dim3(grid_for(count, 256)), dim3(256), 0, e->stream, e->m_genomes.as<MultiGenome>(),
                        n_genomes, first, count, e->m_contig.as<uint32_t>(), e->m_seed.as<uint64_t>(),
                        e->u_genome.as<uint32_t>(), e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>());
+    PlanArrays pw = plan_arrays(e, seeds2);
+    if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode == SIMMR_RNG_PHILOX) pw.ms2 = nullptr;
     hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                        e->d_genomes.as<GenomeDev>(), 0u, count, e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(),
-                       e->u_genome.as<uint32_t>(), plan_arrays(e, seeds2), e->d_tables.as<Tables>(),
+                       e->u_genome.as<uint32_t>(), pw, e->d_tables.as<Tables>(),
                        e->d_err.as<uint32_t>());
   }
   e->plan_sorted = false;
@@ -1071,7 +1079,7 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
     return rc;
   if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
     total = count * 2ull * prof.read_length;
-  } else if ((rc = scan_offsets(e, count, &total))) {
+  } else if ((rc = scan_offsets(e, count, 2u, &total))) {
     return rc;
   }
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
@@ -1334,7 +1342,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   }
   e->plan_sorted = false;
   if (e->emit_variant == 0 && prof.rng_mode == SIMMR_RNG_REFERENCE && (rc = sort_by_length(e, count, 6))) return rc;
-  if ((rc = scan_offsets(e, count, &total))) return rc;
+  if ((rc = scan_offsets(e, count, 1u, &total))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;
   if ((rc = read_err_word(e, &errw))) return rc;

@@ -598,9 +598,9 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
   pl.len[k] = (uint32_t)L;
   pl.a[k] = fs;
   pl.b[k] = re;
-  pl.bytes[k] = 2 * L;
   pl.flags[k] = flags;
-  if (pl.qs2) { pl.qs2[k] = qs; pl.ms2[k] = ms; }
+  if (pl.qs2) pl.qs2[k] = qs;
+  if (pl.ms2) pl.ms2[k] = ms;  // not kept when no kernel will read it (counter mode, custom profiles)
 }
 
 // long reads, reference mode: contig + read_seed come from the outer stream,
@@ -632,7 +632,6 @@ k_plan_long_ref(const GenomeDev* __restrict__ genomes, const LongGenomeRun* __re
   pl.len[k] = (uint32_t)(e - s);
   pl.a[k] = s;
   pl.b[k] = e;
-  pl.bytes[k] = e - s;
   pl.flags[k] = 0;
 }
 
@@ -689,7 +688,6 @@ k_plan_long_per_read(ProfileDev prof, const GenomeDev* __restrict__ genomes,
   pl.len[k] = (uint32_t)(e - s);
   pl.a[k] = s;
   pl.b[k] = e;
-  pl.bytes[k] = e - s;
   pl.flags[k] = 0;
 }
 
@@ -737,13 +735,15 @@ SIMMR_DEV uint64_t wg_exclusive_scan_u64(uint64_t v, uint64_t* lds4, uint64_t* t
   return pre + inc - v;
 }
 
-extern "C" __global__ void __launch_bounds__(SCAN_THREADS)
-k_scan_reduce(const uint64_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ wg_tot) {
+// T = uint64_t (byte counts) or uint32_t (read lengths, `scale` reads per unit: the bytes a unit writes)
+template <typename T>
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_reduce(const T* __restrict__ in, uint64_t n, uint32_t scale, uint64_t* __restrict__ wg_tot) {
   __shared__ uint64_t lds4[4];
   uint64_t base = ((uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
   uint64_t s = 0;
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) s += in[base + i];
+  for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) s += (uint64_t)in[base + i] * scale;
   uint64_t tot;
   (void)wg_exclusive_scan_u64(s, lds4, &tot);
   if (threadIdx.x == 0) wg_tot[blockIdx.x] = tot;
@@ -770,14 +770,15 @@ k_scan_tops(uint64_t* __restrict__ wg_tot, uint64_t n_wg, uint64_t* __restrict__
   if (threadIdx.x == 0) *grand = carry_s;
 }
 
-extern "C" __global__ void __launch_bounds__(SCAN_THREADS)
-k_scan_apply(const uint64_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ wg_tot,
+template <typename T>
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_apply(const T* __restrict__ in, uint64_t n, uint32_t scale, const uint64_t* __restrict__ wg_tot,
              uint64_t* __restrict__ out /* n + 1 */) {
   __shared__ uint64_t lds4[4];
   uint64_t base = ((uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
   uint64_t v[SCAN_ITEMS], s = 0;
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : 0; s += v[i]; }
+  for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? (uint64_t)in[base + i] * scale : 0; s += v[i]; }
   uint64_t tot;
   uint64_t ex = wg_exclusive_scan_u64(s, lds4, &tot) + wg_tot[blockIdx.x];
 #pragma unroll
@@ -2043,7 +2044,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         if (o.read_id) o.read_id[rd] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
         if (o.flags) o.flags[rd] = (paired && !rev) ? 0 : (uint8_t)fl;
         if (!rev) {
-          p_bases += pl.bytes[u];
+          p_bases += paired ? 2ull * L : (uint64_t)L;
           p_redrawn += (fl & SIMMR_FLAG_REDRAWN) ? 1u : 0u;
           p_seedsubst += ((fl & SIMMR_FLAG_QSEED_SUBST) ? 1u : 0u) + ((fl & SIMMR_FLAG_MSEED_SUBST) ? 1u : 0u);
         }
@@ -2643,7 +2644,7 @@ k_count_plan(uint32_t paired, uint64_t n_units, PlanArrays pl, uint32_t const_q,
   __shared__ uint64_t lds4[4];
   uint64_t bases = 0, redrawn = 0, subst = 0;
   for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n_units; k += (uint64_t)gridDim.x * 256) {
-    bases += pl.bytes[k];
+    bases += (uint64_t)pl.len[k] * (paired ? 2u : 1u);
     const uint32_t f = pl.flags[k];
     redrawn += (f & SIMMR_FLAG_REDRAWN) ? 1 : 0;
     subst += ((f & SIMMR_FLAG_QSEED_SUBST) ? 1 : 0) + ((f & SIMMR_FLAG_MSEED_SUBST) ? 1 : 0);
