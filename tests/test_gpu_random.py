@@ -31,35 +31,46 @@ def test_random_configurations_match_the_oracle(engine, oracle, sweep_seed):
         e.stage_genome(SLOT, contigs); host = _oracle.HostGenome(contigs)
         seed = int(rng.integers(0, 1 << 62)); qoff = int(rng.choice([0, 33]))
         kind = rng.integers(0, 4)
-        try:
-            if kind <= 1:
-                L = int(rng.integers(1, 260)); I = int(rng.integers(0, 400)); mq = int(rng.integers(0, 70))
-                if kind == 0:
-                    prof = PerfectShortErrorProfile(L, I).pod()
-                else:
-                    prof = MinimalShortErrorProfile(read_length=L, insert_size=I, mean_phred_score=mq, rng_mode=int(rng.integers(0, 2))).pod()
-                reads = int(rng.integers(0, 1500)); first = int(rng.integers(0, reads // 2 + 2)); count = int(rng.integers(0, 800))
-                if 2 * L + I >= min(lens):
-                    continue
-                dev = e.simulate_pe_reads_from_genome(SLOT, prof, reads, seed, first=first, count=count, read_id_base=3, qual_offset=qoff)
-                ora = _oracle.simulate_pe(lib, host, prof, reads, seed, first=first, count=count, read_id_base=3, qual_offset=qoff, max_len=70000)
+        if kind <= 1:
+            L = int(rng.integers(1, 260)); I = int(rng.integers(0, 400)); mq = int(rng.integers(0, 70))
+            if kind == 0:
+                prof = PerfectShortErrorProfile(L, I).pod()
             else:
-                gm = float(rng.integers(300, 4000)); gs = gm * float(rng.uniform(0.3, 0.9))
-                cls = MinimalLongErrorProfile
-                rm = int(rng.integers(0, 2))
-                prof = cls(gamma_mean=gm, gamma_std=gs, length_mode=int(rng.integers(0, 2)), rng_mode=rm, uniform_start=bool(rng.integers(0, 2)), mean_phred_score=int(rng.integers(0, 60))).pod()
-                if kind == 3:
-                    prof.kind = _abi.PERFECT_LONG
-                if min(lens) <= 20000 and max(lens) <= 20000:
-                    continue
-                reads = int(rng.integers(0, 60)); first = int(rng.integers(0, reads + 1)); count = int(rng.integers(0, 40))
-                dev = e.simulate_long_reads([SLOT], [reads], prof, seed, first=first, count=count, read_id_base=1, qual_offset=qoff)
-                ora = _oracle.simulate_long(lib, [host], [reads], prof, seed, first=first, count=count, read_id_base=1, qual_offset=qoff)
-            d, o = dev.to_host(), ora.trimmed()
-            assert_same(d, o, what=f"it{it} kind{kind} ")
-            n_ok += 1
-        except (SimmrError, RuntimeError):
-            pass  # both sides refuse some configurations (a contig too small for the drawn length, ...)
+                prof = MinimalShortErrorProfile(read_length=L, insert_size=I, mean_phred_score=mq, rng_mode=int(rng.integers(0, 2))).pod()
+            reads = int(rng.integers(0, 1500)); first = int(rng.integers(0, reads // 2 + 2)); count = int(rng.integers(0, 800))
+            if 2 * L + I >= min(lens):
+                continue
+            run_dev = lambda: e.simulate_pe_reads_from_genome(SLOT, prof, reads, seed, first=first, count=count, read_id_base=3, qual_offset=qoff)
+            run_ora = lambda: _oracle.simulate_pe(lib, host, prof, reads, seed, first=first, count=count, read_id_base=3, qual_offset=qoff, max_len=70000)
+        else:
+            gm = float(rng.integers(300, 4000)); gs = gm * float(rng.uniform(0.3, 0.9))
+            cls = MinimalLongErrorProfile
+            rm = int(rng.integers(0, 2))
+            prof = cls(gamma_mean=gm, gamma_std=gs, length_mode=int(rng.integers(0, 2)), rng_mode=rm, uniform_start=bool(rng.integers(0, 2)), mean_phred_score=int(rng.integers(0, 60))).pod()
+            if kind == 3:
+                prof.kind = _abi.PERFECT_LONG
+            if min(lens) <= 20000 and max(lens) <= 20000:
+                continue
+            reads = int(rng.integers(0, 60)); first = int(rng.integers(0, reads + 1)); count = int(rng.integers(0, 40))
+            run_dev = lambda: e.simulate_long_reads([SLOT], [reads], prof, seed, first=first, count=count, read_id_base=1, qual_offset=qoff)
+            run_ora = lambda: _oracle.simulate_long(lib, [host], [reads], prof, seed, first=first, count=count, read_id_base=1, qual_offset=qoff)
+        # both sides refuse some configurations (a contig too small for the drawn length, ...): the refusal must be mutual
+        dev = ora = None
+        try:
+            ora = run_ora()
+        except RuntimeError as ex:
+            ora_err = str(ex)
+        try:
+            dev = run_dev()
+        except SimmrError as ex:
+            dev_err = str(ex)
+        assert (dev is None) == (ora is None), (f"it{it} kind{kind}: device " + ("refused: " + dev_err if dev is None else "ran") +
+                                                 ", oracle " + ("refused: " + ora_err if ora is None else "ran"))
+        if dev is None:
+            continue
+        d, o = dev.to_host(), ora.trimmed()
+        assert_same(d, o, what=f"it{it} kind{kind} ")
+        n_ok += 1
     assert n_ok > 150
 
 
