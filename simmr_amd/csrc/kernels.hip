@@ -862,6 +862,15 @@ SIMMR_DEV uint32_t reverse_groups16(uint32_t x) {
   uint32_t y = __builtin_bitreverse32(x);
   return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
 }
+// low bit of each of the sixteen 2-bit codes -> 16 bits
+SIMMR_DEV uint32_t c16_odd(uint32_t c) {
+  c &= 0x55555555u;
+  c = (c | (c >> 1)) & 0x33333333u;
+  c = (c | (c >> 2)) & 0x0F0F0F0Fu;
+  c = (c | (c >> 4)) & 0x00FF00FFu;
+  c = (c | (c >> 8)) & 0x0000FFFFu;
+  return c;
+}
 // 16 mask bits -> 16 two-bit groups (each bit duplicated)
 SIMMR_DEV uint32_t spread16(uint32_t m) {
   m = (m | (m << 8)) & 0x00FF00FFu;
@@ -2526,102 +2535,107 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
         wpos++;
         return w;
       };
-      uint32_t creg = 0, ereg = 0;
-      auto src_code = [&](uint32_t sp) -> uint32_t {  // source base sp: ACGT 0-3, N 4, '-' 5
-        if ((sp & 15u) == 0u) {
-          creg = fetch_codes16(packed, (int64_t)(src0 + sp));
-          if (HAS_EXC) ereg = mask ? fetch_mask16(mask, (int64_t)(src0 + sp)) : 0u;
-        }
-        uint32_t c = (creg >> (2u * (sp & 15u))) & 3u;
-        if (HAS_EXC && ((ereg >> (sp & 15u)) & 1u)) c = 4u + (c & 1u);
-        return c;
-      };
       // bases i .. i+K-1 of the edited sequence: 2 bits per base plus one flag bit per base for N and for '-';
       // owin / oexc: the same positions of the original (for the counters)
       uint32_t win = 0, nm = 0, dm = 0, owin = 0, oexc = 0;
-      for (uint32_t j = 0; j < K; j++) {
-        if (!__any(j < n)) break;
-        if (j < n) {
-          const uint32_t c = src_code(j);
-          win |= (c < 4u ? c : 0u) << (2u * j);
-          if (HAS_EXC) { nm |= (c == 4u ? 1u : 0u) << j; dm |= (c == 5u ? 1u : 0u) << j; }
-        }
+      if (n) {  // lanes without a read have no plane to read from
+        const uint32_t c16 = fetch_codes16(packed, (int64_t)src0);  // K <= 10 bases
+        const uint32_t e16 = (HAS_EXC && mask) ? fetch_mask16(mask, (int64_t)src0) : 0u;
+        const uint32_t k = K < n ? K : n;
+        const uint32_t keep = (1u << k) - 1u;
+        const uint32_t exc = e16 & keep;
+        win = c16 & ((1u << (2u * k)) - 1u) & ~spread16(exc);
+        if (HAS_EXC) { nm = exc & ~c16_odd(c16); dm = exc & c16_odd(c16); }  // exception code 4 + (code & 1): N / '-'
       }
       owin = win; oexc = nm | dm;
       bool dead = false;  // after an error the lane only copies
-      uint64_t acc_lo = 0, acc_hi = 0;  // 16 output bases
       uint8_t* const sd = seq + off;
-      for (uint32_t i = 0; __any(i < n); i++) {
-        if ((i & 7u) == 0u) {
-          const bool need = i < n && have < (wpos >> 4) + 2u;
-          if (__any(need)) {
-            if (need) { refill_words(key, have, row + (have & 1u) * 16u); have++; }
-          }
-        }
-        if (i >= n) continue;
-        // three_bit_encode_kmer fails on anything but ACGTN (encoding.rs:149-176): a '-' skips the k-mer
-        if (i + K <= n && !dead && (!HAS_EXC || dm == 0u)) {
-          uint32_t first = 0, cnt = 0, zone = 0;
-          if (!HAS_EXC || nm == 0u) {
-            const Rec16 d = C.kmer_direct[win];
-            first = d.x; cnt = d.y; zone = d.z;
-          } else {
-            uint32_t key3 = 0;  // the model's code of a k-mer with an N
-            for (uint32_t j = 0; j < K; j++)
-              key3 |= (((nm >> j) & 1u) ? 4u : ((win >> (2u * j)) & 3u)) << (3u * j);
-            uint32_t h = ((key3 * 0x9E3779B1u) >> 7) & C.kmer_mask;
-            Rec16 slot = C.kmer_slots[h];
-            while (slot.x != key3 && slot.x != 0xFFFFFFFFu) { h = (h + 1u) & C.kmer_mask; slot = C.kmer_slots[h]; }
-            if (slot.x == key3) { first = slot.y; cnt = slot.z; zone = slot.w; }
-          }
-          if (cnt == 0xFFFFFFFFu) {
-            bad_kmer = true; dead = true;  // WeightedAliasIndex::new(..).unwrap() panics
-          } else if (cnt != 0u) {
-            uint32_t c;
-            for (;;) {  // uniform_index.sample
-              const uint64_t m = (uint64_t)next_word() * cnt;
-              if ((uint32_t)m <= zone) { c = (uint32_t)(m >> 32); break; }
+      const uint32_t top2 = 2u * (K - 1u), top1 = K - 1u;
+      for (uint32_t i0 = 0; __any(i0 < n); i0 += 16u) {
+        // the 16 source bases that enter the window during this group: positions i0 + K .. i0 + K + 15
+        // (at most K + 31 bases past the read: inside the plane's back padding)
+        const uint32_t s16 = i0 < n ? fetch_codes16(packed, (int64_t)(src0 + i0 + K)) : 0u;
+        const uint32_t x16 = (HAS_EXC && mask && i0 < n) ? fetch_mask16(mask, (int64_t)(src0 + i0 + K)) : 0u;
+        uint32_t out[4] = {0u, 0u, 0u, 0u};  // 16 output bases
+#pragma unroll
+        for (uint32_t t = 0; t < 16u; t++) {
+          const uint32_t i = i0 + t;
+          if ((t & 7u) == 0u) {
+            const bool need = i < n && have < (wpos >> 4) + 2u;
+            if (__any(need)) {
+              if (need) { refill_words(key, have, row + (have & 1u) * 16u); have++; }
             }
-            const Rec16 rec = C.kmer_recs[first + c];
-            const float v12 = __uint_as_float((next_word() >> 9) | 0x3F800000u);
-            const float x = __fadd_rn(__fmul_rn(__fsub_rn(v12, 1.0f), __uint_as_float(rec.w)), 0.0f);
-            const uint32_t alt = x < __uint_as_float(rec.x) ? rec.y : rec.z;
-            if (alt & 0x80000000u) { bad_kmer = true; dead = true; }  // an N = a deletion, 5-7 = decode error
-            else { win = alt; nm = 0u; }
+          }
+          if (i < n) {
+            // three_bit_encode_kmer fails on anything but ACGTN (encoding.rs:149-176): a '-' skips the k-mer
+            if (i + K <= n && !dead && (!HAS_EXC || dm == 0u)) {
+              uint32_t first = 0, cnt = 0, zone = 0;
+              if (!HAS_EXC || nm == 0u) {
+                const Rec16 d = C.kmer_direct[win];
+                first = d.x; cnt = d.y; zone = d.z;
+              } else {
+                uint32_t key3 = 0;  // the model's code of a k-mer with an N
+                for (uint32_t j = 0; j < K; j++)
+                  key3 |= (((nm >> j) & 1u) ? 4u : ((win >> (2u * j)) & 3u)) << (3u * j);
+                uint32_t h = ((key3 * 0x9E3779B1u) >> 7) & C.kmer_mask;
+                Rec16 slot = C.kmer_slots[h];
+                while (slot.x != key3 && slot.x != 0xFFFFFFFFu) { h = (h + 1u) & C.kmer_mask; slot = C.kmer_slots[h]; }
+                if (slot.x == key3) { first = slot.y; cnt = slot.z; zone = slot.w; }
+              }
+              if (cnt == 0xFFFFFFFFu) {
+                bad_kmer = true; dead = true;  // WeightedAliasIndex::new(..).unwrap() panics
+              } else if (cnt != 0u) {
+                uint32_t c;
+                for (;;) {  // uniform_index.sample
+                  const uint64_t m = (uint64_t)next_word() * cnt;
+                  if ((uint32_t)m <= zone) { c = (uint32_t)(m >> 32); break; }
+                }
+                const Rec16 rec = C.kmer_recs[first + c];
+                const float v12 = __uint_as_float((next_word() >> 9) | 0x3F800000u);
+                const float x = __fadd_rn(__fmul_rn(__fsub_rn(v12, 1.0f), __uint_as_float(rec.w)), 0.0f);
+                const uint32_t alt = x < __uint_as_float(rec.x) ? rec.y : rec.z;
+                if (alt & 0x80000000u) { bad_kmer = true; dead = true; }  // an N = a deletion, 5-7 = decode error
+                else { win = alt; nm = 0u; }
+              }
+            }
+            const uint32_t code = win & 3u, ocode = owin & 3u;
+            uint32_t ch = __builtin_amdgcn_perm(0u, 0x54474341u, code | 0x0c0c0c00u);  // "ACGT"[code]
+            bool differs = code != ocode;
+            if (HAS_EXC) {
+              const uint32_t en = nm & 1u, ed = dm & 1u, oe = oexc & 1u;
+              if (en) ch = 'N';
+              if (ed) ch = '-';
+              differs = (en | ed) ? false : (oe != 0u || code != ocode);  // an exception is only ever replaced, never created
+              n_acgt += oe ? 0u : 1u;
+            } else {
+              n_acgt++;
+            }
+            n_subst += differs ? 1u : 0u;
+            out[t >> 2] |= ch << (8u * (t & 3u));
+            win >>= 2; owin >>= 2;
+            if (HAS_EXC) { nm >>= 1; dm >>= 1; oexc >>= 1; }
+            if (i + K < n) {
+              const uint32_t c2 = (s16 >> (2u * t)) & 3u;
+              if (HAS_EXC) {
+                const uint32_t ex = (x16 >> t) & 1u;
+                const uint32_t cc = ex ? 0u : c2;
+                win |= cc << top2; owin |= cc << top2;
+                nm |= (ex & ~c2 & 1u) << top1; dm |= (ex & c2 & 1u) << top1;
+                oexc |= ex << top1;
+              } else {
+                win |= c2 << top2; owin |= c2 << top2;
+              }
+            }
           }
         }
-        const uint32_t code = win & 3u, ocode = owin & 3u;
-        uint32_t ch = (0x54474341u >> (8u * code)) & 0xffu;
-        bool differs = code != ocode;
-        if (HAS_EXC) {
-          const uint32_t en = nm & 1u, ed = dm & 1u, oe = oexc & 1u;
-          if (en) ch = 'N';
-          if (ed) ch = '-';
-          differs = (en | ed) ? false : (oe != 0u || code != ocode);  // an exception is only ever replaced, never created
-          n_acgt += oe ? 0u : 1u;
-        } else {
-          n_acgt++;
-        }
-        n_subst += differs ? 1u : 0u;
-        const uint64_t put = (uint64_t)ch << (8u * (i & 7u));
-        if (i & 8u) acc_hi |= put; else acc_lo |= put;
-        win >>= 2; owin >>= 2;
-        if (HAS_EXC) { nm >>= 1; dm >>= 1; oexc >>= 1; }
-        if (i + K < n) {
-          const uint32_t c = src_code(i + K);
-          const uint32_t c2 = c < 4u ? c : 0u;
-          win |= c2 << (2u * (K - 1u)); owin |= c2 << (2u * (K - 1u));
-          if (HAS_EXC) {
-            nm |= (c == 4u ? 1u : 0u) << (K - 1u); dm |= (c == 5u ? 1u : 0u) << (K - 1u);
-            oexc |= (c >= 4u ? 1u : 0u) << (K - 1u);
+        if (i0 < n) {
+          const uint64_t lo = (uint64_t)out[0] | ((uint64_t)out[1] << 32), hi = (uint64_t)out[2] | ((uint64_t)out[3] << 32);
+          if (i0 + 16u <= n) {
+            *reinterpret_cast<u64_unaligned*>(sd + i0) = lo;
+            *reinterpret_cast<u64_unaligned*>(sd + i0 + 8u) = hi;
+          } else {
+            store_tail(sd + i0, lo, hi, n - i0);
           }
-        }
-        if ((i & 15u) == 15u) {
-          *reinterpret_cast<u64_unaligned*>(sd + (i - 15u)) = acc_lo;
-          *reinterpret_cast<u64_unaligned*>(sd + (i - 7u)) = acc_hi;
-          acc_lo = 0; acc_hi = 0;
-        } else if (i + 1u == n) {
-          store_tail(sd + (i & ~15u), acc_lo, acc_hi, (i & 15u) + 1u);
         }
       }
     }
