@@ -133,3 +133,59 @@ def test_c1_perfect_short_full_roundtrip(big):
         assert bool((seq[a:b:2] == fwd).all())
         rc = comp[ref[(st[1::2, None] - 1 - k[None, :])].long()]
         assert bool((seq[a + 1:b:2] == rc).all())
+
+
+def test_c5_custom_long_properties(big):
+    """BASELINE configs[4] in the large: a custom (simmrd-shaped) long-read model, per-read lengths, 500 k reads
+    (10 Gbases), checked on the device through size-independent properties: determinism, sharded == whole, the
+    constant quality tail, substitutions only where the counters say, alphabet."""
+    import torch
+    from simmr_amd import CustomShortErrorProfile, model_io
+    eng = big
+    n_pos = 1000
+    prof = CustomShortErrorProfile(model_io.synthetic_long_model(kmer_size=7, n_positions=n_pos, seed=1, n_kmers=4 ** 7,
+                                                                  read_length_mean=20000.0, read_length_std=4000.0))
+    pod = prof.pod()
+    pod.length_mode = _abi.LEN_PER_READ
+    pod.long_start_mode = _abi.START_UNIFORM
+    n_reads = 500_000
+    eng.counters_reset()
+    whole = eng.simulate_long_reads([5], [n_reads], pod, 42, qual_offset=33)
+    c = eng.counters()
+    tb = whole.total_bases
+    assert whole.n_reads == n_reads and c[_abi.CNT_READS] == n_reads and c[_abi.CNT_BASES] == tb
+    off = whole.seq_off[: n_reads + 1]
+    lens = off[1:] - off[:-1]
+    assert int(off[0]) == 0 and int(off[-1]) == tb
+    assert abs(lens.double().mean().item() - 20000) < 100 and abs(lens.double().std().item() - 4000) < 100
+    assert bool((whole.end[:n_reads] - whole.start[:n_reads] == lens).all())
+    # alphabet: the synthetic genome has no N, and an alternate with an N would have been refused
+    seq = whole.seq[:tb]
+    hist = torch.bincount(seq.to(torch.int64), minlength=256)
+    assert int(hist[[65, 67, 71, 84]].sum()) == tb
+    # qualities: from position n_pos - 1 on one value per read (custom_short.rs:339-350): compare every read's
+    # last quality with the one at position n_pos - 1
+    at = (off[:-1] + (n_pos - 1)).clamp(max=tb - 1)
+    longer = lens > n_pos
+    assert bool((whole.qual[at][longer] == whole.qual[(off[1:] - 1)][longer]).all())
+    qsum = int(whole.qual[:tb].to(torch.int64).sum().item()) - 33 * tb
+    assert c[_abi.CNT_QUAL_SUM] == qsum
+    # the substitution counter against the bytes, on the first 2000 reads
+    ref = eng.unstage(5, 0, 0, GENOME) if hasattr(eng, "unstage") else None
+    if ref is not None:
+        refb = torch.from_numpy(np.frombuffer(ref, dtype=np.uint8).copy()).to(seq.device)
+        mism = 0
+        for r in range(2000):
+            a, b = int(off[r]), int(off[r + 1])
+            s0 = int(whole.start[r])
+            mism += int((seq[a:b] != refb[s0:s0 + (b - a)]).sum().item())
+        assert 0.05 < mism / int(off[2000]) < 0.15
+    assert 0.05 < c[_abi.CNT_SUBSTITUTIONS] / c[_abi.CNT_ACGT_BASES] < 0.15
+    # determinism and sharding: checksums of a shard's byte range
+    cs_whole = checksum_range(whole.seq, int(off[123_456]), int(off[223_456]))
+    cq_whole = checksum_range(whole.qual, int(off[123_456]), int(off[223_456]))
+    part = eng.simulate_long_reads([5], [n_reads], pod, 42, first=123_456, count=100_000, qual_offset=33)
+    assert part.total_bases == int(off[223_456]) - int(off[123_456])
+    shift = int(off[123_456]) % 256
+    assert torch.equal(torch.roll(colsum256(part.seq[:part.total_bases]), shift), cs_whole)
+    assert torch.equal(torch.roll(colsum256(part.qual[:part.total_bases]), shift), cq_whole)
