@@ -189,3 +189,68 @@ def test_c5_custom_long_properties(big):
     shift = int(off[123_456]) % 256
     assert torch.equal(torch.roll(colsum256(part.seq[:part.total_bases]), shift), cs_whole)
     assert torch.equal(torch.roll(colsum256(part.qual[:part.total_bases]), shift), cq_whole)
+
+
+def test_c3_minimal_long_properties(big):
+    """BASELINE configs[2]: minimal-long, gamma(8000, 6000) per-read lengths, 2 M reads (16 Gbases) in counter mode:
+    lengths follow the gamma law, reads lie inside the sequence, the substitution rate and Phred mean are the
+    reference's, a shard equals the same range of the whole run."""
+    import torch
+    from simmr_amd import MinimalLongErrorProfile
+    eng = big
+    prof = MinimalLongErrorProfile(gamma_mean=8000.0, gamma_std=6000.0, length_mode=_abi.LEN_PER_READ,
+                                   rng_mode=_abi.RNG_PHILOX).pod()
+    n_reads = 2_000_000
+    eng.counters_reset()
+    whole = eng.simulate_long_reads([5], [n_reads], prof, 42, qual_offset=33)
+    c = eng.counters()
+    tb = whole.total_bases
+    off = whole.seq_off[: n_reads + 1]
+    lens = off[1:] - off[:-1]
+    assert c[_abi.CNT_READS] == n_reads and c[_abi.CNT_BASES] == tb and int(off[-1]) == tb
+    # floor(Gamma(shape (8/6)^2, scale 6000^2/8000)) saturated to u16: mean a little under 8000, sd about 6000
+    assert 7800 < lens.double().mean().item() < 8050 and 5700 < lens.double().std().item() < 6100
+    assert int(lens.max()) <= 65535 and bool((whole.end[:n_reads] <= GENOME).all())
+    rate = c[_abi.CNT_SUBSTITUTIONS] / c[_abi.CNT_ACGT_BASES]
+    assert abs(rate / 0.013404 - 1) < 0.02 and abs(c[_abi.CNT_QUAL_SUM] / tb - 29.5) < 0.05
+    a, b = 700_000, 900_000
+    cs = checksum_range(whole.seq, int(off[a]), int(off[b]))
+    cq = checksum_range(whole.qual, int(off[a]), int(off[b]))
+    part = eng.simulate_long_reads([5], [n_reads], prof, 42, first=a, count=b - a, qual_offset=33)
+    shift = int(off[a]) % 256
+    assert torch.equal(torch.roll(colsum256(part.seq[:part.total_bases]), shift), cs)
+    assert torch.equal(torch.roll(colsum256(part.qual[:part.total_bases]), shift), cq)
+
+
+def test_c4_many_genomes_one_plan(engine):
+    """One GPU's share of BASELINE configs[3]: 125 genomes (5 Mbp each) x 1 M reads of minimal-short in ONE plan:
+    every genome gets its reads in order, ids run through, a later shard equals the same range of the whole."""
+    import torch
+    eng = engine
+    n_g, per = 125, 1_000_000
+    slots = list(range(100, 100 + n_g))
+    for g, s in enumerate(slots):
+        eng.stage_synthetic(s, [5_000_000], 1000 + g)
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()
+    eng.counters_reset()
+    whole = eng.simulate_pe_reads_multi(slots, [per] * n_g, prof, 42, qual_offset=33)
+    n = whole.n_reads
+    assert n == n_g * per and eng.counters()[_abi.CNT_READS] == n
+    genome = whole.genome[:n].to(torch.int64)
+    expect = torch.arange(n, device=genome.device) // per + 100
+    assert bool((genome == expect).all())
+    ids = whole.read_id[:n].to(torch.int64)
+    assert bool((ids == torch.arange(n, device=ids.device) // 2).all())  # simulate.rs:85-89: one id per pair, in order
+    off = whole.seq_off[: n + 1]
+    # same seed for every genome (simulate.rs:137): genomes with one sequence each draw the same pe_seed list, hence
+    # the same lengths
+    l0 = (off[1:per + 1] - off[:per])
+    l7 = (off[7 * per + 1:8 * per + 1] - off[7 * per:8 * per])
+    assert bool((l0 == l7).all())
+    a_pair, n_pair = 3 * (per // 2) + 1234, 400_000  # a shard that crosses a genome boundary
+    part = eng.simulate_pe_reads_multi(slots, [per] * n_g, prof, 42, first=a_pair, count=n_pair, qual_offset=33)
+    a, b = int(off[2 * a_pair]), int(off[2 * (a_pair + n_pair)])
+    assert part.total_bases == b - a
+    shift = a % 256
+    assert torch.equal(torch.roll(colsum256(part.seq[:part.total_bases]), shift), checksum_range(whole.seq, a, b))
+    assert torch.equal(torch.roll(colsum256(part.qual[:part.total_bases]), shift), checksum_range(whole.qual, a, b))
