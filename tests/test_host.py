@@ -64,6 +64,13 @@ def test_no_device_fails_loudly():
     assert rc == _abi.ENODEV
 
 
+def test_missing_library_fails_loudly(tmp_path):
+    """No fallback: without the built HIP library the loader raises."""
+    with pytest.raises(ImportError) as ei:
+        _abi.load(tmp_path / "libsimmr_hip.so")
+    assert "build the HIP extension" in str(ei.value)
+
+
 def test_entropy_substitute_matches_oracle(oracle):
     lib = _abi.load()
     for x in (0, 1, 42, 2 ** 64 - 1, 9713269763989775522):
