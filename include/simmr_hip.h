@@ -286,6 +286,19 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
                     uint64_t seed, simmr_range shard, simmr_plan_info* info);
 int simmr_long_emit(simmr_engine* e, uint32_t read_id_base, const simmr_reads_out* out);
 
+/* ---- counters across GPUs ---------------------------------------------------
+ * The path has one exchange step: the sum of the run counters over the GPUs of a
+ * run.  One engine per process and device; rank 0 makes an id and hands it to the other ranks by
+ * whatever channel the host has; every rank then joins.  RCCL is loaded at run time
+ * (librccl.so.1), so a single-GPU user needs none.  Replaces nothing in the reference (it is a
+ * single process); the counters are what a maintainer would log next to the metadata TSV. */
+#define SIMMR_COMM_ID_BYTES 128
+int simmr_comm_unique_id(uint8_t* id128);                                   /* ncclGetUniqueId */
+int simmr_comm_init(simmr_engine* e, const uint8_t* id128, int rank, int world);  /* ncclCommInitRank on the engine's device */
+/* In-place sum over the ranks of n u64 values in device memory (ncclAllReduce on the engine's
+ * stream; asynchronous like the rest).  Without a communicator (one GPU) it does nothing. */
+int simmr_allreduce_counts(simmr_engine* e, uint64_t* counts_device, uint32_t n);
+
 /* ---- counters / timing ---------------------------------------------------- */
 /* Copies the SIMMR_N_COUNTERS running counters to a DEVICE array (for the
  * caller's all-reduce) and/or a HOST array; either may be NULL.  The device

@@ -18,6 +18,7 @@ OK, EINVAL, ENOMEM, ENODEV, ERANGE, ESTATE, EGENOME, ENOTSUP = 0, -22, -12, -19,
 
 # enum simmr_profile_kind
 PERFECT_SHORT, MINIMAL_SHORT, PERFECT_LONG, MINIMAL_LONG, CUSTOM = range(5)
+COMM_ID_BYTES = 128
 # enum simmr_rng_mode
 RNG_REFERENCE, RNG_PHILOX = 0, 1
 # enum simmr_length_mode
@@ -138,6 +139,9 @@ SYMBOLS = {
     "simmr_long_emit": (C.c_int, [C.c_void_p, C.c_uint32, _P(ReadsOut)]),
     "simmr_counters": (C.c_int, [C.c_void_p, C.c_void_p, _P(C.c_uint64)]),
     "simmr_counters_reset": (C.c_int, [C.c_void_p]),
+    "simmr_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "simmr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "simmr_allreduce_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "simmr_last_emit_kernel_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "simmr_last_plan_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "simmr_entropy_substitute": (C.c_uint64, [C.c_uint64, C.c_uint32]),

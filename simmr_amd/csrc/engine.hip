@@ -5,6 +5,7 @@
 // on one HIP stream.  No CPU compute path exists here: every entry point that
 // produces reads needs a gfx950 device.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <math.h>
 #include <stdarg.h>
@@ -64,6 +65,7 @@ struct simmr_engine {
   int device = -1;
   int n_cu = 0;
   hipStream_t stream = nullptr;
+  void* comm = nullptr;  // ncclComm_t of simmr_comm_init (RCCL, bound at run time)
   std::string err;
   std::vector<GenomeHost> genomes;
   DevBuf d_genomes;  // GenomeDev[genomes.size()]
@@ -670,10 +672,98 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
   return SIMMR_OK;
 }
 
+// ---- the run counters across GPUs: one all-reduce over RCCL ------------------------------
+// RCCL is bound at run time (dlopen), so that a process which already carries one (PyTorch bundles its own
+// librccl) keeps a single copy, and a single-GPU user needs none.
+namespace {
+struct RcclId { char internal[128]; };  // ncclUniqueId
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi* rccl_api(std::string* why) {
+  static RcclApi api;
+  static bool tried = false;
+  static std::string err;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) {
+      err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
+    } else {
+      api.GetUniqueId = (int (*)(RcclId*))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(api.lib, "ncclCommInitRank");
+      api.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(api.lib, "ncclAllReduce");
+      api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+      api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) {
+        err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+        api.lib = nullptr;
+      }
+    }
+  }
+  if (!api.lib) { if (why) *why = err; return nullptr; }
+  return &api;
+}
+void comm_release(simmr_engine* e) {
+  if (!e->comm) return;
+  if (RcclApi* a = rccl_api(nullptr)) (void)a->CommDestroy(e->comm);
+  e->comm = nullptr;
+}
+}  // namespace
+
+int simmr_comm_unique_id(uint8_t* id128) {
+  if (!id128) return SIMMR_EINVAL;
+  std::string why;
+  RcclApi* a = rccl_api(&why);
+  if (!a) return SIMMR_ENODEV;
+  RcclId id;
+  if (a->GetUniqueId(&id) != 0) return SIMMR_ENODEV;
+  memcpy(id128, id.internal, sizeof id.internal);
+  return SIMMR_OK;
+}
+
+int simmr_comm_init(simmr_engine* e, const uint8_t* id128, int rank, int world) {
+  if (!e) return SIMMR_EINVAL;
+  if (!id128 || world < 1 || rank < 0 || rank >= world) return e->fail(SIMMR_EINVAL, "bad communicator arguments (rank %d of %d)", rank, world);
+  HIP_TRY(e, hipSetDevice(e->device));
+  std::string why;
+  RcclApi* a = rccl_api(&why);
+  if (!a) return e->fail(SIMMR_ENODEV, "%s", why.c_str());
+  comm_release(e);
+  RcclId id;
+  memcpy(id.internal, id128, sizeof id.internal);
+  const int rc = a->CommInitRank(&e->comm, world, id, rank);
+  if (rc != 0) {
+    e->comm = nullptr;
+    return e->fail(SIMMR_ENODEV, "ncclCommInitRank: %s", a->GetErrorString ? a->GetErrorString(rc) : "error");
+  }
+  return SIMMR_OK;
+}
+
+int simmr_allreduce_counts(simmr_engine* e, uint64_t* counts_device, uint32_t n) {
+  if (!e) return SIMMR_EINVAL;
+  if (!e->comm) return SIMMR_OK;  // one GPU: nothing to add
+  if (!counts_device) return e->fail(SIMMR_EINVAL, "counts_device is NULL");
+  HIP_TRY(e, hipSetDevice(e->device));
+  RcclApi* a = rccl_api(nullptr);
+  const int rc = a->AllReduce(counts_device, counts_device, n, /* ncclUint64 */ 5, /* ncclSum */ 0, e->comm, e->stream);
+  if (rc != 0) return e->fail(SIMMR_ENODEV, "ncclAllReduce: %s", a->GetErrorString ? a->GetErrorString(rc) : "error");
+  return SIMMR_OK;
+}
+
 void simmr_engine_destroy(simmr_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
+  comm_release(e);
   for (auto& g : e->genomes) { g.packed.release(); g.mask.release(); g.d_contigs.release(); }
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_qs2,

@@ -283,6 +283,23 @@ class Engine:
     def counters_reset(self):
         self._check(self.lib.simmr_counters_reset(self._h))
 
+    # -- the counters across GPUs without torch.distributed: RCCL through the C ABI ------
+    def comm_unique_id(self) -> bytes:
+        """rank 0: an id to hand to the other ranks (ncclGetUniqueId)"""
+        buf = C.create_string_buffer(_abi.COMM_ID_BYTES)
+        rc = self.lib.simmr_comm_unique_id(buf)
+        if rc != 0:
+            raise SimmrError(rc, "simmr_comm_unique_id failed (is librccl loadable?)")
+        return buf.raw
+
+    def comm_init(self, comm_id: bytes, rank: int, world: int):
+        buf = C.create_string_buffer(bytes(comm_id), _abi.COMM_ID_BYTES)
+        self._check(self.lib.simmr_comm_init(self._h, buf, int(rank), int(world)))
+
+    def allreduce_counts(self, tensor):
+        """in-place sum over the ranks of a CUDA int64 tensor (a no-op without a communicator)"""
+        self._check(self.lib.simmr_allreduce_counts(self._h, C.c_void_p(tensor.data_ptr()), int(tensor.numel())))
+
     def last_emit_kernel_ms(self) -> float:
         ms = C.c_float()
         self._check(self.lib.simmr_last_emit_kernel_ms(self._h, C.byref(ms)))

@@ -706,3 +706,25 @@ def test_philox_mode_perfect_long(engine, oracle, genome_multi, genome_1m):
     ha, hb = np.bincount(dev["qual"], minlength=64) / n, np.bincount(ref["qual"], minlength=64) / n
     assert ha[41:].sum() == 0 and hb[41:].sum() == 0 and abs(ha[40] - hb[40]) < 0.005
     assert np.abs(ha - hb).max() < 0.005
+
+
+def test_counter_allreduce_through_the_abi(engine, genome_multi):
+    """simmr_comm_* / simmr_allreduce_counts (RCCL bound at run time): without a communicator the sum is a no-op;
+    a one-rank communicator leaves the counters as they are (more ranks need more GPUs than this box has)."""
+    import torch
+    prof = PerfectShortErrorProfile(50, 70).pod()
+    engine.counters_reset()
+    engine.simulate_pe_reads_from_genome(1, prof, 2000, 3)
+    t = torch.zeros(_abi.N_COUNTERS, dtype=torch.int64, device=engine.device)
+    engine.counters_to(t)
+    torch.cuda.synchronize()
+    before = t.clone()
+    engine.allreduce_counts(t)  # no communicator yet
+    torch.cuda.synchronize()
+    assert torch.equal(t, before) and int(t[_abi.CNT_READS]) == 2000
+    cid = engine.comm_unique_id()
+    assert len(cid) == _abi.COMM_ID_BYTES
+    engine.comm_init(cid, 0, 1)
+    engine.allreduce_counts(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t, before)
