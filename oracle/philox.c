@@ -4,20 +4,27 @@
  * CPU restatement of the SIMMR_RNG_PHILOX mode of include/simmr_hip.h — the
  * counter-based mode BASELINE.json's north_star prescribes for the per-base
  * draws (tolerance parity only; it is NOT the reference's generator).  The
- * specification lives here and in DESIGN.md §4:
+ * specification lives here and in DESIGN.md §4 (version 2 of the mode: a
+ * two-level draw, 16 bits per base on the common outcomes and one full word on
+ * the rare ones):
  *   - Philox4x32-10 (Salmon et al., SC'11; Random123 constants), key = the
- *     read's Phred seed (pe_seed / drawn-or-substituted mate-2 seed / read_seed),
- *     counter = (b >> 2, 0, 'simm', 'r\0\0\1'); base b takes output word b & 3.
- *   - that one word W draws the Phred score and the substitution together from
- *     the joint law of minimal_short.rs:83-140 with an alias table over the 1024
- *     outcomes o = q | s << 8:
+ *     read's Phred seed (pe_seed / drawn-or-substituted mate-2 seed / read_seed).
+ *   - the joint law of minimal_short.rs:83-140 over the 1024 outcomes o = q | s << 8:
  *       P(q)      = P(floor(N(mean,10)) saturated to u8 == q)                    (minimal profiles)
  *                 = P(round(-10 log10(1 - min(N(0.99, 0.05), 0.9999))) == q)      (perfect-long,
  *                   perfect_long.rs:60-78: q = 40 carries the mass of the 0.9999 cap)
  *       p_q       = P(gen::<f32>() > accuracy(q)) = (2^24 - 1 - t) / 2^24,
  *                   t = min(floor(accuracy(q) * 2^24), 2^24 - 1)   (the reference's 24-bit test)
  *       w(q, 0)   = P(q) (1 - p_q),   w(q, s) = P(q) p_q / 3 for s = 1, 2, 3
- *       idx = W >> 22, frac = W & 0x3fffff, o = frac < thr22[idx] ? idx : alias[idx]
+ *     is split exactly into  w(o) = c(o) / 2^16 + (E / 2^16) r(o):  c(o) = floor(2^16 w(o)) cells of a
+ *     16-bit draw, E = 2^16 - sum c(o) "escape" cells, r(o) = (2^16 w(o) - c(o)) / E the residual law.
+ *   - level 1: counter (b >> 3, 0, 'simm', 'r\0\0\2'); base b takes half (b & 1) (0 = low 16 bits) of
+ *     output word (b & 7) >> 1.  That 16-bit value v picks column idx = (v >> 3) & 1023 of a 1024-column
+ *     alias table whose thresholds count 64ths: f = (v >> 13) << 3 | (v & 7), outcome = f < T[idx] ? A[idx]
+ *     : B[idx] (integer Vose construction over the cells c(o) and the E escape cells).
+ *   - level 2, only when level 1 answered "escape" (about 0.14 % of the bases): counter
+ *     (b >> 2, 1, 'simm', 'r\0\0\2'), output word b & 3 = W; idx = W >> 22, frac = W & 0x3fffff,
+ *     o = frac < thr22[idx] ? idx : alias[idx] over the residual law r(o).
  *   - s > 0 and the base is ACGT: the base becomes "ACGT"[(code + s) & 3] — each of
  *     the three other bases with probability 1/3, as SliceRandom::choose does
  *     (minimal_short.rs:121-128); non-ACGT bases are left alone.
@@ -55,11 +62,8 @@ static double phred_cdf_upper(uint32_t kind, double mean, int q) { /* P(Phred <=
   return 0.5 * erfc(-(((double)(q + 1) - mean) / 10.0) / 1.4142135623730951);
 }
 
-/* table[i] = thr22 | alias << 22 with thr22 in [0, 2^22 - 1], i = q | s << 8 */
-void orc_philox_joint_table(uint32_t kind, uint8_t mean_phred, uint32_t table[1024]) {
-  enum { N = 1024 };
-  double odds[N];
-  int alias[N], smalls[N], bigs[N];
+/* w[o] = the joint law over o = q | s << 8 */
+static void joint_law(uint32_t kind, uint8_t mean_phred, double w[1024]) {
   double cdf_prev = 0.0;
   const double mean = (double)mean_phred;
   for (int q = 0; q < 256; q++) {
@@ -70,10 +74,16 @@ void orc_philox_joint_table(uint32_t kind, uint8_t mean_phred, uint32_t table[10
     float tf = floorf(orc_convert_phred_to_accuracy((uint8_t)q) * 16777216.0f);
     double t = tf > 16777215.0f ? 16777215.0 : (double)tf;
     double pq = (16777215.0 - t) / 16777216.0;
-    odds[q] = P * (1.0 - pq) * (double)N;
-    for (int s = 1; s < 4; s++) odds[q + 256 * s] = P * pq / 3.0 * (double)N;
+    w[q] = P * (1.0 - pq);
+    for (int s = 1; s < 4; s++) w[q + 256 * s] = P * pq / 3.0;
   }
-  /* Vose alias method, worklists as LIFO stacks filled in increasing index order */
+}
+
+/* Vose alias method over 1024 columns of odds[] (mean 1), worklists as LIFO stacks filled in increasing
+ * index order; table[i] = thr22 | alias << 22 with thr22 in [0, 2^22 - 1] */
+static void alias22(double odds[1024], uint32_t table[1024]) {
+  enum { N = 1024 };
+  int alias[N], smalls[N], bigs[N];
   int ns = 0, nb = 0;
   for (int i = 0; i < N; i++) alias[i] = i;
   for (int i = 0; i < N; i++) { if (odds[i] < 1.0) smalls[ns++] = i; else bigs[nb++] = i; }
@@ -92,23 +102,85 @@ void orc_philox_joint_table(uint32_t kind, uint8_t mean_phred, uint32_t table[10
   }
 }
 
+/* The two tables of the mode.
+ *   t1[col] = T | A << 8 | B << 20: T in [0, 64] 64ths of the column that answer A, the rest answer B;
+ *             A, B = outcome q | s << 8, or ORC_PHILOX_ESC (1024) = "draw again at level 2"
+ *   t2[idx] = thr22 | alias << 22 over the residual law (all zero when there is no escape cell)
+ * returns E, the number of escape cells among the 65536 */
+uint32_t orc_philox_tables(uint32_t kind, uint8_t mean_phred, uint32_t t1[1024], uint32_t t2[1024]) {
+  enum { N = 1024, CELLS = 65536, UNIT = 64 };
+  double w[N], odds[N];
+  int64_t c[N];
+  joint_law(kind, mean_phred, w);
+  int64_t sum = 0;
+  int nz = 0;
+  for (int o = 0; o < N; o++) {
+    c[o] = (int64_t)floor(w[o] * (double)CELLS);
+    sum += c[o];
+    if (c[o] > 0) nz++;
+  }
+  int64_t E = (int64_t)CELLS - sum;
+  /* a column per outcome with cells, one more for the escape: give up the smallest outcomes if that is too many */
+  while (E < 0 || nz + (E > 0 ? 1 : 0) > N) {
+    int m = -1;
+    for (int o = 0; o < N; o++) if (c[o] > 0 && (m < 0 || c[o] < c[m])) m = o;
+    E += c[m]; c[m] = 0; nz--;
+  }
+  /* integer Vose: column k < n holds entry k (outcomes with cells in increasing order, then the escape) */
+  int64_t wt[N];
+  uint32_t prim[N];
+  int alias[N], smalls[N], bigs[N], T[N];
+  int n = 0;
+  for (int o = 0; o < N; o++) if (c[o] > 0) { prim[n] = (uint32_t)o; wt[n] = c[o]; n++; }
+  if (E > 0) { prim[n] = ORC_PHILOX_ESC; wt[n] = E; n++; }
+  for (int k = n; k < N; k++) { prim[k] = prim[0]; wt[k] = 0; }
+  int ns = 0, nb = 0;
+  for (int k = 0; k < N; k++) { alias[k] = k; T[k] = UNIT; }
+  for (int k = 0; k < N; k++) { if (wt[k] < UNIT) smalls[ns++] = k; else bigs[nb++] = k; }
+  while (ns > 0 && nb > 0) {
+    int s = smalls[--ns], b = bigs[--nb];
+    alias[s] = b;
+    T[s] = (int)wt[s];
+    wt[b] -= UNIT - wt[s];
+    if (wt[b] < UNIT) smalls[ns++] = b; else bigs[nb++] = b;
+  }
+  for (int k = 0; k < N; k++) t1[k] = (uint32_t)T[k] | (prim[k] << 8) | (prim[alias[k]] << 20);
+  /* residual law */
+  if (E > 0) {
+    for (int o = 0; o < N; o++) odds[o] = (w[o] * (double)CELLS - (double)c[o]) / (double)E * (double)N;
+    alias22(odds, t2);
+  } else {
+    memset(t2, 0, N * sizeof(uint32_t));
+  }
+  return (uint32_t)E;
+}
+
 /* One read: qualities for bases [0, len) and the mutated copy of `seq` (forward-strand slice order). */
 void orc_philox_read(const simmr_error_profile* p, const uint8_t* seq, uint64_t len, uint64_t key64,
                      uint8_t* qual_out, uint8_t* seq_out) {
-  static _Thread_local uint32_t table[1024];
+  static _Thread_local uint32_t t1[1024], t2[1024];
   static _Thread_local int table_for = -1;
   const int want = (int)p->mean_phred | (p->kind == SIMMR_PERFECT_LONG ? 0x100 : 0);
-  if (table_for != want) { orc_philox_joint_table(p->kind, p->mean_phred, table); table_for = want; }
+  if (table_for != want) { orc_philox_tables(p->kind, p->mean_phred, t1, t2); table_for = want; }
   const uint32_t key[2] = {(uint32_t)key64, (uint32_t)(key64 >> 32)};
   uint32_t w[4] = {0, 0, 0, 0};
   for (uint64_t b = 0; b < len; b++) {
-    if ((b & 3) == 0) {
-      const uint32_t ctr[4] = {(uint32_t)(b >> 2), 0u, 0x73696D6Du, 0x72000001u};
+    if ((b & 7) == 0) {
+      const uint32_t ctr[4] = {(uint32_t)(b >> 3), 0u, 0x73696D6Du, 0x72000002u};
       orc_philox4x32_10(ctr, key, w);
     }
-    const uint32_t W = w[b & 3];
-    const uint32_t e = table[W >> 22];
-    const uint32_t o = ((W & 0x3fffffu) < (e & 0x3fffffu)) ? (W >> 22) : (e >> 22);
+    const uint32_t v = (w[(b & 7) >> 1] >> (16 * (b & 1))) & 0xffffu;
+    const uint32_t e = t1[(v >> 3) & 1023u];
+    const uint32_t f = ((v >> 13) << 3) | (v & 7u);
+    uint32_t o = f < (e & 0x7fu) ? (e >> 8) & 0x7ffu : e >> 20;
+    if (o == ORC_PHILOX_ESC) {
+      const uint32_t ctr2[4] = {(uint32_t)(b >> 2), 1u, 0x73696D6Du, 0x72000002u};
+      uint32_t w2[4];
+      orc_philox4x32_10(ctr2, key, w2);
+      const uint32_t W = w2[b & 3];
+      const uint32_t e2 = t2[W >> 22];
+      o = ((W & 0x3fffffu) < (e2 & 0x3fffffu)) ? (W >> 22) : (e2 >> 22);
+    }
     const uint32_t q = o & 0xffu, sft = o >> 8;
     qual_out[b] = (uint8_t)q;
     uint8_t nt = seq[b];

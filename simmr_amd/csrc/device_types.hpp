@@ -34,6 +34,7 @@ struct GenomeDev {
 };
 
 #define SIMMR_K_CUSTOM 4u
+#define PHILOX_ESC 1024u /* level-1 answer of the counter mode: draw again at level 2 */
 #define SIMMR_ERRBIT_FASTQ 8u /* a FASTQ header does not fit, or a genome / contig index has no name */
 #define SIMMR_ERRBIT_KMER 16u /* simulate_errors chose an alternate the reference cannot splice (deletion / bad code / bad weights) */
 #define SIMMR_ERRBIT_PDF 4u /* custom PDF picked a bin without a range (a reference panic) or ran out of words */
@@ -82,8 +83,12 @@ struct ProfileDev {
   double read_length_std, insert_size_std;
   CustomDev custom;
   uint32_t long_start_uniform;   // SIMMR_START_UNIFORM
-  const uint32_t* philox_phred;  // SIMMR_RNG_PHILOX: 1024 joint alias entries (thr22 | alias << 22)
-  uint32_t philox_qmax;          // largest Phred the alias table can return
+  // SIMMR_RNG_PHILOX: level 1 = 1024 columns of a 16-bit draw, T | A << 8 | B << 20 (T 64ths
+  // answer outcome A, the rest B; outcome = q | s << 8 or PHILOX_ESC); level 2 = 1024 alias entries
+  // thr22 | alias << 22 over the residual law behind the escape cells
+  const uint32_t* philox_t1;
+  const uint32_t* philox_t2;
+  uint32_t philox_qmax;          // largest Phred either table can return
 };
 
 struct Key8 {

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <random>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "kernels.hip"
@@ -368,15 +369,14 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
       return e->fail(SIMMR_EINVAL, "negative standard deviation");
   }
   if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind != SIMMR_PERFECT_SHORT) {
-    // Joint (Phred, substitution) alias table over the 1024 outcomes o = q | s << 8:
-    // w(q,0) = P(q)(1 - p_q), w(q,s) = P(q) p_q / 3; P(q) = P(floor(N(mean, 10)) saturated to u8 == q),
-    // p_q = the probability of the reference's 24-bit test gen::<f32>() > accuracy(q).  Vose's method
-    // with LIFO worklists filled in increasing index order; entry = thr22 | alias << 22.
-    constexpr int N = 1024;
-    std::vector<double> odds(N);
-    std::vector<int> alias(N), smalls(N), bigs(N);
+    // The two tables of the counter mode (restated in oracle/philox.c).  The joint law over the 1024
+    // outcomes o = q | s << 8, w(q,0) = P(q)(1 - p_q), w(q,s) = P(q) p_q / 3 (P(q) = the profile's Phred law,
+    // p_q = the probability of the reference's 24-bit test gen::<f32>() > accuracy(q), minimal_short.rs:83-140),
+    // is split exactly into c(o) = floor(2^16 w(o)) cells of a 16-bit draw plus E escape cells that lead to a
+    // full-word draw from the residual law (2^16 w(o) - c(o)) / E.
+    constexpr int N = 1024, CELLS = 65536, UNIT = 64;
+    std::vector<double> w(N), odds(N);
     double prev = 0.0;
-    int ns = 0, nb = 0;
     for (int q = 0; q < 256; q++) {
       // P(Phred <= q): minimal profiles floor(N(mean, 10)) saturated to u8; perfect-long (perfect_long.rs:60-78)
       // round(-10 log10(1 - min(N(0.99, 0.05), 0.9999))), whose cap puts everything above 0.9999 on q = 40
@@ -393,31 +393,74 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
       const float tf = floorf(acc * 16777216.0f);
       const double t = tf > 16777215.0f ? 16777215.0 : (double)tf;
       const double pq = (16777215.0 - t) / 16777216.0;
-      odds[q] = P * (1.0 - pq) * (double)N;
-      for (int sft = 1; sft < 4; sft++) odds[q + 256 * sft] = P * pq / 3.0 * (double)N;
+      w[q] = P * (1.0 - pq);
+      for (int sft = 1; sft < 4; sft++) w[q + 256 * sft] = P * pq / 3.0;
     }
-    for (int i = 0; i < N; i++) alias[i] = i;
-    for (int i = 0; i < N; i++) { if (odds[i] < 1.0) smalls[ns++] = i; else bigs[nb++] = i; }
+    std::vector<int64_t> cells(N), wt(N);
+    int64_t sum = 0;
+    int nz = 0;
+    for (int o = 0; o < N; o++) {
+      cells[o] = (int64_t)floor(w[o] * (double)CELLS);
+      sum += cells[o];
+      if (cells[o] > 0) nz++;
+    }
+    int64_t E = (int64_t)CELLS - sum;
+    while (E < 0 || nz + (E > 0 ? 1 : 0) > N) {  // one column per outcome with cells and one for the escape
+      int m = -1;
+      for (int o = 0; o < N; o++) if (cells[o] > 0 && (m < 0 || cells[o] < cells[m])) m = o;
+      E += cells[m]; cells[m] = 0; nz--;
+    }
+    // level 1: integer Vose over the entries (outcomes with cells in increasing order, then the escape), 64 cells
+    // per column, LIFO worklists filled in increasing column order
+    std::vector<uint32_t> prim(N);
+    std::vector<int> alias(N), smalls(N), bigs(N), T(N);
+    int n = 0, ns = 0, nb = 0;
+    for (int o = 0; o < N; o++) if (cells[o] > 0) { prim[n] = (uint32_t)o; wt[n] = cells[o]; n++; }
+    if (E > 0) { prim[n] = PHILOX_ESC; wt[n] = E; n++; }
+    for (int k = n; k < N; k++) { prim[k] = prim[0]; wt[k] = 0; }
+    for (int k = 0; k < N; k++) { alias[k] = k; T[k] = UNIT; }
+    for (int k = 0; k < N; k++) { if (wt[k] < UNIT) smalls[ns++] = k; else bigs[nb++] = k; }
     while (ns > 0 && nb > 0) {
       const int sm = smalls[--ns], bg = bigs[--nb];
       alias[sm] = bg;
-      odds[bg] = odds[bg] - 1.0 + odds[sm];
-      if (odds[bg] < 1.0) smalls[ns++] = bg; else bigs[nb++] = bg;
+      T[sm] = (int)wt[sm];
+      wt[bg] -= UNIT - wt[sm];
+      if (wt[bg] < UNIT) smalls[ns++] = bg; else bigs[nb++] = bg;
     }
-    while (ns > 0) odds[smalls[--ns]] = 1.0;
-    while (nb > 0) odds[bigs[--nb]] = 1.0;
-    std::vector<uint32_t> table(N);
+    std::vector<uint32_t> table(2 * N, 0u);  // [0, N): level 1 (T | A << 8 | B << 20), [N, 2N): level 2 (thr22 | alias << 22)
     d.philox_qmax = 0;
-    for (int i = 0; i < N; i++) {
-      const double t = floor(odds[i] * 4194304.0);
-      const uint32_t thr = t >= 4194303.0 ? 4194303u : (t <= 0.0 ? 0u : (uint32_t)t);
-      table[i] = thr | ((uint32_t)alias[i] << 22);
-      if (thr > 0 && (uint32_t)(i & 255) > d.philox_qmax) d.philox_qmax = (uint32_t)(i & 255);
-      if ((uint32_t)(alias[i] & 255) > d.philox_qmax) d.philox_qmax = (uint32_t)(alias[i] & 255);
+    auto see = [&](uint32_t o) { if (o != PHILOX_ESC && (o & 255u) > d.philox_qmax) d.philox_qmax = o & 255u; };
+    for (int k = 0; k < N; k++) {
+      table[k] = (uint32_t)T[k] | (prim[k] << 8) | (prim[alias[k]] << 20);
+      if (T[k] > 0) see(prim[k]);
+      if (T[k] < UNIT) see(prim[alias[k]]);
+    }
+    // level 2: Vose's method on the residual law, LIFO worklists filled in increasing index order
+    if (E > 0) {
+      for (int o = 0; o < N; o++) odds[o] = (w[o] * (double)CELLS - (double)cells[o]) / (double)E * (double)N;
+      ns = nb = 0;
+      for (int i = 0; i < N; i++) alias[i] = i;
+      for (int i = 0; i < N; i++) { if (odds[i] < 1.0) smalls[ns++] = i; else bigs[nb++] = i; }
+      while (ns > 0 && nb > 0) {
+        const int sm = smalls[--ns], bg = bigs[--nb];
+        alias[sm] = bg;
+        odds[bg] = odds[bg] - 1.0 + odds[sm];
+        if (odds[bg] < 1.0) smalls[ns++] = bg; else bigs[nb++] = bg;
+      }
+      while (ns > 0) odds[smalls[--ns]] = 1.0;
+      while (nb > 0) odds[bigs[--nb]] = 1.0;
+      for (int i = 0; i < N; i++) {
+        const double t = floor(odds[i] * 4194304.0);
+        const uint32_t thr = t >= 4194303.0 ? 4194303u : (t <= 0.0 ? 0u : (uint32_t)t);
+        table[N + i] = thr | ((uint32_t)alias[i] << 22);
+        if (thr > 0) see((uint32_t)i);
+        if (thr < 4194303u) see((uint32_t)alias[i]);
+      }
     }
     int rc = upload_vec(e, e->ph_table, table);
     if (rc || (rc = sync_check(e, "philox table upload"))) return rc;
-    d.philox_phred = e->ph_table.as<uint32_t>();
+    d.philox_t1 = e->ph_table.as<uint32_t>();
+    d.philox_t2 = e->ph_table.as<uint32_t>() + N;
   }
   *out = d;
   return SIMMR_OK;
@@ -687,16 +730,24 @@ struct RcclApi {
 };
 RcclApi* rccl_api(std::string* why) {
   static RcclApi api;
-  static bool tried = false;
   static std::string err;
-  if (!tried) {
-    tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // SIMMR_RCCL_LIB names the library to load instead of the default candidates (a test points it at a missing
+    // file to check the failure path; a deployment may pin one copy of RCCL with it)
+    const char* forced = getenv("SIMMR_RCCL_LIB");
+    std::vector<const char*> names;
+    if (forced && *forced) names = {forced};
+    else names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string last = "?";
+    for (const char* name : names) {
       api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (api.lib) break;
+      const char* m = dlerror();  // glibc clears the message once it has been read: read it once
+      if (m) last = m;
     }
     if (!api.lib) {
-      err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
+      err = std::string("cannot load librccl: ") + last;
     } else {
       api.GetUniqueId = (int (*)(RcclId*))dlsym(api.lib, "ncclGetUniqueId");
       api.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(api.lib, "ncclCommInitRank");
@@ -708,7 +759,7 @@ RcclApi* rccl_api(std::string* why) {
         api.lib = nullptr;
       }
     }
-  }
+  });
   if (!api.lib) { if (why) *why = err; return nullptr; }
   return &api;
 }
@@ -778,6 +829,18 @@ void simmr_engine_destroy(simmr_engine* e) {
   if (e->ev_d) (void)hipEventDestroy(e->ev_d);
   delete e;
 }
+
+#if defined(SIMMR_STAMPS)
+// diagnostic build only: read and clear the phase cycle sums of k_emit_philox (kernels.hip, PH_STAMP)
+extern "C" int simmr_debug_stamps(uint64_t* out16) {
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(simmr::g_philox_stamps), sizeof h) != hipSuccess) return SIMMR_ENODEV;
+  for (int i = 0; i < 16; i++) out16[i] = h[i];
+  memset(h, 0, sizeof h);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(simmr::g_philox_stamps), h, sizeof h) != hipSuccess) return SIMMR_ENODEV;
+  return SIMMR_OK;
+}
+#endif
 
 int simmr_engine_set_stream(simmr_engine* e, void* hip_stream) {
   if (!e) return SIMMR_EINVAL;

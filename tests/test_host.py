@@ -156,3 +156,21 @@ def test_integration_doc_binds_every_symbol():
     assert len(names) >= 20
     missing = [n for n in sorted(names) if f"pub fn {n}(" not in doc]
     assert not missing, missing
+
+
+def test_missing_rccl_answers_enodev_without_a_gpu():
+    """A host whose librccl cannot be loaded gets SIMMR_ENODEV from the communicator entry points, not a crash
+    (engine.hip:rccl_api reads dlerror() once).  Own process: the loader result is cached per process."""
+    import subprocess, sys
+    code = (
+        "import ctypes as C\n"
+        "from simmr_amd import _abi\n"
+        "lib = _abi.load()\n"
+        "buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()\n"
+        "rc = lib.simmr_comm_unique_id(buf)\n"
+        "rc2 = lib.simmr_comm_unique_id(buf)\n"
+        "print(rc, rc2)\n")
+    env = dict(__import__("os").environ, SIMMR_RCCL_LIB="/nonexistent/librccl-missing.so", PYTHONPATH=str(ROOT))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == [str(_abi.ENODEV)] * 2
