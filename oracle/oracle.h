@@ -201,7 +201,7 @@ int64_t orc_custom_simulate_errors(const orc_model* m, const uint8_t* seq, uint6
 /* ---------------- SIMMR_RNG_PHILOX mode (philox.c): counter-based per-base draws */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 #define ORC_PHILOX_ESC 1024u /* level-1 answer "draw again at level 2" */
-uint32_t orc_philox_tables(uint32_t kind, uint8_t mean_phred, uint32_t t1[1024], uint32_t t2[1024]);
+uint32_t orc_philox_tables(uint32_t kind, uint8_t mean_phred, uint64_t t1[1024], uint32_t t2[1024]);
 void orc_philox_read(const simmr_error_profile* p, const uint8_t* seq, uint64_t len, uint64_t key64,
                      uint8_t* qual_out, uint8_t* seq_out);
 

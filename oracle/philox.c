@@ -4,8 +4,8 @@
  * CPU restatement of the SIMMR_RNG_PHILOX mode of include/simmr_hip.h — the
  * counter-based mode BASELINE.json's north_star prescribes for the per-base
  * draws (tolerance parity only; it is NOT the reference's generator).  The
- * specification lives here and in DESIGN.md §4 (version 2 of the mode: a
- * two-level draw, 16 bits per base on the common outcomes and one full word on
+ * specification lives here and in DESIGN.md §4 (version 3 of the mode: a
+ * two-level draw, 24 bits per base on the common outcomes and one full word on
  * the rare ones):
  *   - Philox4x32-10 (Salmon et al., SC'11; Random123 constants), key = the
  *     read's Phred seed (pe_seed / drawn-or-substituted mate-2 seed / read_seed).
@@ -16,15 +16,16 @@
  *       p_q       = P(gen::<f32>() > accuracy(q)) = (2^24 - 1 - t) / 2^24,
  *                   t = min(floor(accuracy(q) * 2^24), 2^24 - 1)   (the reference's 24-bit test)
  *       w(q, 0)   = P(q) (1 - p_q),   w(q, s) = P(q) p_q / 3 for s = 1, 2, 3
- *     is split exactly into  w(o) = c(o) / 2^16 + (E / 2^16) r(o):  c(o) = floor(2^16 w(o)) cells of a
- *     16-bit draw, E = 2^16 - sum c(o) "escape" cells, r(o) = (2^16 w(o) - c(o)) / E the residual law.
- *   - level 1: counter (b >> 3, 0, 'simm', 'r\0\0\2'); base b takes half (b & 1) (0 = low 16 bits) of
- *     output word (b & 7) >> 1.  That 16-bit value v picks column idx = (v >> 3) & 1023 of a 1024-column
- *     alias table whose thresholds count 64ths: f = (v >> 13) << 3 | (v & 7), outcome = f < T[idx] ? A[idx]
+ *     is split exactly into  w(o) = c(o) / 2^24 + (E / 2^24) r(o):  c(o) = floor(2^24 w(o)) cells of a
+ *     24-bit draw, E = 2^24 - sum c(o) "escape" cells (E ~ 120), r(o) = (2^24 w(o) - c(o)) / E the residual law.
+ *   - level 1: 24 bits per base.  The 16 bases of group g = b >> 4 share the 384 bits of three calls, counters
+ *     (3g, 0, 'simm', 'r\0\0\3'), (3g + 1, ...), (3g + 2, ...), output words in order = a little-endian bit
+ *     string; base b takes bits [24 (b & 15), 24 (b & 15) + 24) = F.  F picks column idx = F >> 14 of a
+ *     1024-column alias table whose thresholds count 16384ths: f = F & 0x3fff, outcome = f < T[idx] ? A[idx]
  *     : B[idx] (integer Vose construction over the cells c(o) and the E escape cells).
- *   - level 2, only when level 1 answered "escape" (about 0.14 % of the bases): counter
- *     (b >> 2, 1, 'simm', 'r\0\0\2'), output word b & 3 = W; idx = W >> 22, frac = W & 0x3fffff,
- *     o = frac < thr22[idx] ? idx : alias[idx] over the residual law r(o).
+ *   - level 2, only when level 1 answered "escape" (7e-6 of the bases): counter (b >> 2, 1, 'simm', 'r\0\0\3'),
+ *     output word b & 3 = W; idx = W >> 22, frac = W & 0x3fffff, o = frac < thr22[idx] ? idx : alias[idx] over
+ *     the residual law r(o).
  *   - s > 0 and the base is ACGT: the base becomes "ACGT"[(code + s) & 3] — each of
  *     the three other bases with probability 1/3, as SliceRandom::choose does
  *     (minimal_short.rs:121-128); non-ACGT bases are left alone.
@@ -103,12 +104,12 @@ static void alias22(double odds[1024], uint32_t table[1024]) {
 }
 
 /* The two tables of the mode.
- *   t1[col] = T | A << 8 | B << 20: T in [0, 64] 64ths of the column that answer A, the rest answer B;
+ *   t1[col] = T | A << 16 | B << 32: T in [0, 16384] 16384ths of the column that answer A, the rest answer B;
  *             A, B = outcome q | s << 8, or ORC_PHILOX_ESC (1024) = "draw again at level 2"
  *   t2[idx] = thr22 | alias << 22 over the residual law (all zero when there is no escape cell)
- * returns E, the number of escape cells among the 65536 */
-uint32_t orc_philox_tables(uint32_t kind, uint8_t mean_phred, uint32_t t1[1024], uint32_t t2[1024]) {
-  enum { N = 1024, CELLS = 65536, UNIT = 64 };
+ * returns E, the number of escape cells among the 2^24 */
+uint32_t orc_philox_tables(uint32_t kind, uint8_t mean_phred, uint64_t t1[1024], uint32_t t2[1024]) {
+  enum { N = 1024, CELLS = 16777216, UNIT = 16384 };
   double w[N], odds[N];
   int64_t c[N];
   joint_law(kind, mean_phred, w);
@@ -144,7 +145,7 @@ uint32_t orc_philox_tables(uint32_t kind, uint8_t mean_phred, uint32_t t1[1024],
     wt[b] -= UNIT - wt[s];
     if (wt[b] < UNIT) smalls[ns++] = b; else bigs[nb++] = b;
   }
-  for (int k = 0; k < N; k++) t1[k] = (uint32_t)T[k] | (prim[k] << 8) | (prim[alias[k]] << 20);
+  for (int k = 0; k < N; k++) t1[k] = (uint64_t)T[k] | ((uint64_t)prim[k] << 16) | ((uint64_t)prim[alias[k]] << 32);
   /* residual law */
   if (E > 0) {
     for (int o = 0; o < N; o++) odds[o] = (w[o] * (double)CELLS - (double)c[o]) / (double)E * (double)N;
@@ -158,23 +159,28 @@ uint32_t orc_philox_tables(uint32_t kind, uint8_t mean_phred, uint32_t t1[1024],
 /* One read: qualities for bases [0, len) and the mutated copy of `seq` (forward-strand slice order). */
 void orc_philox_read(const simmr_error_profile* p, const uint8_t* seq, uint64_t len, uint64_t key64,
                      uint8_t* qual_out, uint8_t* seq_out) {
-  static _Thread_local uint32_t t1[1024], t2[1024];
+  static _Thread_local uint64_t t1[1024];
+  static _Thread_local uint32_t t2[1024];
   static _Thread_local int table_for = -1;
   const int want = (int)p->mean_phred | (p->kind == SIMMR_PERFECT_LONG ? 0x100 : 0);
   if (table_for != want) { orc_philox_tables(p->kind, p->mean_phred, t1, t2); table_for = want; }
   const uint32_t key[2] = {(uint32_t)key64, (uint32_t)(key64 >> 32)};
-  uint32_t w[4] = {0, 0, 0, 0};
+  uint32_t w[13] = {0};  /* the 12 words of a group, one more so that a 64-bit window can be read at word 11 */
   for (uint64_t b = 0; b < len; b++) {
-    if ((b & 7) == 0) {
-      const uint32_t ctr[4] = {(uint32_t)(b >> 3), 0u, 0x73696D6Du, 0x72000002u};
-      orc_philox4x32_10(ctr, key, w);
+    if ((b & 15) == 0) {
+      for (uint32_t c = 0; c < 3; c++) {
+        const uint32_t ctr[4] = {(uint32_t)(3 * (b >> 4) + c), 0u, 0x73696D6Du, 0x72000003u};
+        orc_philox4x32_10(ctr, key, w + 4 * c);
+      }
     }
-    const uint32_t v = (w[(b & 7) >> 1] >> (16 * (b & 1))) & 0xffffu;
-    const uint32_t e = t1[(v >> 3) & 1023u];
-    const uint32_t f = ((v >> 13) << 3) | (v & 7u);
-    uint32_t o = f < (e & 0x7fu) ? (e >> 8) & 0x7ffu : e >> 20;
+    const uint32_t bit = 24u * (uint32_t)(b & 15);
+    const uint64_t win = (uint64_t)w[bit >> 5] | ((uint64_t)w[(bit >> 5) + 1] << 32);
+    const uint32_t F = (uint32_t)(win >> (bit & 31)) & 0xffffffu;
+    const uint64_t e = t1[F >> 14];
+    const uint32_t f = F & 0x3fffu;
+    uint32_t o = f < (uint32_t)(e & 0xffffu) ? (uint32_t)(e >> 16) & 0xffffu : (uint32_t)(e >> 32);
     if (o == ORC_PHILOX_ESC) {
-      const uint32_t ctr2[4] = {(uint32_t)(b >> 2), 1u, 0x73696D6Du, 0x72000002u};
+      const uint32_t ctr2[4] = {(uint32_t)(b >> 2), 1u, 0x73696D6Du, 0x72000003u};
       uint32_t w2[4];
       orc_philox4x32_10(ctr2, key, w2);
       const uint32_t W = w2[b & 3];

@@ -83,9 +83,9 @@ struct ProfileDev {
   double read_length_std, insert_size_std;
   CustomDev custom;
   uint32_t long_start_uniform;   // SIMMR_START_UNIFORM
-  // SIMMR_RNG_PHILOX: level 1 = 1024 columns of a 16-bit draw, T | A << 8 | B << 20 (T 64ths
-  // answer outcome A, the rest B; outcome = q | s << 8 or PHILOX_ESC); level 2 = 1024 alias entries
-  // thr22 | alias << 22 over the residual law behind the escape cells
+  // SIMMR_RNG_PHILOX: level 1 = 1024 columns of a 24-bit draw, philox_t1[c] = T | A << 16 and
+  // philox_t1[1024 + c] = B (T 16384ths of column c answer outcome A, the rest B; outcome = q | s << 8 or PHILOX_ESC);
+  // level 2 = 1024 alias entries thr22 | alias << 22 over the residual law behind the escape cells
   const uint32_t* philox_t1;
   const uint32_t* philox_t2;
   uint32_t philox_qmax;          // largest Phred either table can return

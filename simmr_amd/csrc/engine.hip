@@ -372,9 +372,9 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
     // The two tables of the counter mode (restated in oracle/philox.c).  The joint law over the 1024
     // outcomes o = q | s << 8, w(q,0) = P(q)(1 - p_q), w(q,s) = P(q) p_q / 3 (P(q) = the profile's Phred law,
     // p_q = the probability of the reference's 24-bit test gen::<f32>() > accuracy(q), minimal_short.rs:83-140),
-    // is split exactly into c(o) = floor(2^16 w(o)) cells of a 16-bit draw plus E escape cells that lead to a
-    // full-word draw from the residual law (2^16 w(o) - c(o)) / E.
-    constexpr int N = 1024, CELLS = 65536, UNIT = 64;
+    // is split exactly into c(o) = floor(2^24 w(o)) cells of a 24-bit draw plus E escape cells that lead to a
+    // full-word draw from the residual law (2^24 w(o) - c(o)) / E.
+    constexpr int N = 1024, CELLS = 16777216, UNIT = 16384;
     std::vector<double> w(N), odds(N);
     double prev = 0.0;
     for (int q = 0; q < 256; q++) {
@@ -410,7 +410,7 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
       for (int o = 0; o < N; o++) if (cells[o] > 0 && (m < 0 || cells[o] < cells[m])) m = o;
       E += cells[m]; cells[m] = 0; nz--;
     }
-    // level 1: integer Vose over the entries (outcomes with cells in increasing order, then the escape), 64 cells
+    // level 1: integer Vose over the entries (outcomes with cells in increasing order, then the escape), 16384 cells
     // per column, LIFO worklists filled in increasing column order
     std::vector<uint32_t> prim(N);
     std::vector<int> alias(N), smalls(N), bigs(N), T(N);
@@ -427,11 +427,13 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
       wt[bg] -= UNIT - wt[sm];
       if (wt[bg] < UNIT) smalls[ns++] = bg; else bigs[nb++] = bg;
     }
-    std::vector<uint32_t> table(2 * N, 0u);  // [0, N): level 1 (T | A << 8 | B << 20), [N, 2N): level 2 (thr22 | alias << 22)
+    // [0, N): level 1, T | A << 16; [N, 2N): level 1, B; [2N, 3N): level 2 (thr22 | alias << 22)
+    std::vector<uint32_t> table(3 * N, 0u);
     d.philox_qmax = 0;
     auto see = [&](uint32_t o) { if (o != PHILOX_ESC && (o & 255u) > d.philox_qmax) d.philox_qmax = o & 255u; };
     for (int k = 0; k < N; k++) {
-      table[k] = (uint32_t)T[k] | (prim[k] << 8) | (prim[alias[k]] << 20);
+      table[k] = (uint32_t)T[k] | (prim[k] << 16);
+      table[N + k] = prim[alias[k]];
       if (T[k] > 0) see(prim[k]);
       if (T[k] < UNIT) see(prim[alias[k]]);
     }
@@ -452,7 +454,7 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
       for (int i = 0; i < N; i++) {
         const double t = floor(odds[i] * 4194304.0);
         const uint32_t thr = t >= 4194303.0 ? 4194303u : (t <= 0.0 ? 0u : (uint32_t)t);
-        table[N + i] = thr | ((uint32_t)alias[i] << 22);
+        table[2 * N + i] = thr | ((uint32_t)alias[i] << 22);
         if (thr > 0) see((uint32_t)i);
         if (thr < 4194303u) see((uint32_t)alias[i]);
       }
@@ -460,7 +462,7 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
     int rc = upload_vec(e, e->ph_table, table);
     if (rc || (rc = sync_check(e, "philox table upload"))) return rc;
     d.philox_t1 = e->ph_table.as<uint32_t>();
-    d.philox_t2 = e->ph_table.as<uint32_t>() + N;
+    d.philox_t2 = e->ph_table.as<uint32_t>() + 2 * N;
   }
   *out = d;
   return SIMMR_OK;
@@ -1291,11 +1293,17 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          out->qual, 60u + out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
     } else if (e->prof.rng_mode == SIMMR_RNG_PHILOX) {
       const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
-      const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
+      uint64_t per_cu = 8;
+      if (const char* s = getenv("SIMMR_PHILOX_WGS_PER_CU")) per_cu = std::max<uint64_t>(1, strtoull(s, nullptr, 10));  // measurement knob
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * per_cu);
       bool exc = false;
       if (paired) exc = e->plan_any_exc;
       else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
-      auto kern = exc ? k_emit_philox<true, false> : k_emit_philox<false, false>;
+      // pairs of one genome with few contigs: the contig bases live in LDS (no dependent load per record)
+      const bool cached = paired && !e->plan_multi && e->plan_genome < e->genomes.size() &&
+                          e->genomes[e->plan_genome].contigs.size() <= PHILOX_CBASE;
+      auto kern = cached ? (exc ? k_emit_philox<true, false, true> : k_emit_philox<false, false, true>)
+                         : (exc ? k_emit_philox<true, false, false> : k_emit_philox<false, false, false>);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
                          e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                          e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
@@ -1325,7 +1333,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->d_err.as<uint32_t>());
       const uint64_t cblocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
       const uint32_t cgrid = (uint32_t)std::min<uint64_t>(cblocks, (uint64_t)e->n_cu * 8);
-      auto copy = e->plan_any_exc ? k_emit_philox<true, true> : k_emit_philox<false, true>;
+      auto copy = e->plan_any_exc ? k_emit_philox<true, true, false> : k_emit_philox<false, true, false>;
       hipLaunchKernelGGL(copy, dim3(cgrid), dim3(256), 0, e->stream, e->prof, 1u, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
                          (const uint32_t*)nullptr, e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset,

@@ -1952,7 +1952,7 @@ SIMMR_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_a
 
 SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4]) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-  uint32_t c2 = 0x73696D6Du, c3 = 0x72000002u;
+  uint32_t c2 = 0x73696D6Du, c3 = 0x72000003u;
 #if defined(SIMMR_ABLATE_PHILOX)
   out[0] = c0 * M0 + k0; out[1] = (c0 ^ c1) * M1 + k1; out[2] = out[0] ^ c2 ^ (k1 + W0); out[3] = out[1] ^ c3 ^ (k0 + W1);
   return;
@@ -1969,13 +1969,8 @@ SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1,
 
 #define PHILOX_UNITS 128u
 #define PHILOX_READS 256u  /* 128 pairs x 2 mates */
-#define PHILOX_ROUNDS 10u  /* whole groups per lane and pass */
-#define PHILOX_CHUNK (256u * PHILOX_ROUNDS) /* whole groups per pass = size of the item -> read map */
-#define PHILOX_STAGE (PHILOX_CHUNK + PHILOX_READS) /* source words staged per pass: one per group + one per read */
-#define PHILOX_DEFER 512u  /* items a pass can list for the level-2 pass */
-#ifndef PHILOX_WAVES_PER_SIMD
-#define PHILOX_WAVES_PER_SIMD 4 /* = workgroups per CU that the LDS footprint admits: caps the kernel at 128 VGPRs */
-#endif
+#define PHILOX_MAP_ITEMS 4096u
+#define PHILOX_CBASE 64u /* contig bases kept in LDS by the CACHED kernels */
 
 // bytes a + b with per-byte wrap-around (u8 add of util.rs:46-50)
 SIMMR_DEV uint32_t add_bytes(uint32_t a, uint32_t b) {
@@ -2007,223 +2002,96 @@ struct alignas(16) PhRec {
   uint32_t dst;     // first output byte of the read, relative to the block's first output byte
   uint32_t lw;      // L | (2 * (source position & 15)) << 16 | rev << 31   (L <= 65535: u16 lengths)
   uint64_t wa;      // address of the 2-bit plane word that holds the read's first source base
-  uint32_t gs;      // index of the read's first whole group among the block's whole groups
+  uint32_t gs;      // first item of the read among the block's items
   uint32_t pad;
 };
 
-// what a lane adds up over its items
-struct PhAcc { uint32_t qs, n_subst, n_acgt, n_live, n_wrap; };
-
-// Level-1 LDS entry of column c (T 64ths answer A, the rest B; results r = enc(q) << 8 | esc << 2 | s):
-//   x = (T >> 3) << 29 | c << 19 | (T & 7) << 16 — the draw v (16 bits: idx at bits 3..12, the six fraction bits
-//       around it) satisfies (v << 16) < x  <=>  fraction < T, because the idx bits are equal on both sides;
-//       T = 64 is stored as T = 0 with B = A
+// One base: R holds the 24-bit draw F in its upper 24 bits (the low byte is whatever the bit string has there).
+// Level-1 LDS entry of column c = F >> 14 (T 16384ths answer A, the rest B; results r = enc(q) << 8 | esc << 2 | s):
+//   x = c << 22 | T << 8:  R < x  <=>  F & 0x3fff < T, because the top ten bits are equal on both sides and x has
+//       zeros in the low byte; T = 16384 is stored as T = 0 with B = A
 //   y = r(A) | r(B) << 16
-// One Philox word W = two bases (low half first).  Accumulates into ss (2-bit substitution fields, base j ends at
-// bits 2j after 16 bases), q (quality bytes, 4 bases per word) and ea (or of the results: bit 2 = some base escaped).
-SIMMR_DEV void philox_draw2(uint32_t W, const char* __restrict__ jt, uint32_t& ss, uint32_t& q, uint32_t& ea,
-                            uint32_t& x0, uint32_t& x1) {
+// v_cndmask_b32_sdwa picks the half in place.  A VALU write of VCC needs two wait states before a VALU reads it as
+// a mask on gfx950 (the compiler pads its own code; inside an asm statement that is this statement's job).
+SIMMR_DEV uint32_t philox_pick(uint32_t R, const uint2* __restrict__ jtab) {
 #if defined(SIMMR_ABLATE_LOOKUP)
-  x0 = (W & 0x0003u) | ((W >> 2) & 0x3f00u) | 0x2100u; x1 = ((W >> 16) & 0x0003u) | ((W >> 18) & 0x3f00u) | 0x2100u;
+  return ((R >> 8) & 3u) | ((R >> 10) & 0x3f00u) | 0x2100u;
 #else
-  const uint32_t a0 = W & 0x1ff8u, a1 = (W >> 16) & 0x1ff8u;
-  const uint2 e0 = *reinterpret_cast<const uint2*>(jt + a0), e1 = *reinterpret_cast<const uint2*>(jt + a1);
-  x0 = (W << 16) < e0.x ? e0.y : (e0.y >> 16);
-  x1 = W < e1.x ? e1.y : (e1.y >> 16);  // the low half of W only matters when the high halves are equal: then >= either way
+  const uint2 e = jtab[R >> 22];
+  uint32_t x;
+#if defined(SIMMR_ABLATE_NOP)
+  asm("v_cmp_lt_u32_e32 vcc, %1, %2\n\t"
+#else
+  asm("v_cmp_lt_u32_e32 vcc, %1, %2\n\t"
+      "s_nop 1\n\t"
 #endif
-  ss = __builtin_amdgcn_alignbit(x0, ss, 2);
-  ss = __builtin_amdgcn_alignbit(x1, ss, 2);
-  q = __builtin_amdgcn_perm(x0, q, 0x05030201u);  // q >> 8 | byte 1 of x0 << 24
-  q = __builtin_amdgcn_perm(x1, q, 0x05030201u);
-  ea |= x0 | x1;
+      "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
+      : "=v"(x) : "v"(R), "v"(e.x), "v"(e.y) : "vcc");
+  return x;
+#endif
 }
 
-// The 16 source bases of an item: two plane words (the codes sit at bit offset 2 * (source position & 15)) and the
-// exception bits.  The item passes take them from LDS, where the block staged them before its first store: vmcnt
-// counts loads and stores in issue order, so a global load issued after an item's stores could only be waited for
-// together with those stores' acknowledgements — every item would pay the write latency.
-struct PhSrc { uint64_t two; uint32_t exc; };
-
-// One item: bases [16 ci, 16 ci + n) of read r (n = 16 unless TAIL).  SLOW = the level-2 pass: escaped bases are
-// drawn again from the residual law; !SLOW returns true without storing anything when a base escaped.
-template <bool HAS_EXC, bool COPY_ONLY, bool TAIL, bool SLOW>
-SIMMR_DEV bool philox_item(const uint32_t r, const uint32_t ci, const uint32_t n, const PhSrc src, const uint4* __restrict__ rec4,
-                           const char* __restrict__ jt, const uint32_t* __restrict__ asc,
-                           const uint4* __restrict__ nmask, const uint32_t* __restrict__ nmask2,
-                           const uint32_t* __restrict__ t2, uint8_t* __restrict__ seq_blk,
-                           uint8_t* __restrict__ qual_blk, const uint32_t qoff, const bool q_nowrap, PhAcc& acc) {
-  const uint4 ra = rec4[2 * r];
-  const uint32_t k0 = ra.x, k1 = ra.y, lw = ra.w;
-  const uint32_t L = lw & 0xffffu, rev = lw >> 31;
-  const uint32_t b0 = ci << 4;
-  uint32_t codes = (uint32_t)(src.two >> ((lw >> 16) & 31u));
-  uint32_t exc = src.exc;
-  uint32_t qr[4] = {0, 0, 0, 0}, ss = 0, ea = 0, em = 0;
-  if (!COPY_ONLY) {
+// An item in which a base escaped (one item in 9 000): its 16 draws again, four bases at a time, the escaped ones
+// from the residual law (counter (b >> 2, 1), word b & 3).  A loop, not unrolled: it must not cost the item loop
+// registers.  t1 = the level-1 table as uploaded (T | A << 16, then B), t2 = the level-2 table.
+SIMMR_DEV void philox_repair(const uint32_t k0, const uint32_t k1, const uint32_t ci, const uint32_t* __restrict__ t1,
+                             const uint32_t* __restrict__ t2, const uint32_t qoff, uint32_t& ss, uint32_t qr[4]) {
+  ss = 0u;
+#pragma nounroll
+  for (uint32_t g4 = 0; g4 < 4u; g4++) {
+    // words 3 g4 .. 3 g4 + 2 of the group's twelve: calls (3 g4) >> 2 and (3 g4 + 2) >> 2
+    uint32_t wa[4], wb[4];
+    philox4x32_10(3u * ci + ((3u * g4) >> 2), 0u, k0, k1, wa);
+    philox4x32_10(3u * ci + ((3u * g4 + 2u) >> 2), 0u, k0, k1, wb);
+    // g4 = 0: (a0 a1 a2), 1: (a3 b0 b1), 2: (a2 a3 b0), 3: (b1 b2 b3)  [a = first call above, b = second]
+    const uint32_t w0 = g4 == 0u ? wa[0] : g4 == 1u ? wa[3] : g4 == 2u ? wa[2] : wb[1];
+    const uint32_t w1 = g4 == 0u ? wa[1] : g4 == 1u ? wb[0] : g4 == 2u ? wa[3] : wb[2];
+    const uint32_t w2 = g4 == 0u ? wa[2] : g4 == 1u ? wb[1] : g4 == 2u ? wb[0] : wb[3];
+    const uint32_t F[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8), (w1 >> 16) | ((w2 & 0xffu) << 16), w2 >> 8};
+    uint32_t w2nd[4];
+    philox4x32_10(4u * ci + g4, 1u, k0, k1, w2nd);
+    uint32_t q4 = 0u;
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-      uint32_t w[4];
-      philox4x32_10(2u * ci + (uint32_t)g, 0u, k0, k1, w);
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        uint32_t x0, x1;
-        philox_draw2(w[i], jt, ss, qr[2 * g + (i >> 1)], ea, x0, x1);
-        if (SLOW) em |= (((x0 >> 2) & 1u) << (8 * g + 2 * i)) | (((x1 >> 2) & 1u) << (8 * g + 2 * i + 1));
-      }
-    }
-    if (!SLOW) {
-      if (ea & 4u) return true;
-    } else {
-      if (!em) return false;  // only in the overflow form of the level-2 pass: this item was finished in pass one
-      // level 2: one word per escaped base, counter (b >> 2, 1), against the residual law
-      while (em) {
-        const uint32_t j = (uint32_t)__builtin_ctz(em);
-        em &= em - 1u;
-        const uint32_t b = b0 + j;
-        uint32_t w2[4];
-        philox4x32_10(b >> 2, 1u, k0, k1, w2);
-        const uint32_t W = (b & 2u) ? ((b & 1u) ? w2[3] : w2[2]) : ((b & 1u) ? w2[1] : w2[0]);
+    for (int h = 0; h < 4; h++) {
+      const uint32_t col = F[h] >> 14;
+      const uint32_t e = t1[col];  // T | A << 16; B in the second half of the table
+      uint32_t o = (F[h] & 0x3fffu) < (e & 0xffffu) ? (e >> 16) : t1[1024u + col];
+      if (o == PHILOX_ESC) {
+        const uint32_t W = w2nd[h];
         const uint32_t e2 = t2[W >> 22];
-        const uint32_t o = (W & 0x3fffffu) < (e2 & 0x3fffffu) ? (W >> 22) : (e2 >> 22);
-        const uint32_t enc = ((o & 0xffu) + qoff) & 0xffu, sft = o >> 8;
-        ss = (ss & ~(3u << (2u * j))) | (sft << (2u * j));
-        const uint32_t bsh = 8u * (j & 3u), bm = ~(0xffu << bsh), bv = enc << bsh;
-        if ((j >> 2) == 0u) qr[0] = (qr[0] & bm) | bv;
-        if ((j >> 2) == 1u) qr[1] = (qr[1] & bm) | bv;
-        if ((j >> 2) == 2u) qr[2] = (qr[2] & bm) | bv;
-        if ((j >> 2) == 3u) qr[3] = (qr[3] & bm) | bv;
+        o = (W & 0x3fffffu) < (e2 & 0x3fffffu) ? (W >> 22) : (e2 >> 22);
       }
+      ss |= (o >> 8) << (2u * (4u * g4 + (uint32_t)h));
+      q4 |= (((o & 0xffu) + qoff) & 0xffu) << (8 * h);
     }
+    if (g4 == 0u) qr[0] = q4;
+    if (g4 == 1u) qr[1] = q4;
+    if (g4 == 2u) qr[2] = q4;
+    if (g4 == 3u) qr[3] = q4;
   }
-  // only live ACGT bases mutate (minimal_short.rs:120-128)
-  if (HAS_EXC) ss &= ~spread16(exc);
-  if (TAIL) {
-    // masks of the n live bases of the item: byte masks for the four quality words, 2-bit-field mask
-    const uint4 bm = nmask[n];
-    ss &= nmask2[n];
-    acc.n_acgt += HAS_EXC ? __builtin_popcount(~spread16(exc) & nmask2[n] & 0x55555555u) : n;
-    if (!COPY_ONLY) {
-      uint32_t qs = __builtin_amdgcn_sad_u8(qr[0] & bm.x, 0u, acc.qs);
-      qs = __builtin_amdgcn_sad_u8(qr[1] & bm.y, 0u, qs);
-      qs = __builtin_amdgcn_sad_u8(qr[2] & bm.z, 0u, qs);
-      acc.qs = __builtin_amdgcn_sad_u8(qr[3] & bm.w, 0u, qs);
-      acc.n_live += n;
-    }
-  } else {
-    acc.n_acgt += HAS_EXC ? __builtin_popcount(~spread16(exc) & 0x55555555u) : 16u;
-    if (!COPY_ONLY) {
-      uint32_t qs = __builtin_amdgcn_sad_u8(qr[0], 0u, acc.qs);
-      qs = __builtin_amdgcn_sad_u8(qr[1], 0u, qs);
-      qs = __builtin_amdgcn_sad_u8(qr[2], 0u, qs);
-      acc.qs = __builtin_amdgcn_sad_u8(qr[3], 0u, qs);
-      acc.n_live += 16u;
-    }
-  }
-  acc.n_subst += __builtin_popcount((ss | (ss >> 1)) & 0x55555555u);
-  if (!COPY_ONLY && !q_nowrap) {
-    for (uint32_t j = 0; j < n; j++) acc.n_wrap += ((qr[j >> 2] >> (8 * (j & 3u))) & 0xffu) < qoff ? 1u : 0u;
-  }
-  // substitutions in the 2-bit code domain: code' = (code + s) mod 4, 16 bases at once
-  codes = (((codes & 0x33333333u) + (ss & 0x33333333u)) & 0x33333333u) |
-          (((codes & 0xccccccccu) + (ss & 0xccccccccu)) & 0xccccccccu);
-  // qualities are already offset-encoded, forward order
-  const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
-  const uint32_t o_q = ra.z + b0;
-  uint32_t o_s = o_q;
-  if (rev) {
-    // mate 2 is reverse-complemented after mutation (simulate.rs:283), still in the code domain:
-    // base b0+j -> byte L-1-(b0+j); the 16-n dead groups fall off the low end
-    codes = ~reverse_groups16(codes);
-    if (HAS_EXC) { exc = __builtin_bitreverse32(exc) >> 16; codes ^= spread16(exc); }
-    if (TAIL) {
-      const uint32_t dead = 16u - n;
-      if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
-    }
-    o_s = ra.z + (L - b0 - n);
-  }
-  uint32_t s0, s1, s2, s3;
-  if (HAS_EXC) {
-    s0 = expand4(codes & 0xffu, exc & 0xfu); s1 = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
-    s2 = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu); s3 = expand4(codes >> 24, (exc >> 12) & 0xfu);
-  } else {
-    s0 = asc[codes & 0xffu]; s1 = asc[(codes >> 8) & 0xffu]; s2 = asc[(codes >> 16) & 0xffu]; s3 = asc[codes >> 24];
-  }
-  const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
-#if defined(SIMMR_ABLATE_STORES)
-  // keep the values alive, store nothing (offsets and bounds untouched)
-  asm volatile("" :: "v"(q_lo), "v"(q_hi), "v"(s_lo), "v"(s_hi), "v"(o_q), "v"(o_s));
-#else
-  uint8_t* qd = qual_blk + o_q;
-  uint8_t* sd = seq_blk + o_s;
-  if (!TAIL) {
-    if (!COPY_ONLY) store16(qd, q_lo, q_hi);
-    store16(sd, s_lo, s_hi);
-  } else if (n == 16u) {  // the level-2 pass takes whole groups through this instantiation as well
-    if (!COPY_ONLY) store16(qd, q_lo, q_hi);
-    store16(sd, s_lo, s_hi);
-  } else {
-    if (!COPY_ONLY) store_tail(qd, q_lo, q_hi, n);
-    store_tail(sd, s_lo, s_hi, n);
-  }
-#endif
-  return false;
 }
-
-// The level-2 pass as a real function: it runs for ~2 % of the items, and kept out of line its registers do not
-// count against the occupancy of the two level-1 passes.
-template <bool HAS_EXC>
-__device__ __attribute__((noinline)) PhAcc philox_item_level2(const uint32_t r, const uint32_t ci, const uint32_t n, const uint64_t two,
-                                                              const uint32_t exc, const uint4* rec4, const char* jt,
-                                                              const uint32_t* asc, const uint4* nmask, const uint32_t* nmask2,
-                                                              const uint32_t* t2, uint8_t* seq_blk, uint8_t* qual_blk,
-                                                              const uint32_t qoff, const bool q_nowrap) {
-  PhAcc acc = {0u, 0u, 0u, 0u, 0u};
-  const PhSrc src = {two, exc};
-  (void)philox_item<HAS_EXC, false, true, true>(r, ci, n, src, rec4, jt, asc, nmask, nmask2, t2, seq_blk, qual_blk, qoff,
-                                                q_nowrap, acc);
-  return acc;
-}
-
-// Diagnostic build only (-DSIMMR_STAMPS, `make stamps`): per-wave cycle sums of the phases of a block, added into
-// g_philox_stamps and read with simmr_debug_stamps (engine.hip).  Read the SHARES, not the length: the stamps'
-// waits forbid overlaps the product kernel has.  No stamp executes in the product build.
-#if defined(SIMMR_STAMPS)
-__device__ unsigned long long g_philox_stamps[16];
-#define PH_STAMP(i)                                                                              \
-  do {                                                                                           \
-    unsigned long long t_;                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    st_sum[i] += t_ - st_last;                                                                   \
-    st_last = t_;                                                                                \
-  } while (0)
-#else
-#define PH_STAMP(i) do { } while (0)
-#endif
 
 // COPY_ONLY: the same item machinery without the draws: bases of the planned reads (mate 2 reverse-complemented)
 // with coalesced stores, for the profiles whose qualities another kernel writes (custom-short).
-template <bool HAS_EXC, bool COPY_ONLY>
-__global__ void __launch_bounds__(256, PHILOX_WAVES_PER_SIMD)
+// CACHED: every pair comes from one genome (u_genome == null) with at most PHILOX_CBASE contigs, whose bases sit in
+// LDS: a record then needs no load that depends on another load's result.
+template <bool HAS_EXC, bool COPY_ONLY, bool CACHED>
+__global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
               const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
               const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
               uint32_t qual_offset, uint64_t first_unit, uint32_t read_id_base, OutCols o,
               unsigned long long* __restrict__ counters) {
-  __shared__ uint2 jtab[COPY_ONLY ? 1 : 1024];  // level-1 columns (philox_draw2)
+  __shared__ uint2 jtab[COPY_ONLY ? 1 : 1024];  // level-1 columns (philox_pick)
   __shared__ uint32_t asc[256];  // four 2-bit codes -> four ASCII bytes
   __shared__ PhRec recs[PHILOX_READS];
-  __shared__ uint32_t stage[PHILOX_STAGE];                        // source plane words of the pass
-  __shared__ uint16_t stage_exc[HAS_EXC ? PHILOX_CHUNK : 1];      // exception bits of the pass's groups
   __shared__ uint64_t x_src[HAS_EXC ? PHILOX_READS : 1];          // first source base (exception-plane lookups)
   __shared__ const uint32_t* x_mask[HAS_EXC ? PHILOX_READS : 1];  // exception plane of the read's genome or null
-  __shared__ uint32_t r_gs[PHILOX_READS + 1];  // first whole group of each read, ~0 past the last read
-  __shared__ uint8_t owner[PHILOX_CHUNK];       // whole group -> read, when the block has few enough of them
-  __shared__ uint16_t dlist[COPY_ONLY ? 1 : PHILOX_DEFER];  // items with an escaped base: group index in the pass, or 0x8000 | read
-  __shared__ uint32_t n_def[2];                 // entries wanted in dlist, by pass parity
-  __shared__ uint4 nmask[17];     // byte masks of the first n bytes of 16
+  __shared__ uint32_t r_gs[PHILOX_READS + 1];  // first item of each read, ~0 past the last read
+  __shared__ uint8_t owner[PHILOX_MAP_ITEMS];   // item -> read, when the block has few enough items
+  __shared__ uint64_t cbase[CACHED ? PHILOX_CBASE : 1];
+  __shared__ uint4 nmask[17];    // byte masks of the first n bytes of 16
   __shared__ uint32_t nmask2[17]; // the low 2n bits
   __shared__ uint32_t lds4[4];
   const uint32_t qoff = qual_offset & 0xffu;
@@ -2232,40 +2100,41 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #pragma unroll
     for (uint32_t c = t; !COPY_ONLY && c < 1024u; c += 256u) {
       const uint32_t e = prof.philox_t1[c];
-      uint32_t T = e & 0x7fu;
-      const uint32_t A = (e >> 8) & 0x7ffu;
-      uint32_t B = e >> 20;
-      if (T >= 64u) { T = 0u; B = A; }
+      uint32_t T = e & 0xffffu;
+      const uint32_t A = e >> 16;
+      uint32_t B = prof.philox_t1[1024u + c];
+      if (T >= 16384u) { T = 0u; B = A; }
       auto res = [&](uint32_t oc) { return oc == PHILOX_ESC ? ((qoff << 8) | 4u) : (((((oc & 0xffu) + qoff) & 0xffu) << 8) | (oc >> 8)); };
-      jtab[c] = make_uint2(((T >> 3) << 29) | (c << 19) | ((T & 7u) << 16), res(A) | (res(B) << 16));
+      jtab[c] = make_uint2((c << 22) | (T << 8), res(A) | (res(B) << 16));
     }
     if (t <= 16u) {
       auto bytes = [](int k) { return k >= 4 ? 0xffffffffu : (k <= 0 ? 0u : ((1u << (8 * k)) - 1u)); };
       nmask[t] = make_uint4(bytes((int)t), bytes((int)t - 4), bytes((int)t - 8), bytes((int)t - 12));
       nmask2[t] = t >= 16u ? 0xffffffffu : ((1u << (2u * t)) - 1u);
     }
-    if (t < 2u) n_def[t] = 0u;
     const uint32_t acgt = 0x54474341u;  // "ACGT"
     asc[t] = ((acgt >> (8 * (t & 3u))) & 0xffu) | (((acgt >> (8 * ((t >> 2) & 3u))) & 0xffu) << 8) |
              (((acgt >> (8 * ((t >> 4) & 3u))) & 0xffu) << 16) | (((acgt >> (8 * (t >> 6))) & 0xffu) << 24);
   }
+  typedef const __attribute__((address_space(1))) ContigDev* global_contig_ptr;  // (a pointer out of a struct is generic: flat loads)
+  const uint32_t* packed0 = nullptr;
+  const uint32_t* mask0 = nullptr;
+  if (CACHED) {
+    const GenomeDev* G0 = genomes + genome_const;
+    packed0 = G0->packed;
+    mask0 = (HAS_EXC && G0->has_exc) ? G0->mask : nullptr;
+    const uint32_t nc = G0->n_contigs < PHILOX_CBASE ? G0->n_contigs : PHILOX_CBASE;
+    if (threadIdx.x < nc) cbase[threadIdx.x] = ((global_contig_ptr)G0->contigs)[threadIdx.x].base;
+  }
   const uint4* rec4 = reinterpret_cast<const uint4*>(recs);
-  const char* jt = reinterpret_cast<const char*>(jtab);
-  // per-lane sums: 32 bits hold what one lane of a grid of >= 2^16 lanes can see (2^32 bases per lane); the sum of
-  // the quality bytes alone is widened once per block.  qsum adds encoded qualities; the offset is taken off at the end
-  uint64_t qsum = 0;
-  PhAcc acc = {0u, 0u, 0u, 0u, 0u};
+  uint64_t qsum = 0, n_live = 0;  // qsum adds encoded qualities; the offset is taken off at the end
+  uint32_t n_subst = 0, n_acgt = 0, n_wrap = 0;
   uint64_t p_bases = 0;  // plan-derived counters, gathered while the read records are written
   uint32_t p_redrawn = 0, p_seedsubst = 0;
   const uint64_t n_reads = paired ? 2 * n_units : n_units;
   const bool q_nowrap = qoff + prof.philox_qmax <= 255u;  // then no encoded quality wraps
   const uint32_t rpu = paired ? 2u : 1u;
   const uint64_t n_blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
-  uint32_t par = 0;  // parity of the pass (which n_def counter it uses)
-#if defined(SIMMR_STAMPS)
-  unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
-#endif
   for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     const uint64_t u0 = blk * PHILOX_UNITS;
     const uint32_t nu = (n_units - u0) < PHILOX_UNITS ? (uint32_t)(n_units - u0) : PHILOX_UNITS;
@@ -2273,40 +2142,41 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     const uint64_t out0 = u_off[u0];  // the block's first output byte (same for every lane: a scalar load)
     uint8_t* const seq_blk = seq + out0;
     uint8_t* const qual_blk = qual + out0;
-    PH_STAMP(9);    // level-2 pass of the previous block (and the loop overhead)
     lds_barrier();  // the previous block's items are done with the records
-    PH_STAMP(0);    // waiting at the top barrier
-    uint32_t tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));  // opaque per block: nothing derived from the lane index is hoisted out of this loop
-    uint32_t g = 0, my_tail = 0, my_groups = 0;
-    PhSrc src_tail = {0ull, 0u};
-    if (tid < nr) {
-      const uint32_t t = tid;
+    uint32_t g = 0;
+    if (threadIdx.x < nr) {
+      const uint32_t t = threadIdx.x;
       const uint64_t u = u0 + (paired ? (t >> 1) : t);
       const uint32_t rev = paired ? (t & 1u) : 0u;
       const uint32_t L = pl.len[u];
-      g = L >> 4;
-      my_groups = g;
-      my_tail = L & 15u;
-      const GenomeDev* G = genomes + (u_genome ? u_genome[u] : genome_const);
+      g = (L + 15u) >> 4;
       const uint32_t contig = u_contig[u];
+      const uint32_t genome = (!CACHED && u_genome) ? u_genome[u] : genome_const;
       const uint64_t dst = u_off[u] + (rev ? L : 0u);
       const uint64_t pos = rev ? pl.b[u] : pl.a[u];  // first source base of this read on the contig
-      const uint64_t src = G->contigs[contig].base + pos;
       const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
+      uint64_t cb;
+      const uint32_t* packed;
+      const uint32_t* mk = nullptr;
+      if (CACHED) {
+        cb = cbase[contig & (PHILOX_CBASE - 1u)];
+        packed = packed0;
+        mk = mask0;
+      } else {
+        const GenomeDev* G = genomes + genome;
+        cb = ((global_contig_ptr)G->contigs)[contig].base;
+        packed = G->packed;
+        if (HAS_EXC) mk = G->has_exc ? G->mask : nullptr;
+      }
+      const uint64_t src = cb + pos;
       PhRec rc;
       rc.k0 = (uint32_t)key; rc.k1 = (uint32_t)(key >> 32);
       rc.dst = (uint32_t)(dst - out0);
       rc.lw = (L & 0xffffu) | ((2u * (uint32_t)(src & 15u)) << 16) | (rev << 31);
-      rc.wa = (uint64_t)(uintptr_t)(G->packed + (src >> 4));
+      rc.wa = (uint64_t)(uintptr_t)(packed + (src >> 4));
       rc.gs = 0; rc.pad = 0;
       recs[t] = rc;
-      const uint32_t* mk = nullptr;
-      if (HAS_EXC) { mk = G->has_exc ? G->mask : nullptr; x_src[t] = src; x_mask[t] = mk; }
-      if (my_tail) {  // the partial group at the end of the read: its source goes to registers now, before any store
-        src_tail.two = *reinterpret_cast<global_u64_unaligned_ptr>(rc.wa + 4ull * g);
-        if (HAS_EXC && mk) src_tail.exc = fetch_mask16(mk, (int64_t)(src + (g << 4)));
-      }
+      if (HAS_EXC) { x_src[t] = src; x_mask[t] = mk; }
 #if defined(SIMMR_ABLATE_META)
       if (false) {
 #else
@@ -2325,7 +2195,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           if (o.end) o.end[rd] = pl.b[u];                  // simulate.rs:516
         }
         if (o.contig) o.contig[rd] = contig;
-        if (o.genome) o.genome[rd] = u_genome ? u_genome[u] : genome_const;
+        if (o.genome) o.genome[rd] = genome;
         if (o.read_id) o.read_id[rd] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
         if (o.flags) o.flags[rd] = (paired && !rev) ? 0 : (uint8_t)fl;
         if (!rev) {
@@ -2335,22 +2205,22 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         }
       }
     }
-    PH_STAMP(1);    // plan loads, record, metadata stores issued
-    uint32_t n_full;
-    const uint32_t ex = wg_exclusive_scan_u32<true>(g, lds4, &n_full, tid);
-    if (tid < nr) recs[tid].gs = ex;
-    r_gs[tid] = tid < nr ? ex : 0xffffffffu;
-    // short reads: every read writes its index over its whole groups, so a group finds its read with one LDS load
-    const bool use_map = n_full <= PHILOX_CHUNK;
-    if (use_map && tid < nr)
-      for (uint32_t j = 0; j < g; j++) owner[ex + j] = (uint8_t)tid;
-    // the tail's source words are in registers from here on (their wait sits here, not behind the items' stores)
-    asm volatile("" : "+v"(src_tail.two), "+v"(src_tail.exc));
-    PH_STAMP(2);    // scan, map
+    uint32_t n_items;
+    const uint32_t ex = wg_exclusive_scan_u32<true>(g, lds4, &n_items, threadIdx.x);
+    if (threadIdx.x < nr) recs[threadIdx.x].gs = ex;
+    r_gs[threadIdx.x] = threadIdx.x < nr ? ex : 0xffffffffu;
+    // short reads: every read writes its index over its items, so an item finds its read with one LDS load
+    const bool use_map = n_items <= PHILOX_MAP_ITEMS;
+    if (use_map && threadIdx.x < nr)
+      for (uint32_t j = 0; j < g; j++) owner[ex + j] = (uint8_t)threadIdx.x;
     lds_barrier();
-    PH_STAMP(3);    // barrier after the map
-    auto locate = [&](const uint32_t item, uint32_t& r_, uint32_t& ci_) {
-      uint32_t r = 0;  // read of this group: last r with r_gs[r] <= item
+#if defined(SIMMR_ABLATE_ITEMS)
+    const uint32_t i_end = n_items < 256u ? n_items : 256u;  // one round instead of all
+#else
+    const uint32_t i_end = n_items;
+#endif
+    for (uint32_t item = threadIdx.x; item < i_end; item += 256) {
+      uint32_t r = 0;  // read of this item: last r with r_gs[r] <= item
       if (use_map) {
         r = owner[item];
       } else {
@@ -2358,127 +2228,100 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         for (uint32_t step = PHILOX_READS / 2; step; step >>= 1)
           if (r_gs[r + step] <= item) r += step;
       }
-      r_ = r; ci_ = item - r_gs[r];
-    };
-    for (uint32_t c0 = 0;; c0 += PHILOX_CHUNK) {
-      const uint32_t c_end = (n_full - c0) < PHILOX_CHUNK ? n_full : c0 + PHILOX_CHUNK;
-      const bool last = c_end == n_full;
-      // ---- stage the source of the pass's groups: group `item` of read r keeps its two plane words at
-      // stage[(item - c0) + (r - r0)] and the word after it (neighbouring groups of a read share a word: both write
-      // it, with the same value).  All loads of a lane are in flight together; nothing is stored to memory before
-      // the next pass's staging.
-      uint32_t r0 = 0, ci0 = 0;
-      if (c0 < c_end) locate(c0, r0, ci0);
-      {
-        uint64_t two[PHILOX_ROUNDS];
-        uint32_t sidx[PHILOX_ROUNDS], exc[PHILOX_ROUNDS];
+      const uint4 ra = rec4[2 * r], rb = rec4[2 * r + 1];
+      const uint32_t k0 = ra.x, k1 = ra.y, lw = ra.w;
+      const uint32_t L = lw & 0xffffu, rev = lw >> 31;
+      const uint32_t ci = item - rb.z;
+      const uint32_t b0 = ci << 4;
+      const uint32_t n = (L - b0) < 16u ? (L - b0) : 16u;
+      // the 16 source bases: 32 bits at bit offset 2 * (source position & 15) of two plane words
+      const uint64_t wa = ((uint64_t)rb.x | ((uint64_t)rb.y << 32)) + 4ull * ci;
+      uint32_t codes = (uint32_t)(*reinterpret_cast<global_u64_unaligned_ptr>(wa) >> ((lw >> 16) & 31u));
+      uint32_t exc = 0u;
+      if (HAS_EXC) { const uint32_t* mk = x_mask[r]; if (mk) exc = fetch_mask16(mk, (int64_t)(x_src[r] + b0)); }
+      // per base: 24 bits -> (Phred, substitution shift s); qualities packed as bytes, s as 2-bit fields
+      uint32_t qr[4] = {0, 0, 0, 0}, ss = 0, ea = 0;
+      if (!COPY_ONLY) {
+        uint32_t w[12];
 #pragma unroll
-        for (uint32_t k = 0; k < PHILOX_ROUNDS; k++) {
-          const uint32_t item = c0 + tid + 256u * k;
-          two[k] = 0ull; sidx[k] = 0xffffffffu; exc[k] = 0u;
-          if (item < c_end) {
-            uint32_t r, ci;
-            locate(item, r, ci);
-            const uint4 rb = rec4[2 * r + 1];
-            const uint64_t wa = ((uint64_t)rb.x | ((uint64_t)rb.y << 32)) + 4ull * ci;
-            two[k] = *reinterpret_cast<global_u64_unaligned_ptr>(wa);
-            sidx[k] = (item - c0) + (r - r0);
-            if (HAS_EXC) { const uint32_t* mk = x_mask[r]; if (mk) exc[k] = fetch_mask16(mk, (int64_t)(x_src[r] + (ci << 4))); }
+        for (int c = 0; c < 3; c++) philox4x32_10(3u * ci + (uint32_t)c, 0u, k0, k1, w + 4 * c);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          const uint32_t w0 = w[3 * g4], w1 = w[3 * g4 + 1], w2 = w[3 * g4 + 2];
+          const uint32_t R[4] = {w0 << 8, __builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 8), w2};
+#pragma unroll
+          for (int h = 0; h < 4; h++) {
+            const uint32_t x = philox_pick(R[h], jtab);
+            ss = __builtin_amdgcn_alignbit(x, ss, 2);  // ascending, so base j ends at bits 2j of ss
+            ea |= x;
+            // byte h of qr[g4] = enc(q) = byte 1 of x
+            if (h == 0) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[g4]) : "v"(x));
+            else if (h == 1) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[g4]) : "v"(x));
+            else if (h == 2) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[g4]) : "v"(x));
+            else asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[g4]) : "v"(x));
           }
         }
-#pragma unroll
-        for (uint32_t k = 0; k < PHILOX_ROUNDS; k++) {
-          if (sidx[k] != 0xffffffffu) {
-            stage[sidx[k]] = (uint32_t)two[k];
-            stage[sidx[k] + 1u] = (uint32_t)(two[k] >> 32);
-            if (HAS_EXC) stage_exc[tid + 256u * k] = (uint16_t)exc[k];
-          }
-        }
+        if (ea & 4u) philox_repair(k0, k1, ci, prof.philox_t1, prof.philox_t2, qoff, ss, qr);
       }
-      PH_STAMP(4);  // staging: loads issued, waited for, written to LDS
-      lds_barrier();
-      PH_STAMP(5);  // barrier after staging
-      // ---- pass one: level-1 draws; an item with an escaped base is listed, not finished
-#if defined(SIMMR_ABLATE_ITEMS)
-      const uint32_t i_end = c_end < c0 + 256u ? c_end : c0 + 256u;  // one round instead of all
+      // only live ACGT bases mutate (minimal_short.rs:120-128)
+      // masks of the n live bases of the item: byte masks for the four quality words, 2-bit-field mask
+      const uint4 bm = nmask[n];
+      const uint32_t live2 = nmask2[n];
+      if (HAS_EXC) ss &= ~spread16(exc);
+      ss &= live2;
+      n_subst += __builtin_popcount((ss | (ss >> 1)) & 0x55555555u);
+      n_acgt += HAS_EXC ? __builtin_popcount(~spread16(exc) & live2 & 0x55555555u) : n;
+      if (!COPY_ONLY) {
+        uint32_t qs = __builtin_amdgcn_sad_u8(qr[0] & bm.x, 0u, 0u);
+        qs = __builtin_amdgcn_sad_u8(qr[1] & bm.y, 0u, qs);
+        qs = __builtin_amdgcn_sad_u8(qr[2] & bm.z, 0u, qs);
+        qs = __builtin_amdgcn_sad_u8(qr[3] & bm.w, 0u, qs);
+        qsum += qs;
+        n_live += n;
+      }
+      if (!COPY_ONLY && !q_nowrap) {
+        for (uint32_t j = 0; j < n; j++) n_wrap += ((qr[j >> 2] >> (8 * (j & 3u))) & 0xffu) < qoff ? 1u : 0u;
+      }
+      // substitutions in the 2-bit code domain: code' = (code + s) mod 4, 16 bases at once
+      codes = (((codes & 0x33333333u) + (ss & 0x33333333u)) & 0x33333333u) |
+              (((codes & 0xccccccccu) + (ss & 0xccccccccu)) & 0xccccccccu);
+      // qualities are already offset-encoded, forward order
+      const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
+      const uint32_t o_q = ra.z + b0;
+      uint32_t o_s = o_q;
+      if (rev) {
+        // mate 2 is reverse-complemented after mutation (simulate.rs:283), still in the code domain:
+        // base b0+j -> byte L-1-(b0+j); the 16-n dead groups fall off the low end
+        codes = ~reverse_groups16(codes);
+        if (HAS_EXC) { exc = __builtin_bitreverse32(exc) >> 16; codes ^= spread16(exc); }
+        const uint32_t dead = 16u - n;
+        if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
+        o_s = ra.z + (L - b0 - n);
+      }
+      uint32_t s0, s1, s2, s3;
+      if (HAS_EXC) {
+        s0 = expand4(codes & 0xffu, exc & 0xfu); s1 = expand4((codes >> 8) & 0xffu, (exc >> 4) & 0xfu);
+        s2 = expand4((codes >> 16) & 0xffu, (exc >> 8) & 0xfu); s3 = expand4(codes >> 24, (exc >> 12) & 0xfu);
+      } else {
+        s0 = asc[codes & 0xffu]; s1 = asc[(codes >> 8) & 0xffu]; s2 = asc[(codes >> 16) & 0xffu]; s3 = asc[codes >> 24];
+      }
+      const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
+#if defined(SIMMR_ABLATE_STORES)
+      asm volatile("" :: "v"(q_lo), "v"(q_hi), "v"(s_lo), "v"(s_hi), "v"(o_q), "v"(o_s));  // alive, not stored
 #else
-      const uint32_t i_end = c_end;
+      uint8_t* qd = qual_blk + o_q;
+      uint8_t* sd = seq_blk + o_s;
+      if (n == 16u) {
+        if (!COPY_ONLY) store16(qd, q_lo, q_hi);
+        store16(sd, s_lo, s_hi);
+      } else {
+        if (!COPY_ONLY) store_tail(qd, q_lo, q_hi, n);
+        store_tail(sd, s_lo, s_hi, n);
+      }
 #endif
-      for (uint32_t item = c0 + tid; item < i_end; item += 256u) {
-        uint32_t r, ci;
-        locate(item, r, ci);
-        const uint32_t si = (item - c0) + (r - r0);
-        PhSrc src;
-        src.two = (uint64_t)stage[si] | ((uint64_t)stage[si + 1u] << 32);
-        src.exc = HAS_EXC ? (uint32_t)stage_exc[item - c0] : 0u;
-        if (philox_item<HAS_EXC, COPY_ONLY, false, false>(r, ci, 16u, src, rec4, jt, asc, nmask, nmask2, prof.philox_t2,
-                                                          seq_blk, qual_blk, qoff, q_nowrap, acc)) {
-          const uint32_t k = atomicAdd(&n_def[par], 1u);
-          if (k < PHILOX_DEFER) dlist[k] = (uint16_t)(item - c0);
-        }
-      }
-      PH_STAMP(6);  // pass one, whole groups
-      if (last && my_tail) {  // the partial group at the end of this lane's read
-        if (philox_item<HAS_EXC, COPY_ONLY, true, false>(tid, my_groups, my_tail, src_tail, rec4, jt, asc, nmask, nmask2,
-                                                         prof.philox_t2, seq_blk, qual_blk, qoff, q_nowrap, acc)) {
-          const uint32_t k = atomicAdd(&n_def[par], 1u);
-          if (k < PHILOX_DEFER) dlist[k] = (uint16_t)(0x8000u | tid);
-        }
-      }
-      if (COPY_ONLY) {
-        if (last) break;
-        lds_barrier();  // the staged words are free again
-        continue;
-      }
-      PH_STAMP(7);  // partial groups
-      lds_barrier();
-      PH_STAMP(8);  // barrier before the level-2 pass
-      // ---- level-2 pass: the listed items, by full waves.  If more were wanted than the list holds (never with a
-      // sane law: > 512 of <= 2816 items), every item of the pass is looked at again and the escaped ones are finished.
-      const uint32_t nd = n_def[par];
-      if (tid == 0) n_def[par ^ 1u] = 0u;  // the next pass's counter: nobody reads or adds to it before the next barrier
-      const bool ovf = nd > PHILOX_DEFER;
-      const uint32_t n_cand = ovf ? (c_end - c0) + (last ? nr : 0u) : nd;
-      for (uint32_t k = tid; k < n_cand; k += 256) {
-        uint32_t ent;
-        if (!ovf) ent = dlist[k];
-        else ent = k < (c_end - c0) ? k : (0x8000u | (k - (c_end - c0)));
-        uint32_t r, ci, n;
-        uint64_t two;
-        uint32_t exc = 0u;
-        if (ent & 0x8000u) {
-          // a partial group: rare enough (one lane in ~60 blocks) to fetch its source again
-          r = ent & 0xffu;
-          const uint32_t L = recs[r].lw & 0xffffu;
-          ci = L >> 4; n = L & 15u;
-          if (n == 0u) continue;
-          two = *reinterpret_cast<global_u64_unaligned_ptr>(recs[r].wa + 4ull * ci);
-          if (HAS_EXC) { const uint32_t* mk = x_mask[r]; if (mk) exc = fetch_mask16(mk, (int64_t)(x_src[r] + (ci << 4))); }
-        } else {
-          const uint32_t item = c0 + ent;
-          locate(item, r, ci);
-          n = 16u;
-          const uint32_t si = ent + (r - r0);
-          two = (uint64_t)stage[si] | ((uint64_t)stage[si + 1u] << 32);
-          if (HAS_EXC) exc = (uint32_t)stage_exc[ent];
-        }
-        const PhAcc d2 = philox_item_level2<HAS_EXC>(r, ci, n, two, exc, rec4, jt, asc, nmask, nmask2, prof.philox_t2, seq_blk,
-                                                     qual_blk, qoff, q_nowrap);
-        acc.qs += d2.qs; acc.n_subst += d2.n_subst; acc.n_acgt += d2.n_acgt; acc.n_live += d2.n_live; acc.n_wrap += d2.n_wrap;
-      }
-      par ^= 1u;
-      if (last) break;
-      lds_barrier();  // the list and the staged words are free again
     }
-    qsum += acc.qs;
-    acc.qs = 0u;
   }
-#if defined(SIMMR_STAMPS)
-  if ((threadIdx.x & 63u) == 0)
-    for (int i = 0; i < 10; i++) atomicAdd(&g_philox_stamps[i], st_sum[i]);
-#endif
-  uint64_t n_subst = acc.n_subst, n_acgt = acc.n_acgt;
-  qsum = qsum + 256ull * acc.n_wrap - (uint64_t)qoff * acc.n_live;  // sum of the raw Phred values
+  qsum = qsum + 256ull * n_wrap - (uint64_t)qoff * n_live;  // sum of the raw Phred values
   for (int d = 32; d > 0; d >>= 1) {
     n_subst += __shfl_down(n_subst, d, 64);
     n_acgt += __shfl_down(n_acgt, d, 64);

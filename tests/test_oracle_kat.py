@@ -111,18 +111,18 @@ def test_philox4x32_10_random123_vectors(oracle):
     assert ph([0xffffffff] * 4, [0xffffffff] * 2) == "408f276d 41c83b0e a20bc7c6 6d5451fd"
     assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         "d16cfe09 94fdcceb 5001e420 24126ea1"
-    # the two tables of the mode (level 1: 16-bit draws over 65536 cells, level 2: the residual law behind the
+    # the two tables of the mode (level 1: 24-bit draws over 2^24 cells, level 2: the residual law behind the
     # escape cells): implied outcome probabilities vs the analytic law
     def implied(kind, mean):
-        t1, t2 = (C.c_uint32 * 1024)(), (C.c_uint32 * 1024)()
+        t1, t2 = (C.c_uint64 * 1024)(), (C.c_uint32 * 1024)()
         E = oracle.orc_philox_tables(kind, mean, t1, t2)
         a1 = np.array(list(t1), dtype=np.uint64)
-        T, A, B = (a1 & 0x7f).astype(int), ((a1 >> 8) & 0x7ff).astype(int), (a1 >> 20).astype(int)
-        assert T.max() <= 64 and A.max() <= 1024 and B.max() <= 1024
+        T, A, B = (a1 & 0xffff).astype(np.int64), ((a1 >> 16) & 0xffff).astype(int), (a1 >> 32).astype(int)
+        assert T.max() <= 16384 and A.max() <= 1024 and B.max() <= 1024
         cells = np.zeros(1025)
         np.add.at(cells, A, T)
-        np.add.at(cells, B, 64 - T)
-        assert cells.sum() == 65536 and cells[1024] == E
+        np.add.at(cells, B, 16384 - T)
+        assert cells.sum() == 2 ** 24 and cells[1024] == E
         tab = np.array(list(t2), dtype=np.uint64)
         thr, al = (tab & 0x3fffff).astype(float), (tab >> 22).astype(int)
         P2 = np.zeros(1024)
@@ -131,9 +131,9 @@ def test_philox4x32_10_random123_vectors(oracle):
             P2[al[i]] += (1 - thr[i] / 4194304) / 1024
         if E:
             assert abs(P2.sum() - 1) < 1e-12
-        return cells[:1024] / 65536 + (E / 65536) * P2, E
+        return cells[:1024] / 2 ** 24 + (E / 2 ** 24) * P2, E
     P, E = implied(1, 30)  # kind 1 = minimal-short
-    assert 0 < E < 200  # ~0.14 % of the draws go to level 2
+    assert 0 < E < 300  # 7e-6 of the draws go to level 2
     assert abs(P.sum() - 1) < 1e-12
     from math import erf, sqrt
     cdf = lambda x: 0.5 * (1 + erf((x - 30.0) / 10.0 / sqrt(2)))

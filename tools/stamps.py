@@ -20,14 +20,14 @@ out = Reads.allocate(info.n_reads, info.total_bases, eng.device, qual_offset=33)
 lib = _abi.load()
 buf = (C.c_uint64 * 16)()
 names = ["top barrier", "plan loads + record + metadata", "scan + map", "barrier after map", "staging loads -> LDS",
-         "barrier after staging", "pass one (whole groups)", "partial groups", "barrier before level 2", "level-2 pass + loop"]
+         "barrier after staging", "whole groups", "partial groups + loop"]
 for it in range(2):
     eng.pe_plan(0, prof, reads, 42, 0, reads // 2, (0, 0))
     lib.simmr_debug_stamps(buf)  # clear
     eng.pe_emit(0, out)
     torch.cuda.synchronize()
     assert lib.simmr_debug_stamps(buf) == 0
-    tot = sum(buf[:10])
+    tot = sum(buf[:8])
     print(f"run {it}: emit kernel {eng.last_emit_kernel_ms():.3f} ms; wave-cycles by phase:")
     for i, n in enumerate(names):
         print(f"  {n:34s} {buf[i]:>16d}  {100.0 * buf[i] / tot:5.1f} %")
