@@ -369,7 +369,7 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
       return e->fail(SIMMR_EINVAL, "negative standard deviation");
   }
   if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind != SIMMR_PERFECT_SHORT) {
-    // The two tables of the counter mode (restated in oracle/philox.c).  The joint law over the 1024
+    // The two tables of the counter mode.  The joint law over the 1024
     // outcomes o = q | s << 8, w(q,0) = P(q)(1 - p_q), w(q,s) = P(q) p_q / 3 (P(q) = the profile's Phred law,
     // p_q = the probability of the reference's 24-bit test gen::<f32>() > accuracy(q), minimal_short.rs:83-140),
     // is split exactly into c(o) = floor(2^24 w(o)) cells of a 24-bit draw plus E escape cells that lead to a
@@ -831,18 +831,6 @@ void simmr_engine_destroy(simmr_engine* e) {
   if (e->ev_d) (void)hipEventDestroy(e->ev_d);
   delete e;
 }
-
-#if defined(SIMMR_STAMPS)
-// diagnostic build only: read and clear the phase cycle sums of k_emit_philox (kernels.hip, PH_STAMP)
-extern "C" int simmr_debug_stamps(uint64_t* out16) {
-  unsigned long long h[16];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(simmr::g_philox_stamps), sizeof h) != hipSuccess) return SIMMR_ENODEV;
-  for (int i = 0; i < 16; i++) out16[i] = h[i];
-  memset(h, 0, sizeof h);
-  if (hipMemcpyToSymbol(HIP_SYMBOL(simmr::g_philox_stamps), h, sizeof h) != hipSuccess) return SIMMR_ENODEV;
-  return SIMMR_OK;
-}
-#endif
 
 int simmr_engine_set_stream(simmr_engine* e, void* hip_stream) {
   if (!e) return SIMMR_EINVAL;

@@ -1913,40 +1913,42 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
 // Philox4x32-10 keyed by the read's Phred seed.  A base draws its Phred score and
 // its substitution together from their joint law over the 1024 outcomes (q, s):
 // s = 0 no substitution, s = 1..3 the base becomes "ACGT"[(code + s) & 3].  The
-// draw has two levels (oracle/philox.c states the specification): 16 bits per base
-// settle it through a 1024-column alias table in all but E of 65536 cells (E ~ 90),
-// and a base that lands on one of those escape cells takes one full word of a
-// second Philox call against the residual law.  So one call serves 8 bases, and
+// draw has two levels (DESIGN.md section 4 states the specification): 24 bits per base
+// settle it through a 1024-column alias table in all but E of 2^24 cells (E ~ 120),
+// and a base that lands on one of those escape cells takes one full word of
+// another Philox call against the residual law.  Three calls serve 16 bases, and
 // since no draw depends on another the work item is "16 consecutive bases of one
-// read" = two calls.
+// read".  An escape is rare enough (one item in 9 000) to be repaired where it is
+// found.
 //
 // A workgroup takes 128 units (256 mates, or 128 long reads), writes one 32-byte
-// record per read to LDS (key, output offset, source word address, length) and
-// the prefix of their item counts, and deals the items to its 256 lanes:
-// consecutive lanes hold consecutive 16-base groups, so a wave's 16-byte quality
-// and base stores are contiguous.  Whole groups and the partial group at the end of a
-// read are separate passes (a wave never mixes the 16-byte store path with the
-// byte-granular one).  An item with an escaped base is not finished where it is
-// found: its index goes to a list in LDS and the list is worked off afterwards by
-// full waves (level-2 pass), because the escape is rare per base (0.14 %) but not
-// per wave (64 x 16 bases).  The kernel is bound by integer VALU issue, so
-// everything is written to minimise the issue cost per base
-// (profiles/microbench/valu_asm_rates*: v_mad_u64_u32 2.1 x, v_perm / v_alignbit
-// 1.6 x a v_add_u32):
-//   * v_mad_u64_u32 gives both halves of a Philox product, v_bitop3_b32 the
-//     three-way xor of a round (4 instructions per round, 10 rounds per 8 bases);
-//   * one 8-byte LDS entry per column: the word the draw is compared with (the
-//     column's own index sits inside it, at the bits the draw keeps it in, so no
-//     field has to be extracted first) and the two results as 16-bit halves;
-//     v_alignbit_b32 shifts s into the packed substitution word and v_perm_b32
-//     drops the quality byte into place;
-//   * the substitutions are one SWAR add modulo 4 on the packed 2-bit codes;
-//   * blocks of short reads keep an item -> read map in LDS (one byte load);
-//     otherwise a branch-free binary search over the item prefix finds the read.
+// record per read to LDS (key, output offset, source word address, length) together
+// with the prefix of their item counts, and deals the items to its 256 lanes in
+// read order: consecutive lanes hold consecutive groups, so a wave's 16-byte quality
+// and base stores are contiguous and every 64-byte line of the output is written
+// in one go.  (Measured in round 2: writing the partial group at the end of each
+// read in a pass of its own makes the kernel's write traffic 45 GB instead of 33 GB
+// per 100 M reads — the lines are written twice, from two store instructions that
+// are too far apart to be merged in L2 — and the kernel HBM-bound at the time it
+// has now.)
+// Instruction choices follow profiles/microbench/valu_asm_rates*: v_mad_u64_u32
+// (2.1 x a v_add_u32) gives both halves of a Philox product, v_bitop3_b32 the
+// three-way xor of a round; one 8-byte LDS entry per column holds the word the
+// draw is compared with (the column's index is its top ten bits, as in the draw,
+// so no field is extracted first) and the two results as 16-bit halves;
+// v_alignbit_b32 shifts s into the packed substitution word, an SDWA move drops
+// the quality byte into place; the substitutions are one SWAR add modulo 4 on the
+// packed 2-bit codes; blocks of short reads keep an item -> read map in LDS (one
+// byte load), otherwise a branch-free binary search over the item prefix finds the
+// read.
 // Named -D switches compile pieces out for differential timing (Makefile, `make ablate`):
 // SIMMR_ABLATE_PHILOX (words from one multiply instead of the ten rounds), SIMMR_ABLATE_LOOKUP
-// (no table lookups), SIMMR_ABLATE_STORES (no global stores of bases / qualities).  They change
-// values only, never an index, a pointer or a loop bound.
+// (no table lookups), SIMMR_ABLATE_STORES (no global stores of bases / qualities), SIMMR_ABLATE_CODES
+// (no load from the reference plane), SIMMR_ABLATE_META (no metadata columns), SIMMR_ABLATE_ITEMS (one
+// round of items per block), SIMMR_ABLATE_ALL16 / SIMMR_ABLATE_ALIGN16 (partial groups stored as
+// 16 bytes / every store aligned down to 16 bytes: wrong bytes, inside the buffers), SIMMR_ABLATE_NOP
+// (without the wait states between the compare and the select).  None of them changes an index, a
+// pointer into a table or a loop bound.
 // ===========================================================================
 SIMMR_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
@@ -2236,7 +2238,11 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint32_t n = (L - b0) < 16u ? (L - b0) : 16u;
       // the 16 source bases: 32 bits at bit offset 2 * (source position & 15) of two plane words
       const uint64_t wa = ((uint64_t)rb.x | ((uint64_t)rb.y << 32)) + 4ull * ci;
+#if defined(SIMMR_ABLATE_CODES)
+      uint32_t codes = (uint32_t)((wa * 0x9E3779B97F4A7C15ull) >> ((lw >> 16) & 31u));  // timing only: no load from the plane
+#else
       uint32_t codes = (uint32_t)(*reinterpret_cast<global_u64_unaligned_ptr>(wa) >> ((lw >> 16) & 31u));
+#endif
       uint32_t exc = 0u;
       if (HAS_EXC) { const uint32_t* mk = x_mask[r]; if (mk) exc = fetch_mask16(mk, (int64_t)(x_src[r] + b0)); }
       // per base: 24 bits -> (Phred, substitution shift s); qualities packed as bytes, s as 2-bit fields
@@ -2309,9 +2315,19 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #if defined(SIMMR_ABLATE_STORES)
       asm volatile("" :: "v"(q_lo), "v"(q_hi), "v"(s_lo), "v"(s_hi), "v"(o_q), "v"(o_s));  // alive, not stored
 #else
+#if defined(SIMMR_ABLATE_ALIGN16)
+      // timing only: every store lands on the aligned 16 bytes below its place (still inside the buffers)
+      uint8_t* qd = (uint8_t*)((uintptr_t)(qual_blk + o_q) & ~(uintptr_t)15);
+      uint8_t* sd = (uint8_t*)((uintptr_t)(seq_blk + o_s) & ~(uintptr_t)15);
+#else
       uint8_t* qd = qual_blk + o_q;
       uint8_t* sd = seq_blk + o_s;
+#endif
+#if defined(SIMMR_ABLATE_ALL16)
+      if (true) {  // timing only: partial groups store 16 bytes too (they overwrite the head of the next read)
+#else
       if (n == 16u) {
+#endif
         if (!COPY_ONLY) store16(qd, q_lo, q_hi);
         store16(sd, s_lo, s_hi);
       } else {
