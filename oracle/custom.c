@@ -332,3 +332,16 @@ int orc_custom_simulate_phred_scores(const orc_custom* c, uint64_t len, uint64_t
   }
   return 0;
 }
+
+/* gaussian (custom_long.rs:36-44): the normal kernel density estimate at x over the points xs with the given
+ * bandwidth, terms added in slice order as the iterator sum does.  (The rest of CustomLongErrorProfile is not
+ * restated: nothing in the reference constructs that profile — no constructor, not in cli.rs:62-70 — see DESIGN.md
+ * section 6; this function is here for the one known-answer test the reference holds for it, custom_long.rs:264-272.) */
+double orc_gaussian_kde(double x, const double* xs, uint64_t n, double bandwidth) {
+  double sum = 0.0;
+  for (uint64_t i = 0; i < n; i++) {
+    const double f = (x - xs[i]) / bandwidth;
+    sum += exp(-0.5 * (f * f));
+  }
+  return sum / (sqrt(2.0 * 3.14159265358979323846264338327950288) * (double)n * bandwidth);
+}

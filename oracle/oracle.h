@@ -197,6 +197,7 @@ int orc_custom_get_insert_size(const orc_custom* c, uint64_t seed, uint16_t* out
 uint16_t orc_custom_minimum_genome_size(const orc_custom* c);
 int orc_custom_simulate_phred_scores(const orc_custom* c, uint64_t len, uint64_t seed, uint8_t* out);
 int64_t orc_custom_simulate_errors(const orc_model* m, const uint8_t* seq, uint64_t len, uint64_t seed, uint8_t* out);
+double orc_gaussian_kde(double x, const double* xs, uint64_t n, double bandwidth);  /* custom_long.rs:36-44 */
 
 /* ---------------- SIMMR_RNG_PHILOX mode (philox.c): counter-based per-base draws */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

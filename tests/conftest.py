@@ -11,6 +11,8 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "provenance(kind): where a known-answer test's expected values come from "
+                            "(reference-held / public third-party / self-generated; tests/test_oracle_kat.py)")
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -25,6 +25,7 @@ def lib(oracle):
     return oracle
 
 
+@pytest.mark.provenance("reference-held")
 def test_reference_simulate_errors_unit_test(lib):
     # custom_long.rs:300-343: 3-mer map {ACC -> CAT (1.0), ATC -> ATC, TCG -> TGT}; "ACCCG" -> "CATGT"
     e = _model.three_bit_encode

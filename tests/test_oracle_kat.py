@@ -2,13 +2,31 @@
 (SURVEY.md §8c): public ChaCha vectors, rand 0.8's StdRng unit test, the two
 reference-authored RNG values in simmr/src/tests/simulate_tests.rs:27,:75, and
 the reference's live unit tests (util_tests.rs, abundance_profile_tests.rs,
-error_profile_tests.rs, shared/src/encoding.rs:288-314)."""
+error_profile_tests.rs, shared/src/encoding.rs:288-314).
+
+What each test's expected values ARE is marked on the test (`provenance`):
+  reference-held      — literals the reference's own repository holds (its unit tests, fixtures and the two values in
+                        comments of its #[ignore]d tests); the strongest pin there is here
+  public third-party  — published vectors of the algorithms the reference uses through its crates (ChaCha, rand's own
+                        unit test, Random123); they pin the generator, not simmr
+  self-generated      — values this repository produced itself (statistics against analytic laws, frozen outputs of
+                        the restatement); they detect drift and gross errors, they do NOT prove parity
+What the reference-held vectors cover: PCG32 seeding -> ChaCha12 -> next_u64 -> gen_range (range 1 only), the utility
+functions, the abundance profiles, the 2-bit k-mer codes, the perfect-short profile, slicing / reverse complement on the
+reference's fixture, the k-mer splice and the KDE kernel.  NOT covered by any reference-held vector: gen_range's
+multiply-high for a range > 1, the ziggurat tables beyond the literals below, Normal / Gamma / Open01,
+WeightedAliasIndex / Uniform::new, the bincode layout against a real simmrd file."""
 import ctypes as C
 import json
 from pathlib import Path
 
 import numpy as np
 import pytest
+
+
+def provenance(kind):
+    assert kind in ("reference-held", "public third-party", "self-generated")
+    return pytest.mark.provenance(kind)
 
 from simmr_amd import MinimalLongErrorProfile, MinimalShortErrorProfile, PerfectShortErrorProfile
 from tests import _oracle, _synth
@@ -20,6 +38,7 @@ def _hex_words(words):
     return " ".join(int(w).to_bytes(4, "little").hex() for w in words)
 
 
+@provenance("public third-party")
 def test_chacha_public_vectors(oracle):
     key = (C.c_uint32 * 8)()
     out = (C.c_uint32 * 16)()
@@ -30,6 +49,7 @@ def test_chacha_public_vectors(oracle):
                                    "0429c3bb 49e07414 7e0089a5 2eae155f")
 
 
+@provenance("public third-party")
 def test_rand_stdrng_unit_test_value(oracle):
     r = _oracle.Rng()
     seed = (C.c_uint8 * 32)(*([1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16))
@@ -37,6 +57,7 @@ def test_rand_stdrng_unit_test_value(oracle):
     assert oracle.orc_next_u64(C.byref(r)) == 10719222850664546238
 
 
+@provenance("reference-held")
 def test_reference_authored_rng_values(oracle):
     # simulate_tests.rs:27: StdRng::seed_from_u64(42).gen::<u64>() (the comment
     # has one duplicated digit: 97132697663989775522)
@@ -52,6 +73,7 @@ def test_reference_authored_rng_values(oracle):
     assert str(got).startswith("6335") and str(got).endswith("6202")
 
 
+@provenance("self-generated")
 def test_block_boundary_consumption(oracle):
     """next_u64 across the 64-word refill uses consecutive words (rand_core BlockRng)."""
     a, b = _oracle.Rng(), _oracle.Rng()
@@ -64,6 +86,7 @@ def test_block_boundary_consumption(oracle):
         assert v == words[i] | (words[i + 1] << 32)
 
 
+@provenance("public third-party")
 def test_ziggurat_tables_match_rand_distr_literals(oracle):
     # first entries of rand_distr 0.4.3 ziggurat_tables.rs ZIG_NORM_X / ZIG_NORM_F
     X, F = oracle.orc_zig_norm_x(), oracle.orc_zig_norm_f()
@@ -77,6 +100,7 @@ def test_ziggurat_tables_match_rand_distr_literals(oracle):
     assert all(X[i] > X[i + 1] for i in range(256))
 
 
+@provenance("self-generated")
 def test_standard_normal_moments(oracle):
     r = _oracle.Rng()
     oracle.orc_rng_seed_from_u64(C.byref(r), 123)
@@ -85,6 +109,7 @@ def test_standard_normal_moments(oracle):
     assert abs((np.abs(z) > 3.654152885361009).mean() - 2.58e-4) < 1.5e-4  # tail branch is exercised
 
 
+@provenance("self-generated")
 def test_gamma_moments(oracle):
     r = _oracle.Rng()
     oracle.orc_rng_seed_from_u64(C.byref(r), 5)
@@ -101,6 +126,7 @@ def test_gamma_moments(oracle):
     assert abs(sat.mean() - 19833) < 250 and abs((sat == 65535).mean() - 0.0142) < 0.003
 
 
+@provenance("public third-party")
 def test_philox4x32_10_random123_vectors(oracle):
     """Known-answer vectors of Random123's kat_vectors for philox4x32-10 (SIMMR_RNG_PHILOX)."""
     def ph(ctr, key):
@@ -164,6 +190,7 @@ def test_philox4x32_10_random123_vectors(oracle):
 
 
 # ---- reference unit tests restated ------------------------------------------
+@provenance("reference-held")
 def test_util_tests_rs(oracle):
     # util_tests.rs:7-50 complement, :69-109 conversions, :53-66 encoding
     assert bytes(oracle.orc_complement(c) for c in b"aacctg") == b"ttggac"
@@ -185,6 +212,7 @@ def test_util_tests_rs(oracle):
     assert out.tobytes() == b"NACGTT"
 
 
+@provenance("reference-held")
 def test_two_bit_kmer_codes(oracle):
     # shared/src/encoding.rs:288-314
     for kmer, code in ((b"ACGT", 0xE4), (b"AAAAA", 0), (b"TTATC", 0x1CF), (b"GCGCATCT", 0xDC66)):
@@ -195,6 +223,7 @@ def test_two_bit_kmer_codes(oracle):
         assert buf.raw == kmer
 
 
+@provenance("reference-held")
 def test_error_profile_tests_rs(oracle):
     # error_profile_tests.rs:7-21
     p = PerfectShortErrorProfile(150, 150).pod()
@@ -207,6 +236,7 @@ def test_error_profile_tests_rs(oracle):
     assert oracle.orc_profile_minimum_genome_size(C.byref(p), C.byref(v)) == 0 and v.value == 450
 
 
+@provenance("reference-held")
 def test_abundance_profile_tests_rs(oracle):
     # abundance_profile_tests.rs:7-30
     reads = np.zeros(5, dtype=np.uint64)
@@ -215,6 +245,7 @@ def test_abundance_profile_tests_rs(oracle):
     assert list(reads) == [20] * 5 and list(ab) == [20.0] * 5
 
 
+@provenance("reference-held")
 def test_slicing_strings_of_ignored_simulate_tests(oracle):
     """simulate_tests.rs:37,44,83,90 — the read strings of the two #[ignore]d tests,
     checked as slicing / reverse-complement semantics on the committed fixture."""
@@ -229,6 +260,7 @@ def test_slicing_strings_of_ignored_simulate_tests(oracle):
         assert out.tobytes() == want
 
 
+@provenance("self-generated")
 def test_drift_anchors(oracle):
     """Self-generated anchors recorded in SURVEY.md §8c (not reference outputs):
     pe_seed 9713269763989775522 on a 7 920-nt contig with required 60 -> fwd_start 5092;
@@ -241,6 +273,7 @@ def test_drift_anchors(oracle):
     assert pl.fwd_start == 1829
 
 
+@provenance("self-generated")
 def test_oracle_golden_vectors(oracle):
     """Frozen oracle outputs (tests/golden/make_golden.py): any drift in the
     restated RNG chain or simulate path shows up here without a GPU."""
@@ -259,3 +292,13 @@ def test_oracle_golden_vectors(oracle):
             assert hashlib.sha256(np.ascontiguousarray(d[col]).tobytes()).hexdigest() == want, (case["name"], col)
         assert [int(x) for x in d["start"][:8]] == case["start_head"]
         assert d["seq"][:60].tobytes().decode() == case["seq_head"]
+
+
+@provenance("reference-held")
+def test_gaussian_kde_kernel(oracle):
+    """custom_long.rs:264-272: gaussian(4.0, [9, 8, ..., 0], 0.1) == 0.3989422804014327 (an exact f64 comparison in
+    the reference's own test)."""
+    oracle.orc_gaussian_kde.restype = C.c_double
+    oracle.orc_gaussian_kde.argtypes = [C.c_double, C.POINTER(C.c_double), C.c_uint64, C.c_double]
+    xs = (C.c_double * 10)(9.0, 8.0, 7.0, 6.0, 5.0, 4.0, 3.0, 2.0, 1.0, 0.0)
+    assert oracle.orc_gaussian_kde(4.0, xs, 10, 0.1) == 0.3989422804014327
