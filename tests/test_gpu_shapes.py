@@ -1,0 +1,177 @@
+"""The BASELINE.json configurations in their own SHAPE, where one GPU holds them:
+  C4  a thousand staged genomes in one plan, a rank's shard of the global pair range (ranks 0, 3, 7 of 8), checked
+      against per-genome runs of the CPU restatement on the genomes at the shard's borders and in its middle;
+  C3  10 M long reads of gamma(8000, 6000) (80 Gbases, 160 GB of output) through size-independent properties;
+  C5  one GPU's share of 50 M custom-model long reads over 64 staged genomes with 1/(g+1) abundances
+      (CustomAbundanceProfile): the whole share is planned at once and emitted range by range;
+and that an engine's work really lands on the HIP stream it was given (simmr_engine_set_stream)."""
+import numpy as np
+import pytest
+
+from simmr_amd import (CustomAbundanceProfile, MinimalLongErrorProfile, MinimalShortErrorProfile, _abi)
+from simmr_amd.simulate import GenomeRef, determine_reads, split_range
+from tests import _oracle, _synth
+from tests.test_gpu_fullsize import checksum_range, colsum256
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rng_mode", [_abi.RNG_REFERENCE, _abi.RNG_PHILOX])
+def test_c4_thousand_genomes_rank_shards(engine, oracle, rng_mode):
+    """1000 genomes (one sequence of 30 kbp each, SplitMix64(1000 + g)), uniform abundance, 2 M reads: rank r of 8
+    takes pairs [r N / 8, (r + 1) N / 8) of the global pair index through ONE plan over all genomes."""
+    n_g, per = 1000, 2000  # reads per genome (uniform.rs: ceil(N / G))
+    slots = list(range(1000, 1000 + n_g))
+    for g, s in enumerate(slots):
+        engine.stage_synthetic(s, [30_000], 1000 + g)
+    prof = MinimalShortErrorProfile(rng_mode=rng_mode).pod()
+    reads = [per] * n_g
+    total_pairs = n_g * (per // 2)
+    for rank in (0, 3, 7):
+        first, count = split_range(total_pairs, rank, 8)
+        dev = engine.simulate_pe_reads_multi(slots, reads, prof, 42, first=first, count=count, qual_offset=33).to_host()
+        assert dev["read_id"].size == 2 * count
+        # ids and genomes of the whole shard follow from the global pair index alone
+        pair = first + np.arange(count)
+        assert np.array_equal(dev["read_id"], np.repeat(pair, 2).astype(np.uint32))  # simulate.rs:85-89
+        assert np.array_equal(dev["genome"], np.repeat(pair // (per // 2) + 1000, 2).astype(np.uint32))
+        g_lo, g_hi = first // (per // 2), (first + count - 1) // (per // 2)
+        for g in sorted({g_lo, (g_lo + g_hi) // 2, g_hi}):
+            host = _oracle.HostGenome(_synth.synthetic_contigs([30_000], 1000 + g))
+            a = max(first, g * (per // 2)) - g * (per // 2)            # pairs [a, b) of genome g are in the shard
+            b = min(first + count, (g + 1) * (per // 2)) - g * (per // 2)
+            ora = _oracle.simulate_pe(oracle, host, prof, per, 42, first=a, count=b - a,
+                                      read_id_base=g * (per // 2), qual_offset=33).trimmed()
+            r0 = 2 * (g * (per // 2) + a - first)                      # first read of that range in the shard
+            r1 = r0 + 2 * (b - a)
+            o0 = int(dev["seq_off"][r0])
+            assert np.array_equal(dev["seq_off"][r0:r1 + 1] - o0, ora["seq_off"]), (rank, g)
+            for col in ("start", "end", "contig", "read_id", "flags"):
+                assert np.array_equal(dev[col][r0:r1], ora[col]), (rank, g, col)
+            o1 = int(dev["seq_off"][r1])
+            assert np.array_equal(dev["seq"][o0:o1], ora["seq"]), (rank, g)
+            assert np.array_equal(dev["qual"][o0:o1], ora["qual"]), (rank, g)
+
+
+def test_c3_ten_million_long_reads(engine):
+    """BASELINE configs[2] at its stated size: 10 M reads of gamma(8000, 6000) on the 100 Mbp genome, counter mode."""
+    import torch
+    eng = engine
+    eng.stage_synthetic(5, [100_000_000], 2)
+    prof = MinimalLongErrorProfile(gamma_mean=8000.0, gamma_std=6000.0, length_mode=_abi.LEN_PER_READ,
+                                   rng_mode=_abi.RNG_PHILOX).pod()
+    n_reads = 10_000_000
+    eng.counters_reset()
+    whole = eng.simulate_long_reads([5], [n_reads], prof, 42, qual_offset=33)
+    torch.cuda.synchronize()
+    c = eng.counters()
+    tb = whole.total_bases
+    off = whole.seq_off[: n_reads + 1]
+    lens = off[1:] - off[:-1]
+    assert c[_abi.CNT_READS] == n_reads and c[_abi.CNT_BASES] == tb and int(off[0]) == 0 and int(off[-1]) == tb
+    assert 7.7e10 < tb < 8.1e10
+    assert 7800 < lens.double().mean().item() < 8050 and 5700 < lens.double().std().item() < 6100
+    assert int(lens.max()) <= 65535 and int(lens.min()) >= 1
+    assert bool((whole.end[:n_reads] - whole.start[:n_reads] == lens).all()) and bool((whole.end[:n_reads] <= 100_000_000).all())
+    rate = c[_abi.CNT_SUBSTITUTIONS] / c[_abi.CNT_ACGT_BASES]
+    assert abs(rate / 0.013404 - 1) < 0.02 and abs(c[_abi.CNT_QUAL_SUM] / tb - 29.5) < 0.05
+    assert bool((whole.read_id[:n_reads].to(torch.int64) == torch.arange(n_reads, device=off.device)).all())
+    # alphabet and quality range on a slice from the far end of the 160 GB
+    a, b = int(off[n_reads - 20_000]), tb
+    hist = torch.bincount(whole.seq[a:b].to(torch.int64), minlength=256)
+    assert int(hist[[65, 67, 71, 84]].sum()) == b - a
+    assert int(whole.qual[a:b].min()) >= 33 and int(whole.qual[a:b].max()) <= 33 + 93
+    # a shard deep inside equals the same range of the whole run
+    s0, s1 = 9_200_000, 9_300_000
+    cs = checksum_range(whole.seq, int(off[s0]), int(off[s1]))
+    cq = checksum_range(whole.qual, int(off[s0]), int(off[s1]))
+    base = int(off[s0])
+    n_part = int(off[s1]) - base
+    del whole
+    torch.cuda.empty_cache()
+    part = eng.simulate_long_reads([5], [n_reads], prof, 42, first=s0, count=s1 - s0, qual_offset=33)
+    assert part.total_bases == n_part
+    assert torch.equal(torch.roll(colsum256(part.seq[:n_part]), base % 256), cs)
+    assert torch.equal(torch.roll(colsum256(part.qual[:n_part]), base % 256), cq)
+
+
+def test_c5_share_of_one_gpu(engine):
+    """BASELINE configs[4], one GPU's share: 64 genomes of 10 Mbp, abundances 1/(g + 1) through CustomAbundanceProfile
+    (normalised by custom.rs:29-38), 50 M reads in the run, rank 0 of 8 = 6.25 M reads of the custom long-read model.
+    The share is PLANNED at once (the run layout over the genomes, lengths, positions) and emitted in ranges of
+    1 M reads (the whole share would be 250 GB of output); the ranges tile the plan."""
+    import torch
+    from simmr_amd import CustomShortErrorProfile, model_io
+    eng = engine
+    n_g = 64
+    slots = list(range(300, 300 + n_g))
+    for g, s in enumerate(slots):
+        eng.stage_synthetic(s, [10_000_000], 500 + g)
+    keep = CustomShortErrorProfile(model_io.synthetic_long_model(kmer_size=7, n_positions=200, seed=1, n_kmers=4 ** 7,
+                                                                 read_length_mean=20000.0, read_length_std=4000.0))
+    pod = keep.pod()
+    pod.length_mode = _abi.LEN_PER_READ
+    pod.long_start_mode = _abi.START_UNIFORM
+    refs = [GenomeRef(s, 10_000_000, f"g{g}.fna", f"id{g}", 1) for g, s in enumerate(slots)]
+    ab = determine_reads(50_000_000, refs, keep, CustomAbundanceProfile([1.0 / (g + 1) for g in range(n_g)]), False)
+    reads = [r for r, _ in ab]
+    total = sum(reads)
+    assert 50_000_000 <= total <= 50_000_000 + n_g and reads[0] > reads[1] > reads[-1] > 0
+    first, count = split_range(total, 0, 8)
+    info = eng.long_plan(slots, reads, pod, 42, first, count)
+    assert info.n_reads == count and 1.2e11 < info.total_bases < 1.3e11   # ~20 kb each
+    bounds = np.cumsum([0] + reads)
+    done_bases = 0
+    for a in range(0, count, 1_000_000):
+        n = min(1_000_000, count - a)
+        part = eng.simulate_long_reads(slots, reads, pod, 42, first=first + a, count=n, qual_offset=33)
+        tb = part.total_bases
+        off = part.seq_off[: n + 1]
+        lens = off[1:] - off[:-1]
+        assert abs(lens.double().mean().item() - 20000) < 150 and int(off[-1]) == tb
+        gidx = np.searchsorted(bounds, first + a + np.arange(0, n, 50_000), side="right") - 1
+        got = part.genome[:n][::50_000].cpu().numpy()
+        assert np.array_equal(got, np.array(slots)[gidx])          # reads go to the genomes in run order
+        ids = part.read_id[:n].to(torch.int64)
+        assert bool((ids == first + a + torch.arange(n, device=ids.device)).all())
+        assert bool((part.end[:n] - part.start[:n] == lens).all()) and bool((part.end[:n] <= 10_000_000).all())
+        hist = torch.bincount(part.seq[: min(tb, 1 << 28)].to(torch.int64), minlength=256)
+        assert int(hist[[65, 67, 71, 84]].sum()) == min(tb, 1 << 28)
+        done_bases += tb
+        del part
+        torch.cuda.empty_cache()
+    assert done_bases == info.total_bases                           # the ranges tile the planned share
+
+
+def test_engine_set_stream_puts_the_work_on_that_stream(engine):
+    """simmr_engine_set_stream: events recorded on the given stream around a simulate call see the kernels' time;
+    events on another stream see none of it."""
+    import torch
+    eng = engine
+    eng.stage_synthetic(7, [5_000_000], 9)
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()
+    side, other = torch.cuda.Stream(), torch.cuda.Stream()
+    info = eng.pe_plan(7, prof, 8_000_000, 3)
+    from simmr_amd.engine import Reads
+    out = Reads.allocate(info.n_reads, info.total_bases, eng.device, qual_offset=33)
+    torch.cuda.synchronize()
+    try:
+        with torch.cuda.stream(side):
+            eng.use_current_torch_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        o0.record(other)
+        eng.pe_plan(7, prof, 8_000_000, 3)
+        eng.pe_emit(0, out)
+        e1.record(side)
+        o1.record(other)
+        torch.cuda.synchronize()
+        on_side, on_other = e0.elapsed_time(e1), o0.elapsed_time(o1)
+        kernel_ms = eng.last_emit_kernel_ms()
+        assert kernel_ms > 0.2 and on_side >= kernel_ms and on_other < 0.5 * kernel_ms, (on_side, on_other, kernel_ms)
+        whole = out.to_host()
+        assert whole["read_id"].size == 8_000_000 and int(whole["seq_off"][-1]) == info.total_bases
+    finally:
+        with torch.cuda.stream(torch.cuda.default_stream()):
+            eng.use_current_torch_stream()
