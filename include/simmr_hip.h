@@ -140,7 +140,8 @@ typedef struct simmr_plan_info {
  * of pair (r >> 1); mates are interleaved exactly as fastq.rs:32-121 writes
  * them.  Any pointer except seq/qual/seq_off may be NULL to skip that column. */
 typedef struct simmr_reads_out {
-  uint8_t* seq;       /* ASCII bases, total_bases bytes                       */
+  uint8_t* seq;       /* ASCII bases, total_bases bytes (no slack needed: every emit kernel bounds its last store;
+                         tests/test_gpu_shapes.py runs each of them between canaries at exactly this size) */
   uint8_t* qual;      /* Phred + qual_offset, total_bases bytes               */
   uint64_t* seq_off;  /* n_reads + 1 CSR offsets into seq / qual              */
   uint64_t* start;    /* ReadMetadata.start_pos (mate 2: the larger bound)    */

@@ -1527,10 +1527,16 @@ int simmr_long_emit(simmr_engine* e, uint32_t read_id_base, const simmr_reads_ou
 
 // ---- FASTQ framing (fastq.rs:14-124) -------------------------------------------------
 namespace {
-// fastq.rs:34-56 chains String::replace over the template in this order.  With ids free of braces
-// no replacement can create or complete a placeholder for a later step, so the chain equals one
-// left-to-right scan for the seven patterns; that scan is compiled here into literal / field pieces.
-bool compile_header_format(const char* fmt, std::vector<uint8_t>* blob, FqTemplate* tp) {
+// fastq.rs:34-56 chains String::replace over the template in this order.  The chain equals one left-to-right scan
+// for the seven patterns unless a replacement completes a placeholder of a LATER step.  Ids are refused when they hold
+// a brace, so the braces of such a placeholder would have to be literal text of the template with a replaced value
+// between them; the values of read_id / start / end are digits and those of reverse_complement / pair are t, f, 1, 2 —
+// no placeholder name of a later step can contain them — which leaves genome_id (step 1) and sequence_id (step 3):
+// "{:read_{:genome_id:}:}" with the genome id "id" becomes "{:read_id:}", and step 2 replaces it.  *risky says that
+// the template has a genome_id or sequence_id field with a '{' in literal text before it and a '}' in literal text
+// after it; the caller then answers SIMMR_ENOTSUP and the host writer, which replays the chain, takes over.
+bool compile_header_format(const char* fmt, std::vector<uint8_t>* blob, FqTemplate* tp, bool* risky) {
+  *risky = false;
   static const struct { const char* pat; uint32_t kind; } pats[] = {
       {"{:genome_id:}", FQ_GENOME_ID}, {"{:read_id:}", FQ_READ_ID}, {"{:sequence_id:}", FQ_SEQUENCE_ID},
       {"{:start_position:}", FQ_START}, {"{:end_position:}", FQ_END}, {"{:reverse_complement:}", FQ_REVCOMP},
@@ -1564,7 +1570,21 @@ bool compile_header_format(const char* fmt, std::vector<uint8_t>* blob, FqTempla
       }
     if (!hit) i++;
   }
-  return flush(n);
+  if (!flush(n)) return false;
+  for (uint32_t a = 0; a < tp->n_segs; a++) {
+    if (tp->segs[a].kind != FQ_GENOME_ID && tp->segs[a].kind != FQ_SEQUENCE_ID) continue;
+    bool open_before = false, close_after = false;
+    for (uint32_t b = 0; b < tp->n_segs; b++) {
+      if (tp->segs[b].kind != FQ_LITERAL) continue;
+      const uint8_t* t = blob->data() + tp->segs[b].off;
+      for (uint32_t k = 0; k < tp->segs[b].len; k++) {
+        if (b < a && t[k] == '{') open_before = true;
+        if (b > a && t[k] == '}') close_after = true;
+      }
+    }
+    if (open_before && close_after) *risky = true;
+  }
+  return true;
 }
 bool has_brace(const char* s) { return strchr(s, '{') || strchr(s, '}'); }
 }  // namespace
@@ -1579,12 +1599,21 @@ int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fas
     return e->fail(SIMMR_EINVAL, "simmr_fastq_plan needs every column of simmr_reads_out");
   HIP_TRY(e, hipSetDevice(e->device));
   std::vector<uint8_t> blob;
-  if (!compile_header_format(header_format, &blob, &e->fq_tpl))
+  bool risky = false;
+  if (!compile_header_format(header_format, &blob, &e->fq_tpl, &risky))
     return e->fail(SIMMR_ENOTSUP, "header format has more than %d pieces", FQ_MAX_SEGS);
+  if (risky)
+    return e->fail(SIMMR_ENOTSUP, "the header format has braces around a genome / sequence id: the reference's chain of "
+                                  "replacements may build a placeholder out of them (fastq.rs:34-56)");
   const uint32_t lit_bytes = (uint32_t)blob.size();  // the literals come first in the blob
   if (lit_bytes > FQ_LIT_MAX) return e->fail(SIMMR_ENOTSUP, "header format has more than %u literal bytes", FQ_LIT_MAX);
   uint32_t n_slots = 0;
-  for (uint32_t g = 0; g < names->n_genomes; g++) n_slots = std::max(n_slots, names->genome_idx[g] + 1);
+  for (uint32_t g = 0; g < names->n_genomes; g++) {
+    // a name for a genome index the engine has never seen is a caller error (and index + 1 below must not wrap)
+    if (names->genome_idx[g] >= e->genomes.size())
+      return e->fail(SIMMR_EINVAL, "simmr_fastq_plan: genome index %u was never staged", names->genome_idx[g]);
+    n_slots = std::max(n_slots, names->genome_idx[g] + 1);
+  }
   std::vector<uint32_t> gid_off(std::max(n_slots, 1u), 0), gid_len(std::max(n_slots, 1u), 0), cbase(std::max(n_slots, 1u), 0),
       ncontig(std::max(n_slots, 1u), 0), coff, clen;
   size_t row = 0;

@@ -43,7 +43,8 @@ class Reads:
     def allocate(cls, n_reads: int, total_bases: int, device, qual_offset: int = 0) -> "Reads":
         torch = _torch()
         n = max(int(n_reads), 1)
-        # seq/qual padded so 16-byte vector stores of the last chunk stay in bounds
+        # the library needs exactly total_bases bytes (include/simmr_hip.h); the slack only keeps torch views of
+        # whole 16-byte rows possible for the tests' checksums
         nb = (int(total_bases) + 15) // 16 * 16 + 16
         return cls(
             seq=torch.empty(nb, dtype=torch.uint8, device=device),

@@ -86,10 +86,15 @@ def test_fastq_left_to_the_host(engine, genome_multi):
     n = len(genome_multi.contigs)
     for names, fmt in (([(1, "id{with}braces", ["c"] * n)], FMT), ([(1, "g", ["{:pair:}"] + ["c"] * (n - 1))], FMT),
                        ([(1, "g", ["c" * 300] * n)], FMT), ([(1, "g", ["c"] * n)], "{:pair:}x" * 13),
-                       ([(0, "wrong slot", ["c"])], FMT)):
+                       ([(0, "wrong slot", ["c"])], FMT),
+                       # the chain of replacements would complete "{:read_id:}" out of the template's own braces
+                       ([(1, "id", ["c"] * n)], "@{:read_{:genome_id:}:}/{:pair:}")):
         with pytest.raises(SimmrError) as ei:
             engine.fastq(reads, fmt, names, True)
         assert ei.value.code == _abi.ENOTSUP
+    with pytest.raises(SimmrError) as ei:  # a genome index the engine has never seen (0xffffffff + 1 must not wrap)
+        engine.fastq(reads, FMT, [(0xffffffff, "g", ["c"])], True)
+    assert ei.value.code == _abi.EINVAL
     # an empty shard is an empty file
     empty = engine.simulate_pe_reads_from_genome(1, PerfectShortErrorProfile().pod(), 100, 1, first=50, count=0, qual_offset=33)
     assert engine.fastq(empty, FMT, [(1, "g", ["c"] * n)], True).numel() == 0

@@ -16,6 +16,14 @@ from tests.test_gpu_fullsize import checksum_range, colsum256
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def genome_multi(engine):
+    lens = [300_000, 90_001, 30_017, 70_000, 123_457]
+    contigs = _synth.synthetic_contigs(lens, 7)
+    engine.stage_genome(1, contigs)
+    return _oracle.HostGenome(contigs)
+
+
 @pytest.mark.parametrize("rng_mode", [_abi.RNG_REFERENCE, _abi.RNG_PHILOX])
 def test_c4_thousand_genomes_rank_shards(engine, oracle, rng_mode):
     """1000 genomes (one sequence of 30 kbp each, SplitMix64(1000 + g)), uniform abundance, 2 M reads: rank r of 8
@@ -144,34 +152,132 @@ def test_c5_share_of_one_gpu(engine):
 
 
 def test_engine_set_stream_puts_the_work_on_that_stream(engine):
-    """simmr_engine_set_stream: events recorded on the given stream around a simulate call see the kernels' time;
-    events on another stream see none of it."""
+    """simmr_engine_set_stream: the emit kernels queue up behind earlier work of the stream the engine was given (a
+    100 ms spin on that stream delays them), and not behind work of a stream it was not given."""
+    import time
     import torch
+    from simmr_amd.engine import Reads
     eng = engine
     eng.stage_synthetic(7, [5_000_000], 9)
     prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()
-    side, other = torch.cuda.Stream(), torch.cuda.Stream()
-    info = eng.pe_plan(7, prof, 8_000_000, 3)
-    from simmr_amd.engine import Reads
+    side = torch.cuda.Stream()
+    info = eng.pe_plan(7, prof, 2_000_000, 3)
     out = Reads.allocate(info.n_reads, info.total_bases, eng.device, qual_offset=33)
-    torch.cuda.synchronize()
+    spin = 400_000_000  # device clock cycles: well over 100 ms
+
+    def emit_behind_a_spin_on_side():
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(spin)
+        t0 = time.perf_counter()
+        eng.pe_emit(0, out)  # on the engine's stream
+        done = torch.cuda.Event()
+        done.record(side if on_side else torch.cuda.current_stream())
+        done.synchronize()  # the emit kernels are through
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return dt
+
     try:
+        on_side = True
         with torch.cuda.stream(side):
             eng.use_current_torch_stream()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(side)
-        o0.record(other)
-        eng.pe_plan(7, prof, 8_000_000, 3)
-        eng.pe_emit(0, out)
-        e1.record(side)
-        o1.record(other)
-        torch.cuda.synchronize()
-        on_side, on_other = e0.elapsed_time(e1), o0.elapsed_time(o1)
-        kernel_ms = eng.last_emit_kernel_ms()
-        assert kernel_ms > 0.2 and on_side >= kernel_ms and on_other < 0.5 * kernel_ms, (on_side, on_other, kernel_ms)
-        whole = out.to_host()
-        assert whole["read_id"].size == 8_000_000 and int(whole["seq_off"][-1]) == info.total_bases
+        eng.pe_plan(7, prof, 2_000_000, 3)
+        dt = emit_behind_a_spin_on_side()
+        assert dt > 0.08, dt                            # the kernels waited for the spin
+        first = out.to_host()
+        on_side = False
+        with torch.cuda.stream(torch.cuda.default_stream()):
+            eng.use_current_torch_stream()
+        eng.pe_plan(7, prof, 2_000_000, 3)
+        out.seq.zero_()
+        dt = emit_behind_a_spin_on_side()
+        assert dt < 0.08, dt                            # nothing of the engine's is behind the other stream's spin
+        again = out.to_host()
+        for col in ("seq", "qual", "seq_off", "read_id"):
+            assert np.array_equal(first[col], again[col]), col
     finally:
         with torch.cuda.stream(torch.cuda.default_stream()):
             eng.use_current_torch_stream()
+
+
+# ---- the output contract: seq / qual hold exactly total_bases bytes -------------------------------------------
+def _exact_reads(engine, info, qual_offset):
+    """simmr_reads_out whose seq / qual are EXACTLY total_bases long, cut out of larger canary-filled buffers."""
+    import torch
+    from simmr_amd.engine import Reads
+    PAD = 256
+    tb = int(info.total_bases)
+    r = Reads.allocate(info.n_reads, tb, engine.device, qual_offset)
+    bufs = []
+    for name in ("seq", "qual"):
+        buf = torch.full((tb + 2 * PAD,), 0xA5, dtype=torch.uint8, device=engine.device)
+        setattr(r, name, buf[PAD:PAD + tb])
+        bufs.append(buf)
+    assert r.pod().seq_capacity == tb
+    return r, bufs, PAD, tb
+
+
+def _canaries_intact(bufs, PAD, tb):
+    for b in bufs:
+        assert bool((b[:PAD] == 0xA5).all()) and bool((b[PAD + tb:] == 0xA5).all())
+
+
+@pytest.mark.parametrize("path", ["perfect-short", "minimal-short", "minimal-short-wave", "philox-short", "custom-short",
+                                  "minimal-long", "philox-long", "perfect-long", "custom-long"])
+def test_emit_stays_inside_exact_capacity(engine, genome_multi, path, monkeypatch):
+    """include/simmr_hip.h promises that seq and qual need total_bases bytes, not a byte more: every emit kernel is run
+    with buffers of exactly that size between canaries (lengths that are no multiple of 16, so the last chunk is a
+    partial one), and must reproduce the padded run."""
+    import torch
+    from simmr_amd import (CustomShortErrorProfile, PerfectLongErrorProfile, PerfectShortErrorProfile, model_io)
+    from simmr_amd.engine import Engine
+    eng = engine
+    if path == "minimal-short-wave":  # the wave-per-unit emit kernel is chosen when the engine is created
+        monkeypatch.setenv("SIMMR_EMIT_VARIANT", "1")
+        eng = Engine(0)
+        eng.stage_genome(1, genome_multi.contigs)
+    keep = None
+    long_mode = path.endswith("long")
+    if path == "perfect-short":
+        pod = PerfectShortErrorProfile(read_length=37, insert_size=45).pod()
+    elif path in ("minimal-short", "minimal-short-wave"):
+        pod = MinimalShortErrorProfile(read_length=41, insert_size=60).pod()
+    elif path == "philox-short":
+        pod = MinimalShortErrorProfile(read_length=41, insert_size=60, rng_mode=_abi.RNG_PHILOX).pod()
+    elif path == "custom-short":
+        keep = CustomShortErrorProfile(model_io.synthetic_short_model(n_positions=40, seed=5, mean_len=45, sd_len=7,
+                                                                      mean_insert=70, sd_insert=10))
+        pod = keep.pod()
+    elif path == "minimal-long":
+        pod = MinimalLongErrorProfile(gamma_mean=900.0, gamma_std=700.0, length_mode=_abi.LEN_PER_READ).pod()
+    elif path == "philox-long":
+        pod = MinimalLongErrorProfile(gamma_mean=900.0, gamma_std=700.0, length_mode=_abi.LEN_PER_READ,
+                                      rng_mode=_abi.RNG_PHILOX).pod()
+    elif path == "perfect-long":
+        pod = PerfectLongErrorProfile(gamma_mean=900.0, gamma_std=700.0, length_mode=_abi.LEN_PER_READ).pod()
+    else:
+        keep = CustomShortErrorProfile(model_io.synthetic_long_model(kmer_size=5, n_positions=60, seed=2, n_kmers=600,
+                                                                     with_n=False, read_length_mean=700.0, read_length_std=200.0))
+        pod = keep.pod()
+        pod.length_mode = _abi.LEN_PER_READ
+        pod.long_start_mode = _abi.START_UNIFORM
+    try:
+        if long_mode:
+            info = eng.long_plan([1], [333], pod, 7)
+            padded = eng.simulate_long_reads([1], [333], pod, 7, qual_offset=33).to_host()
+            info = eng.long_plan([1], [333], pod, 7)
+        else:
+            info = eng.pe_plan(1, pod, 2601, 7)
+            padded = eng.simulate_pe_reads_from_genome(1, pod, 2601, 7, qual_offset=33).to_host()
+            info = eng.pe_plan(1, pod, 2601, 7)
+        r, bufs, PAD, tb = _exact_reads(eng, info, 33)
+        (eng.long_emit if long_mode else eng.pe_emit)(0, r)
+        torch.cuda.synchronize()
+        _canaries_intact(bufs, PAD, tb)
+        exact = r.to_host()
+        for col in ("seq", "qual", "seq_off", "start", "end", "contig", "read_id", "flags"):
+            assert np.array_equal(exact[col], padded[col]), col
+    finally:
+        if eng is not engine:
+            eng.close()
