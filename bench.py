@@ -243,7 +243,11 @@ def main():
             "mean_phred": float(counters[_abi.CNT_QUAL_SUM]) / max(float(counters[_abi.CNT_BASES]), 1.0),
             "plan_ms_per_step": sum(plan_ms) / max(len(plan_ms), 1),
             "roofline": {
+                # "hbm" is the roofline the fraction below is taken against (the contract's two choices are hbm and
+                # mfma, and this path has no matrix work); what actually limits the kernel is in `limiter`
                 "bound": "hbm",
+                "limiter": ("hbm write path" if args.profile == "perfect-short" else
+                            "VALU issue (integer RNG and table lookups) next to the HBM write path: see `valu`"),
                 "kernel": ("k_emit_perfect_pe" if args.profile == "perfect-short" else
                            "k_emit_custom_pe" if args.profile == "custom-short" else
                            "k_custom_long_qual + k_custom_long_splice" if custom is not None else
@@ -256,9 +260,13 @@ def main():
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": emit_avg_ms,
                 "note": ("HBM-write bound data movement" if args.profile == "perfect-short" else
-                         "integer-VALU bound (RNG), not HBM bound: see DESIGN.md section 4 and profiles/"),
+                         "see DESIGN.md section 4 and profiles/r2: differential timing (make ablate) puts the stores at "
+                         "a third of the kernel and the instruction stream at two thirds"),
             },
         }
+        valu = measured_valu(args, 2 * pairs_per_gpu, emit_avg_ms)
+        if valu is not None:
+            result["roofline"]["valu"] = valu
         if other is not None:
             result["other_rng_mode"] = other
         if world == 1 and not args.no_cpu_baseline and not long_mode:
@@ -269,21 +277,44 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(args, reads_per_gpu):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1/g_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs of this very
-    command); only reported for the workload it was measured on."""
+def _profile_record(args, reads_per_gpu):
+    """The committed rocprofv3 PMC record of this very command (profiles/r2/pmc_traffic.json: one counter set per
+    run, no tracing); only for the workload it was measured on."""
     try:
-        t = json.load(open(ROOT / "profiles" / "r1" / "g_traffic.json"))
+        t = json.load(open(ROOT / "profiles" / "r2" / "pmc_traffic.json"))
     except OSError:
         return None
     if reads_per_gpu != 100_000_000 or args.genome_bases != 100_000_000:
         return None
     if args.profile == "minimal-short" and args.rng == "philox":
-        return t["bytes_raw"]
+        return t.get("k_emit_philox")
     if args.profile == "perfect-short":
-        return t["perfect_short"]["bytes_raw"]
+        return t.get("k_emit_perfect_pe")
     return None
+
+
+def measured_traffic(args, reads_per_gpu):
+    """HBM bytes per launch of the dominant kernel: FETCH_SIZE + WRITE_SIZE of separate --pmc passes, raw (the guide's
+    x2 correction of FETCH_SIZE applies to wide coalesced reads; this kernel reads 8-byte gathers and plan columns, so
+    the raw figure is reported and the doubled one is in the file).  Not measured by this run: a constant from the
+    committed profile, null for any other workload."""
+    t = _profile_record(args, reads_per_gpu)
+    return None if t is None else t["bytes_raw"]
+
+
+def measured_valu(args, reads_per_gpu, kernel_ms):
+    """VALU wave-instructions per launch (SQ_INSTS_VALU of the committed PMC pass) against the measured issue peak of
+    plain 32-bit integer VALU instructions (profiles/microbench/valu_asm_rates2_mi355x.txt: v_add_u32 8.4e11
+    wave-instructions/s on the whole chip; v_perm / v_alignbit / SDWA forms issue at 0.66 of that, v_mad_u64_u32 at
+    0.47): the time the instruction stream alone needs, as a share of the kernel's time."""
+    t = _profile_record(args, reads_per_gpu)
+    if t is None or "SQ_INSTS_VALU" not in t or kernel_ms <= 0:
+        return None
+    peak = 8.443e11
+    need_ms = t["SQ_INSTS_VALU"] / peak * 1e3
+    return {"wave_instructions_per_launch": t["SQ_INSTS_VALU"], "issue_peak_per_s": peak, "unit": "wave-instructions",
+            "min_time_ms_at_peak": need_ms, "frac_of_kernel_time": need_ms / kernel_ms,
+            "source": "profiles/r2/pmc_traffic.json (committed PMC pass of this command), not measured by this run"}
 
 
 def usable_cores():
