@@ -1954,8 +1954,10 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
 // (no load from the reference plane), SIMMR_ABLATE_META (no metadata columns), SIMMR_ABLATE_ITEMS (one
 // round of items per block), SIMMR_ABLATE_ALL16 / SIMMR_ABLATE_ALIGN16 (partial groups stored as
 // 16 bytes / every store aligned down to 16 bytes: wrong bytes, inside the buffers), SIMMR_ABLATE_NOP
-// (without the wait states between the compare and the select).  None of them changes an index, a
-// pointer into a table or a loop bound.
+// (without the wait states between the compare and the select), SIMMR_ABLATE_HOTSTORE (the same store
+// instructions, all landing in the first 64 KB of the two streams: store issue without the DRAM write
+// path), SIMMR_ABLATE_LINES (every store instruction of a wave writes sixteen whole 64-byte lines).  None
+// of them changes an index, a pointer into a table or a loop bound.
 // ===========================================================================
 SIMMR_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
@@ -2322,7 +2324,16 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #if defined(SIMMR_ABLATE_STORES)
       asm volatile("" :: "v"(q_lo), "v"(q_hi), "v"(s_lo), "v"(s_hi), "v"(o_q), "v"(o_s));  // alive, not stored
 #else
-#if defined(SIMMR_ABLATE_ALIGN16)
+#if defined(SIMMR_ABLATE_LINES)
+      // timing only: every 16-byte store instruction of a wave writes sixteen WHOLE 64-byte lines (the wave's first
+      // lane's place rounded down to 1 KB, then lane by lane); wrong places, inside the buffers
+      uint8_t* qd = qual + (((uint64_t)__builtin_amdgcn_readfirstlane(o_q) + out0) & ~1023ull) + 16u * (threadIdx.x & 63u);
+      uint8_t* sd = seq + (((uint64_t)__builtin_amdgcn_readfirstlane(o_s) + out0) & ~1023ull) + 16u * (threadIdx.x & 63u);
+#elif defined(SIMMR_ABLATE_HOTSTORE)
+      // timing only: every store lands in the first 64 KB of the buffers (same instructions, no DRAM write traffic)
+      uint8_t* qd = qual + ((o_q + (uint32_t)out0) & 0xffffu);
+      uint8_t* sd = seq + ((o_s + (uint32_t)out0) & 0xffffu);
+#elif defined(SIMMR_ABLATE_ALIGN16)
       // timing only: every store lands on the aligned 16 bytes below its place (still inside the buffers)
       uint8_t* qd = (uint8_t*)((uintptr_t)(qual_blk + o_q) & ~(uintptr_t)15);
       uint8_t* sd = (uint8_t*)((uintptr_t)(seq_blk + o_s) & ~(uintptr_t)15);
