@@ -179,7 +179,14 @@ struct KmerTables {
   std::vector<Rec16> slots;   // {3-bit key (~0 = empty), first record, n alternates (~0 = unusable weights), zone}
   std::vector<Rec16> recs;    // {odds f32, alternate c, alternate alias(c), Uniform(0, sum) scale f32}
   uint32_t mask = 0;
+  // The same columns at a fixed stride, for models whose k-mer codes fit a byte table in LDS (k <= 7) and whose lists
+  // are short: a visited k-mer then costs ONE dependent global load (its column) instead of two (entry, then column).
+  std::vector<uint8_t> cnt8;  // by 2-bit k-mer code: n alternates (0 = not in the model, 255 = unusable weights)
+  std::vector<Rec16> cols;    // [code * stride + c]
+  uint32_t stride = 0;        // 0 = no fixed-stride tables
 };
+constexpr uint32_t KMER_FAST_MAX_K = 7;          // 4^7 bytes = 16 KB of LDS
+constexpr uint32_t KMER_FAST_MAX_STRIDE = 32;    // 4^7 * 32 * 16 B = 8 MB at most
 
 inline float pairwise_sum_f32(const float* v, size_t n) {
   if (n <= 32) { float s = 0.0f; for (size_t i = 0; i < n; i++) s += v[i]; return s; }
@@ -289,6 +296,23 @@ inline bool build_kmer_tables(const ModelHost& m, KmerTables* t, std::string* er
     }
   }
   if (t->recs.empty()) t->recs.push_back(Rec16{0u, 0u, 0u, 0u});
+  // fixed-stride copy of the direct entries' columns
+  t->cnt8.clear(); t->cols.clear(); t->stride = 0;
+  if (K <= KMER_FAST_MAX_K) {
+    uint32_t longest = 1;
+    for (const Rec16& d : t->direct) if (d.y != 0xFFFFFFFFu && d.y > longest) longest = d.y;
+    if (longest <= KMER_FAST_MAX_STRIDE) {
+      t->stride = longest;
+      t->cnt8.assign(t->direct.size(), 0);
+      t->cols.assign(t->direct.size() * (size_t)longest, Rec16{0u, 0u, 0u, 0u});
+      for (size_t code = 0; code < t->direct.size(); code++) {
+        const Rec16& d = t->direct[code];
+        if (d.y == 0xFFFFFFFFu) { t->cnt8[code] = 255; continue; }
+        t->cnt8[code] = (uint8_t)d.y;
+        for (uint32_t c = 0; c < d.y; c++) t->cols[code * (size_t)longest + c] = t->recs[d.x + c];
+      }
+    }
+  }
   return true;
 }
 

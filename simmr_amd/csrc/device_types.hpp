@@ -68,6 +68,11 @@ struct CustomDev {
   const Rec16* kmer_recs;    // per alias column c: {odds f32, alternate c, alternate alias(c) (2 bits per base, bit 31 = not ACGT), scale f32}
   uint32_t kmer_mask;       // slots - 1
   uint32_t kmer_size;
+  // fixed-stride form of the direct entries (k <= 7, short lists; null otherwise): the counts go to LDS
+  const uint8_t* kmer_cnt8;  // by 2-bit k-mer code: n alternates (0 = absent, 255 = the reference panics)
+  const Rec16* kmer_cols;    // [code * kmer_stride + c], same records as kmer_recs
+  uint32_t kmer_stride;
+  uint32_t pad2;
 };
 
 // Device form of simmr_error_profile, with host-derived constants.

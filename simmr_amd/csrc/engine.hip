@@ -92,7 +92,7 @@ struct simmr_engine {
   // long-read runs
   DevBuf d_runs, d_usable;
   // custom profile tables
-  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, c_colrec, c_binrec, c_kslots, c_krecs, c_kdirect, ph_table;
+  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, c_colrec, c_binrec, c_kslots, c_krecs, c_kdirect, c_kcnt8, c_kcols, ph_table;
   // FASTQ framing
   DevBuf fq_blob, fq_gid_off, fq_gid_len, fq_cbase, fq_ncontig, fq_coff, fq_clen, fq_len, fq_off;
   FqTemplate fq_tpl{};
@@ -293,6 +293,7 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
     if ((rc = upload_vec(e, e->c_kslots, kt.slots)) || (rc = upload_vec(e, e->c_krecs, kt.recs)) ||
         (rc = upload_vec(e, e->c_kdirect, kt.direct)))
       return rc;
+    if (kt.stride && ((rc = upload_vec(e, e->c_kcnt8, kt.cnt8)) || (rc = upload_vec(e, e->c_kcols, kt.cols)))) return rc;
   }
   if ((rc = sync_check(e, "custom table upload"))) return rc;  // the host vectors go out of scope
   ProfileDev d{};
@@ -321,6 +322,9 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
     d.custom.kmer_recs = e->c_krecs.as<Rec16>();
     d.custom.kmer_mask = kt.mask;
     d.custom.kmer_size = (uint32_t)m.kmer_size;
+    d.custom.kmer_stride = kt.stride;
+    d.custom.kmer_cnt8 = kt.stride ? e->c_kcnt8.as<uint8_t>() : nullptr;
+    d.custom.kmer_cols = kt.stride ? e->c_kcols.as<Rec16>() : nullptr;
   }
   *out = d;
   return SIMMR_OK;
@@ -821,7 +825,7 @@ void simmr_engine_destroy(simmr_engine* e) {
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_qs2,
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
-                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->c_kslots, &e->c_krecs, &e->c_kdirect, &e->ph_table,
+                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->c_kslots, &e->c_krecs, &e->c_kdirect, &e->c_kcnt8, &e->c_kcols, &e->ph_table,
                     &e->fq_blob, &e->fq_gid_off, &e->fq_gid_len, &e->fq_cbase, &e->fq_ncontig, &e->fq_coff, &e->fq_clen,
                     &e->fq_len, &e->fq_off, &e->m_genomes, &e->m_contig, &e->m_seed};
   for (DevBuf* b : bufs) b->release();
@@ -1306,10 +1310,23 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       hipLaunchKernelGGL(k_custom_long_qual, dim3(grid), dim3(256), 0, e->stream, e->prof, n_units, order, pl,
                          e->u_off.as<uint64_t>(), e->u_seed.as<uint64_t>(), out->qual, out->qual_offset, counters,
                          e->d_err.as<uint32_t>());
-      auto kern = exc ? k_custom_long_splice<true> : k_custom_long_splice<false>;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), n_units, order,
-                         pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
-                         e->u_seed.as<uint64_t>(), out->seq, counters, e->d_err.as<uint32_t>());
+      bool fast = e->prof.custom.kmer_stride != 0;
+      if (const char* s = getenv("SIMMR_SPLICE_VARIANT")) fast = fast && atoi(s) != 1;  // 1: the two-load kernel (A/B timing)
+      if (fast) {
+        // one workgroup of 1024 lanes per CU around the LDS count table (kernels.hip section 9c)
+        auto kern = exc ? k_custom_long_splice<true, true> : k_custom_long_splice<false, true>;
+        const uint32_t lds = splice_fast_lds_bytes(e->prof.custom.kmer_size);
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint32_t fgrid = (uint32_t)std::min<uint64_t>((n_reads + SPLICE_FAST_LANES - 1) / SPLICE_FAST_LANES, (uint64_t)e->n_cu * 8);
+        hipLaunchKernelGGL(kern, dim3(fgrid), dim3(SPLICE_FAST_LANES), lds, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
+                           n_units, order, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
+                           e->u_seed.as<uint64_t>(), out->seq, counters, e->d_err.as<uint32_t>());
+      } else {
+        auto kern = exc ? k_custom_long_splice<true, false> : k_custom_long_splice<false, false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), n_units, order,
+                           pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
+                           e->u_seed.as<uint64_t>(), out->seq, counters, e->d_err.as<uint32_t>());
+      }
     } else if (e->prof.kind == SIMMR_K_CUSTOM) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
       const uint64_t blocks = (n_units + 255) / 256;  // one lane per pair

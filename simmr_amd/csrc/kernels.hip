@@ -2566,11 +2566,11 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
 // the last k-mer, returns fewer bases than qualities), so the lane raises
 // SIMMR_ERRBIT_KMER instead.
 // ===========================================================================
-__device__ __attribute__((noinline)) void refill_words(const Key key, uint32_t blk, uint32_t* __restrict__ row) {
+__device__ __attribute__((noinline)) void refill_words(const Key key, uint32_t blk, uint32_t* __restrict__ row, uint32_t stride = 1u) {
   uint32_t o[16];
   chacha12_block(key, (uint64_t)blk, o);
 #pragma unroll
-  for (int i = 0; i < 16; i++) row[i] = o[i];
+  for (int i = 0; i < 16; i++) row[(uint32_t)i * stride] = o[i];
 }
 
 // qualities of the long reads (simulate_phred_scores, custom_short.rs:332-353): one lane per read
@@ -2679,21 +2679,45 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
   if ((threadIdx.x & 63u) == 0 && counters) atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
 }
 
-// bases of the long reads (simulate_errors, custom_short.rs:455-516): one lane per read
-template <bool HAS_EXC>
-__global__ void __launch_bounds__(256)
+// bases of the long reads (simulate_errors, custom_short.rs:455-516): one lane per read.
+// FAST (k <= 7 and short alternate lists, CustomDev::kmer_cols): the per-k-mer counts sit in LDS as bytes and the
+// columns at a fixed stride, so a visited k-mer costs one dependent global load (its column) instead of two (entry,
+// then column) — the kernel is bound by that chain and by the rate of per-lane line requests, not by arithmetic.  One
+// workgroup of 1024 lanes per CU then shares the 16 KB count table: LDS = word rows [32][1024] (word-major: lanes
+// of a wave in consecutive banks whatever word each is at) + the Uniform(0, n) zones + the counts.
+constexpr uint32_t SPLICE_FAST_LANES = 1024u;
+__host__ __device__ inline uint32_t splice_fast_lds_bytes(uint32_t k) { return 32u * SPLICE_FAST_LANES * 4u + 256u * 4u + (1u << (2u * k)); }
+template <bool HAS_EXC, bool FAST>
+__global__ void __launch_bounds__(FAST ? 1024 : 256)
 k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint64_t n_units,
                      const uint32_t* __restrict__ order, PlanArrays pl,
                      const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
                      const uint32_t* __restrict__ u_genome, const uint64_t* __restrict__ u_seed,
                      uint8_t* __restrict__ seq, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
-  __shared__ uint32_t words[256][33];  // per lane: two blocks of its stream
+  constexpr uint32_t NT = FAST ? SPLICE_FAST_LANES : 256u;
+  constexpr uint32_t RS = FAST ? SPLICE_FAST_LANES : 1u;  // distance between two words of a lane's row
+  __shared__ uint32_t words[FAST ? 1 : 256][33];  // per lane: two blocks of its stream
+  extern __shared__ uint32_t splice_lds[];        // FAST: rows, zones, counts
   const CustomDev C = prof.custom;
   const uint32_t K = C.kmer_size;  // 1..10 (checked on the host)
   uint32_t n_acgt = 0, n_subst = 0;
   bool bad_kmer = false;
-  uint32_t* const row = words[threadIdx.x];
-  for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n_units; r0 += (uint64_t)gridDim.x * 256) {
+  uint32_t* const row = FAST ? splice_lds + threadIdx.x : words[threadIdx.x];
+  const uint32_t* const s_zone = splice_lds + 32u * SPLICE_FAST_LANES;
+  const uint8_t* const s_cnt8 = reinterpret_cast<const uint8_t*>(s_zone + 256);
+  if (FAST) {
+    uint32_t* zone_w = splice_lds + 32u * SPLICE_FAST_LANES;
+    if (threadIdx.x < 256u) {
+      const uint32_t c = threadIdx.x;  // Uniform::new(0u32, c): the largest accepted low word
+      zone_w[c] = c ? 0xFFFFFFFFu - (uint32_t)((0x100000000ULL - c) % c) : 0u;
+    }
+    uint32_t* cnt_w = zone_w + 256;
+    const uint32_t n_w = (1u << (2u * K)) >> 2;  // 4^K bytes
+    const uint32_t* src_w = reinterpret_cast<const uint32_t*>(C.kmer_cnt8);
+    for (uint32_t w = threadIdx.x; w < n_w; w += NT) cnt_w[w] = src_w[w];
+    __syncthreads();
+  }
+  for (uint64_t r0 = (uint64_t)blockIdx.x * NT; r0 < n_units; r0 += (uint64_t)gridDim.x * NT) {
     const uint64_t ti = r0 + threadIdx.x;
     const uint64_t u = ti < n_units ? (order ? (uint64_t)order[n_units - 1 - ti] : ti) : n_units;
     uint32_t n = 0;
@@ -2710,7 +2734,7 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
       seed = u_seed[u];  // read_seed re-seeds every per-read generator (simulate.rs:497-503)
     }
     const Key key = pcg32_expand(seed);
-    refill_words(key, 0, row);
+    refill_words(key, 0, row, RS);
     // ---- simulate_errors
     {
       // StdRng(read_seed): the row holds two blocks of the stream, block b at words (b & 1) * 16.  Every 8
@@ -2719,8 +2743,8 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
       // between (rejected draws) generates on its own.
       uint32_t wpos = 0, have = 1;  // next word; blocks [0, have) were generated
       auto next_word = [&]() -> uint32_t {
-        if ((wpos >> 4) >= have) { refill_words(key, have, row + (have & 1u) * 16u); have++; }
-        const uint32_t w = row[wpos & 31u];
+        if ((wpos >> 4) >= have) { refill_words(key, have, row + (have & 1u) * 16u * RS, RS); have++; }
+        const uint32_t w = row[(wpos & 31u) * RS];
         wpos++;
         return w;
       };
@@ -2752,14 +2776,21 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
           if ((t & 7u) == 0u) {
             const bool need = i < n && have < (wpos >> 4) + 2u;
             if (__any(need)) {
-              if (need) { refill_words(key, have, row + (have & 1u) * 16u); have++; }
+              if (need) { refill_words(key, have, row + (have & 1u) * 16u * RS, RS); have++; }
             }
           }
           if (i < n) {
             // three_bit_encode_kmer fails on anything but ACGTN (encoding.rs:149-176): a '-' skips the k-mer
             if (i + K <= n && !dead && (!HAS_EXC || dm == 0u)) {
               uint32_t first = 0, cnt = 0, zone = 0;
-              if (!HAS_EXC || nm == 0u) {
+              const Rec16* recs = C.kmer_recs;
+              if ((!HAS_EXC || nm == 0u) && FAST) {
+                cnt = s_cnt8[win];
+                zone = s_zone[cnt];
+                recs = C.kmer_cols;
+                first = win * C.kmer_stride;
+                if (cnt == 255u) cnt = 0xFFFFFFFFu;
+              } else if (!HAS_EXC || nm == 0u) {
                 const Rec16 d = C.kmer_direct[win];
                 first = d.x; cnt = d.y; zone = d.z;
               } else {
@@ -2779,7 +2810,7 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
                   const uint64_t m = (uint64_t)next_word() * cnt;
                   if ((uint32_t)m <= zone) { c = (uint32_t)(m >> 32); break; }
                 }
-                const Rec16 rec = C.kmer_recs[first + c];
+                const Rec16 rec = recs[first + c];
                 const float v12 = __uint_as_float((next_word() >> 9) | 0x3F800000u);
                 const float x = __fadd_rn(__fmul_rn(__fsub_rn(v12, 1.0f), __uint_as_float(rec.w)), 0.0f);
                 const uint32_t alt = x < __uint_as_float(rec.x) ? rec.y : rec.z;
