@@ -2566,7 +2566,10 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
 // the last k-mer, returns fewer bases than qualities), so the lane raises
 // SIMMR_ERRBIT_KMER instead.
 // ===========================================================================
-__device__ __attribute__((noinline)) void refill_words(const Key key, uint32_t blk, uint32_t* __restrict__ row, uint32_t stride = 1u) {
+// (the row is passed as an LDS pointer: through a generic one the sixteen stores compile to flat_store_dword, which
+// take the vector-memory path — 2 per step of the splice, as many as its loads)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __attribute__((noinline)) void refill_words(const Key key, uint32_t blk, lds_u32* __restrict__ row, uint32_t stride = 1u) {
   uint32_t o[16];
   chacha12_block(key, (uint64_t)blk, o);
 #pragma unroll
@@ -2702,7 +2705,7 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
   const uint32_t K = C.kmer_size;  // 1..10 (checked on the host)
   uint32_t n_acgt = 0, n_subst = 0;
   bool bad_kmer = false;
-  uint32_t* const row = FAST ? splice_lds + threadIdx.x : words[threadIdx.x];
+  lds_u32* const row = (lds_u32*)(FAST ? splice_lds + threadIdx.x : words[threadIdx.x]);
   const uint32_t* const s_zone = splice_lds + 32u * SPLICE_FAST_LANES;
   const uint8_t* const s_cnt8 = reinterpret_cast<const uint8_t*>(s_zone + 256);
   if (FAST) {
@@ -2770,6 +2773,62 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
         const uint32_t s16 = i0 < n ? fetch_codes16(packed, (int64_t)(src0 + i0 + K)) : 0u;
         const uint32_t x16 = (HAS_EXC && mask && i0 < n) ? fetch_mask16(mask, (int64_t)(src0 + i0 + K)) : 0u;
         uint32_t out[4] = {0u, 0u, 0u, 0u};  // 16 output bases
+        bool todo = true;  // this group still has to be walked the general way
+        if (FAST) {
+          // A group that lies inside every read of the wave (reads are dealt in order of length, so that is all but the
+          // last of a wave's groups), with no exception base in sight: sixteen steps without a branch per lane.  What
+          // the straight line cannot do — a rejected index draw (1e-9), a k-mer whose weights the reference panics on,
+          // an alternate with an N — is only noticed; such a lane takes its state back and walks the group again below.
+          const bool inside = i0 + 16u + K <= n && !dead && (!HAS_EXC || (nm | dm | oexc | x16) == 0u);
+          if (__all(inside)) {
+            const uint32_t win_0 = win, owin_0 = owin, wpos_0 = wpos, subst_0 = n_subst;
+            const uint32_t kmask2 = (1u << (2u * K)) - 1u;
+            const char* const cols_bytes = reinterpret_cast<const char*>(C.kmer_cols);
+            const uint32_t stride16 = C.kmer_stride << 4;
+            bool rare = false;
+#pragma unroll
+            for (uint32_t t = 0; t < 16u; t++) {
+              if ((t & 7u) == 0u) {
+                const bool need = have < (wpos >> 4) + 2u;  // then at least 17 words are ready: 8 steps take 16
+                if (__any(need)) {
+                  if (need) { refill_words(key, have, row + (have & 1u) * 16u * RS, RS); have++; }
+                }
+              }
+              const uint32_t cnt = s_cnt8[win];
+              const uint32_t zn = s_zone[cnt];
+              const uint32_t w1 = row[(wpos & 31u) * RS], w2 = row[((wpos + 1u) & 31u) * RS];
+              const uint64_t m = (uint64_t)w1 * cnt;
+              const bool hit = cnt - 1u < 254u;
+              // every lane loads (a lane that is not on a k-mer of the model: column 0 of its row, not used): a 32-bit
+              // byte offset from the table's base, so the address is one multiply-add away from the draw
+              const uint32_t c16 = hit ? (uint32_t)(m >> 32) << 4 : 0u;
+              const Rec16 rec = *reinterpret_cast<const Rec16*>(cols_bytes + (__umul24(win, stride16) + c16));
+              const float v12 = __uint_as_float((w2 >> 9) | 0x3F800000u);
+              const float x = __fadd_rn(__fmul_rn(__fsub_rn(v12, 1.0f), __uint_as_float(rec.w)), 0.0f);
+              const uint32_t alt = x < __uint_as_float(rec.x) ? rec.y : rec.z;
+              rare = rare | (cnt == 255u) | (hit & (((uint32_t)m > zn) | ((int32_t)alt < 0)));
+              win = hit ? (alt & kmask2) : win;
+              wpos += hit ? 2u : 0u;
+              const uint32_t code = win & 3u;
+              out[t >> 2] |= __builtin_amdgcn_perm(0u, 0x54474341u, code | 0x0c0c0c00u) << (8u * (t & 3u));
+              n_subst += code != (owin & 3u) ? 1u : 0u;
+              const uint32_t c2 = ((s16 >> (2u * t)) & 3u) << top2;
+              win = (win >> 2) | c2;
+              owin = (owin >> 2) | c2;
+            }
+            n_acgt += 16u;
+#if defined(SIMMR_TEST_SPLICE_REDO)
+            rare = rare || ((i0 >> 4) & 1u) != 0u;  // test build: every other group is taken back and walked again
+#endif
+            todo = rare;
+            if (rare) {
+              // the words of this group are generated again where they are needed (have = the block wpos lies in)
+              win = win_0; owin = owin_0; wpos = wpos_0; n_subst = subst_0; n_acgt -= 16u; have = wpos_0 >> 4;
+              out[0] = 0u; out[1] = 0u; out[2] = 0u; out[3] = 0u;
+            }
+          }
+        }
+        if (todo) {
 #pragma unroll
         for (uint32_t t = 0; t < 16u; t++) {
           const uint32_t i = i0 + t;
@@ -2847,6 +2906,7 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
               }
             }
           }
+        }
         }
         if (i0 < n) {
           const uint64_t lo = (uint64_t)out[0] | ((uint64_t)out[1] << 32), hi = (uint64_t)out[2] | ((uint64_t)out[3] << 32);
