@@ -24,7 +24,7 @@ struct ContigDev {
 };
 
 // One staged genome: 2-bit code plane + optional 1-bit exception plane.
-// Both planes have 16 bytes of addressable padding in front and 64 behind.
+// Both planes have 16 bytes of addressable padding in front and 96 behind.
 struct GenomeDev {
   const uint32_t* packed;
   const uint32_t* mask;  // nullptr when the genome is pure ACGT

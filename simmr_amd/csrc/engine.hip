@@ -56,7 +56,7 @@ struct GenomeHost {
 };
 
 constexpr size_t FRONT_PAD_WORDS = 4;  // 16 bytes in front of each plane
-constexpr size_t BACK_PAD_WORDS = 16;
+constexpr size_t BACK_PAD_WORDS = 24;  // the custom-long splice reads 17 words from the word of base (read end + k - 1)
 
 enum PlanKind { PLAN_NONE = 0, PLAN_PE = 1, PLAN_LONG = 2 };
 

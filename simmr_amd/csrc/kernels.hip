@@ -2767,10 +2767,34 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
       bool dead = false;  // after an error the lane only copies
       uint8_t* const sd = seq + off;
       const uint32_t top2 = 2u * (K - 1u), top1 = K - 1u;
+      // FAST: the source bases come 256 at a time (17 words, shifted to the lane's bit offset once): a lane's loads
+      // then touch every 64-byte line of its stretch about twice instead of sixteen times — the lines do not survive in
+      // L2 between two loads of a lane (75 GB fetched per 20 Gbases with one 8-byte load per group)
+      uint32_t sw[FAST ? 16 : 1];
       for (uint32_t i0 = 0; __any(i0 < n); i0 += 16u) {
         // the 16 source bases that enter the window during this group: positions i0 + K .. i0 + K + 15
-        // (at most K + 31 bases past the read: inside the plane's back padding)
-        const uint32_t s16 = i0 < n ? fetch_codes16(packed, (int64_t)(src0 + i0 + K)) : 0u;
+        // (at most K + 31 bases past the read, K + 271 with the 256-base chunks: inside the plane's back padding)
+        uint32_t s16;
+        if (FAST) {
+          if ((i0 & 255u) == 0u && i0 < n) {
+            const int64_t p = (int64_t)(src0 + i0 + K);
+            const __attribute__((address_space(1))) uint32_t* q = (const __attribute__((address_space(1))) uint32_t*)(packed + (p >> 4));
+            const uint32_t sh = 2u * (uint32_t)(p & 15);
+            uint32_t prev = q[0];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+              const uint32_t next = q[j + 1];
+              sw[j] = __builtin_amdgcn_alignbit(next, prev, sh);
+              prev = next;
+            }
+          }
+          const uint32_t g = (i0 >> 4) & 15u;  // the same for every lane: one indexed register read
+          s16 = sw[0];
+#pragma unroll
+          for (uint32_t j = 1; j < 16u; j++) s16 = g == j ? sw[FAST ? j : 0] : s16;
+        } else {
+          s16 = i0 < n ? fetch_codes16(packed, (int64_t)(src0 + i0 + K)) : 0u;
+        }
         const uint32_t x16 = (HAS_EXC && mask && i0 < n) ? fetch_mask16(mask, (int64_t)(src0 + i0 + K)) : 0u;
         uint32_t out[4] = {0u, 0u, 0u, 0u};  // 16 output bases
         bool todo = true;  // this group still has to be walked the general way
@@ -2791,7 +2815,14 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
               if ((t & 7u) == 0u) {
                 const bool need = have < (wpos >> 4) + 2u;  // then at least 17 words are ready: 8 steps take 16
                 if (__any(need)) {
-                  if (need) { refill_words(key, have, row + (have & 1u) * 16u * RS, RS); have++; }
+                  if (need) {  // (inline: a call here makes everything that lives across the group callee-saved)
+                    uint32_t o[16];
+                    chacha12_block(key, (uint64_t)have, o);
+                    lds_u32* const dst = row + (have & 1u) * 16u * RS;
+#pragma unroll
+                    for (uint32_t j = 0; j < 16u; j++) dst[j * RS] = o[j];
+                    have++;
+                  }
                 }
               }
               const uint32_t cnt = s_cnt8[win];
@@ -2829,8 +2860,7 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
           }
         }
         if (todo) {
-#pragma unroll
-        for (uint32_t t = 0; t < 16u; t++) {
+        auto general_step = [&](const uint32_t t) {
           const uint32_t i = i0 + t;
           if ((t & 7u) == 0u) {
             const bool need = i < n && have < (wpos >> 4) + 2u;
@@ -2890,7 +2920,11 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
               n_acgt++;
             }
             n_subst += differs ? 1u : 0u;
-            out[t >> 2] |= ch << (8u * (t & 3u));
+            {
+              const uint32_t chs = ch << (8u * (t & 3u));  // (t is the same for every lane)
+              if ((t >> 2) == 0u) out[0] |= chs; else if ((t >> 2) == 1u) out[1] |= chs;
+              else if ((t >> 2) == 2u) out[2] |= chs; else out[3] |= chs;
+            }
             win >>= 2; owin >>= 2;
             if (HAS_EXC) { nm >>= 1; dm >>= 1; oexc >>= 1; }
             if (i + K < n) {
@@ -2906,13 +2940,25 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
               }
             }
           }
+        };
+        if (FAST) {  // the cold path of the fast kernel: one copy of the step
+#pragma nounroll
+          for (uint32_t t = 0; t < 16u; t++) general_step(t);
+        } else {
+#pragma unroll
+          for (uint32_t t = 0; t < 16u; t++) general_step(t);
         }
         }
         if (i0 < n) {
           const uint64_t lo = (uint64_t)out[0] | ((uint64_t)out[1] << 32), hi = (uint64_t)out[2] | ((uint64_t)out[3] << 32);
           if (i0 + 16u <= n) {
+#if defined(SIMMR_SPLICE_NT)
+            __builtin_nontemporal_store(lo, reinterpret_cast<u64_unaligned*>(sd + i0));
+            __builtin_nontemporal_store(hi, reinterpret_cast<u64_unaligned*>(sd + i0 + 8u));
+#else
             *reinterpret_cast<u64_unaligned*>(sd + i0) = lo;
             *reinterpret_cast<u64_unaligned*>(sd + i0 + 8u) = hi;
+#endif
           } else {
             store_tail(sd + i0, lo, hi, n - i0);
           }
