@@ -67,7 +67,7 @@ def synthetic_short_model(n_positions=120, seed=3, mean_len=140, sd_len=12, mean
 
 
 def synthetic_long_model(kmer_size=7, n_positions=300, seed=5, n_kmers=3000, lengths=(1500, 6000, 100),
-                         with_n=True, deletion=False, read_length_mean=None, read_length_std=None):
+                         with_n=True, deletion=False, read_length_mean=None, read_length_std=None, max_alts=6):
     """A long-read model (is_long) with k-mer probabilities shaped like simmrd's: per observed k-mer a
     list of (alternate, weight) with the k-mer itself dominant and a few substituted variants.  Some keys
     contain an N (three_bit_encode_kmer accepts it), one key is listed twice (the HashMap keeps the last)."""
@@ -90,7 +90,7 @@ def synthetic_long_model(kmer_size=7, n_positions=300, seed=5, n_kmers=3000, len
         return c
     for idx in picks:
         key = code_of(int(idx))
-        n_alt = int(rng.integers(1, 7))
+        n_alt = int(rng.integers(1, max_alts + 1))  # simmrd keeps up to --max-alt-kmers (default 20) per k-mer
         alts = [(key, float(np.float32(rng.uniform(5, 50))))]
         for _ in range(n_alt - 1):
             pos = int(rng.integers(0, k))

@@ -427,6 +427,20 @@ def test_custom_long_bit_exact(engine, oracle, genome_multi, genome_1m, k, seed,
     assert c[_abi.CNT_QUAL_SUM] == ((d["qual"].astype(np.int64) - 33) % 256).sum()
 
 
+@pytest.mark.parametrize("k,max_alts", [(7, 21), (6, 32), (7, 40), (5, 255)])
+def test_custom_long_alternate_lists_of_simmrd_size(engine, oracle, genome_1m, k, max_alts):
+    """simmrd keeps up to --max-alt-kmers alternates per k-mer (default 20, a u8): lists of up to 32 go through the
+    fixed-stride column table of the fast splice kernel, longer ones through the two-load kernel."""
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    blob = _model.synthetic_long_model(kmer_size=k, n_positions=50, seed=17 + max_alts, n_kmers=4 ** k, max_alts=max_alts,
+                                       lengths=(900, 2500, 100))
+    pod = CustomShortErrorProfile(blob).pod()
+    dev = engine.simulate_long_reads([0], [150], pod, 77, read_id_base=0, qual_offset=33)
+    ora = _oracle.simulate_long(oracle, [genome_1m], [150], pod, 77, read_id_base=0, qual_offset=33)
+    assert_same(dev.to_host(), ora.trimmed(), cols=COLS)
+
+
 def test_custom_long_exceptions_and_sharding(engine, oracle):
     from simmr_amd import CustomShortErrorProfile
     from tests import _model
