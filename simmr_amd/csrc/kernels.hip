@@ -2640,16 +2640,57 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
         if (b0 >= n) continue;
         const uint32_t cnt = (n - b0) < 16u ? (n - b0) : 16u;
         uint64_t q_lo = 0, q_hi = 0;
-        {
-          for (uint32_t j = 0; j < 16; j++) {
-            const uint32_t p = b0 + j;
-            const PdfDev pdf = quality_pdf(C, s_pdfs, p);
-            if (j >= cnt) continue;
-            const uint32_t q = sample(pdf);
-            qsum += q;
-            const uint64_t enc = (q + qoff) & 0xffu;
-            if (j < 8u) q_lo |= enc << (8u * j); else q_hi |= enc << (8u * (j - 8u));
+        uint32_t redo = 0u;
+        // Every position draws from the same four words, so the sixteen samples of a group do not depend on one
+        // another: eight at a time, first all alias columns are loaded, then all bins (two round trips per eight
+        // samples instead of two per sample; the kernel was bound by that chain).  A sample that leaves the straight
+        // path (a rejected draw, a bad bin) is redone the general way.
+#pragma nounroll
+        for (uint32_t h = 0; h < 16u; h += 8u) {
+          Rec16 rec[8];
+          uint32_t colv[8], ok = 0u;
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; j++) {
+            const PdfDev pdf = quality_pdf(C, s_pdfs, b0 + h + j);
+            const uint64_t m = (uint64_t)w0 * pdf.n;
+            colv[j] = (uint32_t)(m >> 32);
+            const bool f = h + j < cnt && (uint32_t)m <= pdf.idx_zone;
+            ok |= (f ? 1u : 0u) << j;
+            rec[j] = C.col_rec[f ? pdf.off + colv[j] : 0u];
           }
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; j++) {
+            const PdfDev pdf = quality_pdf(C, s_pdfs, b0 + h + j);
+            const double odds = __longlong_as_double((long long)(((uint64_t)rec[j].y << 32) | rec[j].x));
+            const uint32_t bin = (__dmul_rn(v01, pdf.w_scale) < odds) ? colv[j] : rec[j].z;
+            const bool f = ((ok >> j) & 1u) != 0u && bin < pdf.n_bins;
+            ok &= ~((f ? 0u : 1u) << j);
+            rec[j] = C.bin_rec[f ? pdf.off_bins + bin : 0u];
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; j++) {
+            const Rec16 br = rec[j];
+            const uint64_t m2 = (uint64_t)w3 * br.x;
+            bool f = ((ok >> j) & 1u) != 0u;
+            uint32_t q = br.x == 0u ? w3 : br.z + (uint32_t)(m2 >> 32);
+            if (br.x != 0u && (uint32_t)m2 > br.y) f = false;
+            if (h + j < cnt) {
+              if (!f) { redo |= 1u << (h + j); q = 0u; }
+              q &= 0xffu;  // `as u8`
+              qsum += q;
+              const uint64_t enc = f ? (q + qoff) & 0xffu : 0u;
+              if (h == 0u) q_lo |= enc << (8u * j); else q_hi |= enc << (8u * j);
+            }
+          }
+        }
+#pragma nounroll
+        while (redo) {  // rare: one copy of the general sampler
+          const uint32_t j = (uint32_t)__builtin_ctz(redo);
+          redo &= redo - 1u;
+          const uint32_t q = sample(quality_pdf(C, s_pdfs, b0 + j));
+          qsum += q;
+          const uint64_t enc = (q + qoff) & 0xffu;
+          if (j < 8u) q_lo |= enc << (8u * j); else q_hi |= enc << (8u * (j - 8u));
         }
         uint8_t* qd = qual + off + b0;
         if (cnt == 16u) {
