@@ -2851,9 +2851,12 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
             const char* const cols_bytes = reinterpret_cast<const char*>(C.kmer_cols);
             const uint32_t stride16 = C.kmer_stride << 4;
             bool rare = false;
+#pragma nounroll
+            for (uint32_t t8 = 0; t8 < 16u; t8 += 8u) {
 #pragma unroll
-            for (uint32_t t = 0; t < 16u; t++) {
-              if ((t & 7u) == 0u) {
+            for (uint32_t tt = 0; tt < 8u; tt++) {
+              const uint32_t t = t8 + tt;
+              if (tt == 0u) {
                 const bool need = have < (wpos >> 4) + 2u;  // then at least 17 words are ready: 8 steps take 16
                 if (__any(need)) {
                   if (need) {  // (inline: a call here makes everything that lives across the group callee-saved)
@@ -2882,11 +2885,16 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
               win = hit ? (alt & kmask2) : win;
               wpos += hit ? 2u : 0u;
               const uint32_t code = win & 3u;
-              out[t >> 2] |= __builtin_amdgcn_perm(0u, 0x54474341u, code | 0x0c0c0c00u) << (8u * (t & 3u));
+              {
+                const uint32_t chs = __builtin_amdgcn_perm(0u, 0x54474341u, code | 0x0c0c0c00u) << (8u * (tt & 3u));
+                if (t8 == 0u) { if (tt < 4u) out[0] |= chs; else out[1] |= chs; }
+                else { if (tt < 4u) out[2] |= chs; else out[3] |= chs; }
+              }
               n_subst += code != (owin & 3u) ? 1u : 0u;
               const uint32_t c2 = ((s16 >> (2u * t)) & 3u) << top2;
               win = (win >> 2) | c2;
               owin = (owin >> 2) | c2;
+            }
             }
             n_acgt += 16u;
 #if defined(SIMMR_TEST_SPLICE_REDO)
