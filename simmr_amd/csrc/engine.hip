@@ -93,6 +93,10 @@ struct simmr_engine {
   DevBuf d_runs, d_usable;
   // custom profile tables
   DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, c_colrec, c_binrec, c_kslots, c_krecs, c_kdirect, c_kcnt8, c_kcols, ph_table;
+  // the custom model whose tables those buffers hold (make_custom_profile)
+  bool custom_cached = false, custom_long = false;
+  uint64_t custom_hash = 0, custom_bytes = 0;
+  ProfileDev custom_prof{};
   // FASTQ framing
   DevBuf fq_blob, fq_gid_off, fq_gid_len, fq_cbase, fq_ncontig, fq_coff, fq_clen, fq_len, fq_off;
   FqTemplate fq_tpl{};
@@ -250,8 +254,32 @@ template <class T> int upload_vec(simmr_engine* e, DevBuf& b, const std::vector<
   return SIMMR_OK;
 }
 
+// 64 bits over the model's bytes (FNV-1a on 8-byte words): the key of the table cache below
+uint64_t model_hash(const void* p, uint64_t n) {
+  const uint8_t* b = (const uint8_t*)p;
+  uint64_t h = 0xcbf29ce484222325ULL ^ n;
+  uint64_t i = 0;
+  for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x100000001b3ULL; h ^= h >> 29; }
+  for (; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ULL;
+  return h;
+}
+
 int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, ProfileDev* out) {
   if (!p->custom_model || p->custom_model_bytes == 0) return e->fail(SIMMR_EINVAL, "custom profile without a model");
+  // A job plans many shards with one model: parsing it, building the alias and k-mer tables and uploading them
+  // (4 ms for the benchmark's model) is done once per model, not once per plan.  The tables live in buffers only
+  // this function writes.
+  const uint64_t mh = model_hash(p->custom_model, p->custom_model_bytes);
+  if (e->custom_cached && e->custom_hash == mh && e->custom_bytes == p->custom_model_bytes && e->custom_long == want_long) {
+    ProfileDev d = e->custom_prof;
+    if (want_long) {
+      if (p->long_start_mode > SIMMR_START_UNIFORM) return e->fail(SIMMR_EINVAL, "unknown long_start_mode %u", p->long_start_mode);
+      d.long_start_uniform = p->long_start_mode == SIMMR_START_UNIFORM ? 1u : 0u;
+    }
+    *out = d;
+    return SIMMR_OK;
+  }
+  e->custom_cached = false;
   ModelHost m;
   std::string err;
   if (!parse_model((const uint8_t*)p->custom_model, p->custom_model_bytes, &m, &err)) return e->fail(SIMMR_EINVAL, "%s", err.c_str());
@@ -326,6 +354,11 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
     d.custom.kmer_cnt8 = kt.stride ? e->c_kcnt8.as<uint8_t>() : nullptr;
     d.custom.kmer_cols = kt.stride ? e->c_kcols.as<Rec16>() : nullptr;
   }
+  e->custom_prof = d;
+  e->custom_hash = mh;
+  e->custom_bytes = p->custom_model_bytes;
+  e->custom_long = want_long;
+  e->custom_cached = true;
   *out = d;
   return SIMMR_OK;
 }
