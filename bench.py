@@ -247,6 +247,11 @@ def main():
                 # mfma, and this path has no matrix work); what actually limits the kernel is in `limiter`
                 "bound": "hbm",
                 "limiter": ("hbm write path" if args.profile == "perfect-short" else
+                            "per-lane table reads (address unit)" if args.profile == "custom-short" else
+                            "latency of the dependent table load per visited k-mer at 4 waves per SIMD, and ChaCha12 issue"
+                            if custom is not None else
+                            "VALU issue (ChaCha12 and the per-base state machines of the reference's streams)"
+                            if args.rng == "reference" else
                             "VALU issue (integer RNG and table lookups) next to the HBM write path: see `valu`"),
                 "kernel": ("k_emit_perfect_pe" if args.profile == "perfect-short" else
                            "k_emit_custom_pe" if args.profile == "custom-short" else
@@ -260,6 +265,8 @@ def main():
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": emit_avg_ms,
                 "note": ("HBM-write bound data movement" if args.profile == "perfect-short" else
+                         "see DESIGN.md section 4 (kernel table)" if (custom is not None or args.profile == "custom-short"
+                                                                     or args.rng == "reference") else
                          "see DESIGN.md section 4 and profiles/r2: differential timing (make ablate) puts the stores at "
                          "a third of the kernel and the instruction stream at two thirds"),
             },
@@ -284,6 +291,8 @@ def _profile_record(args, reads_per_gpu):
         t = json.load(open(ROOT / "profiles" / "r2" / "pmc_traffic.json"))
     except OSError:
         return None
+    if args.profile == "custom-long" and reads_per_gpu == 1_000_000 and args.genome_bases == 100_000_000:
+        return t.get("k_custom_long_splice")
     if reads_per_gpu != 100_000_000 or args.genome_bases != 100_000_000:
         return None
     if args.profile == "minimal-short" and args.rng == "philox":
@@ -299,7 +308,7 @@ def measured_traffic(args, reads_per_gpu):
     the raw figure is reported and the doubled one is in the file).  Not measured by this run: a constant from the
     committed profile, null for any other workload."""
     t = _profile_record(args, reads_per_gpu)
-    return None if t is None else t["bytes_raw"]
+    return None if t is None else t.get("bytes_raw")
 
 
 def measured_valu(args, reads_per_gpu, kernel_ms):
