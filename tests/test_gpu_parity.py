@@ -441,6 +441,25 @@ def test_custom_long_alternate_lists_of_simmrd_size(engine, oracle, genome_1m, k
     assert_same(dev.to_host(), ora.trimmed(), cols=COLS)
 
 
+def test_custom_model_tables_follow_the_model(engine, genome_1m):
+    """The engine keeps the tables of the last custom model (parsed, built and uploaded once per model): another model
+    must replace them, the first one must come back exactly, and the same bytes on the other path must still be refused."""
+    from simmr_amd import CustomShortErrorProfile, SimmrError
+    from tests import _model
+    pa = CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=6, n_positions=40, seed=101, n_kmers=4 ** 6, lengths=(600, 1500, 100)))
+    pb = CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=6, n_positions=40, seed=102, n_kmers=4 ** 6, lengths=(600, 1500, 100)))
+    a, b = pa.pod(), pb.pod()  # (the PODs point into the profiles' model bytes)
+    run = lambda pod: engine.simulate_long_reads([0], [64], pod, 5, read_id_base=0, qual_offset=33).to_host()
+    ra, rb, ra2, rb2 = run(a), run(b), run(a), run(b)
+    for col in ("seq", "qual", "seq_off", "start", "end"):
+        assert np.array_equal(ra[col], ra2[col]) and np.array_equal(rb[col], rb2[col]), col
+    assert not (ra["seq"].shape == rb["seq"].shape and np.array_equal(ra["qual"], rb["qual"]))
+    with pytest.raises(SimmrError) as ei:  # a long-read model on the paired-end path (main.rs:30-33), cached or not
+        engine.simulate_pe_reads_from_genome(0, a, 100, 1)
+    assert ei.value.code == _abi.EINVAL
+    assert np.array_equal(run(a)["seq"], ra["seq"])
+
+
 def test_custom_long_exceptions_and_sharding(engine, oracle):
     from simmr_amd import CustomShortErrorProfile
     from tests import _model
