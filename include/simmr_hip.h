@@ -281,7 +281,9 @@ int simmr_pe_emit(simmr_engine* e, uint32_t read_id_base, const simmr_reads_out*
  * SIMMR_LEN_PER_READ every read draws its own length from that Normal law.
  * A custom model needs kmer_size <= 10 (else SIMMR_ENOTSUP); an alternate
  * k-mer that deletes bases makes the reference panic and simmr_long_emit
- * return SIMMR_ERANGE. */
+ * return SIMMR_ERANGE.  custom_model is read during the plan call only; the
+ * engine keeps the device tables of the last model it was given (keyed by the
+ * model's bytes), so planning many shards with one model builds them once. */
 int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_idx,
                     const uint64_t* genome_reads, const simmr_error_profile* profile, int has_seed,
                     uint64_t seed, simmr_range shard, simmr_plan_info* info);
@@ -341,8 +343,11 @@ uint64_t simmr_entropy_substitute(uint64_t x, uint32_t which);
  * (device memory, >= total bytes).  `reads` must carry every column.
  *
  * SIMMR_ENOTSUP (nothing written; use the host writer): a genome or sequence id
- * containing '{' or '}' (the chained replace could then re-expand it), more than
- * 24 template pieces, or a header longer than 255 bytes. */
+ * containing '{' or '}' (the chained replace could then re-expand it), a template
+ * whose own text has a '{' somewhere before and a '}' somewhere after a
+ * {:genome_id:} or {:sequence_id:} field (the inserted id could complete a
+ * placeholder with them), more than 24 template pieces, or a header longer than
+ * 255 bytes.  SIMMR_EINVAL: a genome_idx entry that is not a staged slot. */
 typedef struct simmr_fastq_names {
   uint32_t n_genomes;
   const uint32_t* genome_idx;      /* engine genome slot of each entry */
