@@ -1871,7 +1871,11 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
         for (int j = 0; j < 8; j++) {
           if (s.i < L) q_step<PL>(s, ((uint64_t)w[2 * j + 1] << 32) | w[2 * j], zx2, zf2f, T, prof, ring, qual_offset);
         }
-        ring_flush_fwd(ring, s.i);
+        // Sectors are flushed by the whole wave at the same blocks (every 8th: 64 slots, about one sector per lane),
+        // not by each lane at the block in which its own sector fills: flushing every block ran the flush code with
+        // an eighth of the lanes.  A lane holds < 64 unflushed bytes after a flush and adds <= 64 until the next: the
+        // 128-byte ring never wraps onto them.  A finished lane flushes its last, partial sector at once.
+        if ((blk & 7u) == 7u || s.i >= L) ring_flush_fwd(ring, s.i);
       }
       qsum_tot += s.qsum;
     }
@@ -1895,7 +1899,9 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
 #pragma unroll
         for (int j = 0; j < 16; j++)
           if (s.i < L) m_step<HAS_EXC>(s, w[j], L, rev, packed, mask, src, thr, qsrc, qual_offset, ring);
-        if (rev) ring_flush_rev(ring, L - s.i); else ring_flush_fwd(ring, s.i);
+        if ((blk & 3u) == 3u || s.i >= L) {  // every 4th block: 64 words, about one sector per lane (as above)
+          if (rev) ring_flush_rev(ring, L - s.i); else ring_flush_fwd(ring, s.i);
+        }
       }
       subst_tot += s.n_subst;
       acgt_tot += HAS_EXC ? s.n_acgt : L;
