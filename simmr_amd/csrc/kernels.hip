@@ -1772,43 +1772,41 @@ SIMMR_DEV void m_step(LaneM& s, uint32_t w, uint32_t L, uint32_t rev, const uint
                       const uint32_t* __restrict__ mask, uint64_t src,
                       const uint32_t* __restrict__ thr, const uint8_t* __restrict__ qsrc, uint32_t qoff,
                       const OutRing& ring) {
-  if (s.st == 0) {
-    const uint32_t i = s.i;
-    // registers are refilled one chunk ahead so the loads overlap the steps
-    if ((i & 15u) == 0) {
-      s.qreg = s.qnext; s.qreg2 = s.qnext2;
-      load_q16(qsrc, i + 16, L, s.qnext, s.qnext2);
-      s.creg = s.cnext;
-      s.cnext = fetch_codes16(packed, (int64_t)(src + i + 16));
-      if (HAS_EXC) { s.ereg = s.enext; s.enext = mask ? fetch_mask16(mask, (int64_t)(src + i + 16)) : 0u; }
-    }
-    // byte (i & 7) of qreg, zero-extended, in one v_perm_b32
-    const uint64_t qh = (i & 8u) ? s.qreg2 : s.qreg;
-    const uint32_t q = (__builtin_amdgcn_perm((uint32_t)(qh >> 32), (uint32_t)qh, (i & 7u) | 0x0c0c0c00u) - qoff) & 0xffu;
-    uint32_t code = (s.creg >> (2 * (i & 15u))) & 3u;
-    uint32_t exc = 0;
-    if (HAS_EXC) {
-      exc = (s.ereg >> (i & 15u)) & 1u;
-      if (exc) code = 4u + (code & 1u);
-      s.n_acgt += exc ? 0u : 1u;
-    }
-    // gen::<f32>() > accuracy(q)  <=>  (w >> 8) > floor(acc * 2^24)
-    if ((w >> 8) > thr[q] && !exc) {
-      s.st = 1;
-    } else {
-      m_emit<HAS_EXC>(s, code, ring);
-    }
-  } else {
-    // choose(&[3 alternatives]) = gen_range(0..3u32), zone 0xBFFFFFFF
-    const uint64_t m = (uint64_t)w * 3u;
-    if ((uint32_t)m <= 0xBFFFFFFFu) {
-      const uint32_t k = (uint32_t)(m >> 32);
-      const uint32_t c = (s.creg >> (2 * (s.i & 15u))) & 3u;
-      s.st = 0;
-      s.n_subst++;
-      m_emit<HAS_EXC>(s, k + (k >= c ? 1u : 0u), ring);
-    }
+  // One word, read both ways by every lane — as the f32 test of base i (state 0) and as a draw of choose() for the
+  // base that is waiting (state 1) — and the state picks: some lane of a wave is in state 1 in two steps of three, so
+  // the two readings as separate branches cost more than both of them straight.
+  const uint32_t i = s.i;
+  const bool choosing = s.st != 0u;
+  // registers are refilled one chunk ahead so the loads overlap the steps
+  if (!choosing && (i & 15u) == 0) {
+    s.qreg = s.qnext; s.qreg2 = s.qnext2;
+    load_q16(qsrc, i + 16, L, s.qnext, s.qnext2);
+    s.creg = s.cnext;
+    s.cnext = fetch_codes16(packed, (int64_t)(src + i + 16));
+    if (HAS_EXC) { s.ereg = s.enext; s.enext = mask ? fetch_mask16(mask, (int64_t)(src + i + 16)) : 0u; }
   }
+  // byte (i & 7) of qreg, zero-extended, in one v_perm_b32
+  const uint64_t qh = (i & 8u) ? s.qreg2 : s.qreg;
+  const uint32_t q = (__builtin_amdgcn_perm((uint32_t)(qh >> 32), (uint32_t)qh, (i & 7u) | 0x0c0c0c00u) - qoff) & 0xffu;
+  const uint32_t c = (s.creg >> (2 * (i & 15u))) & 3u;
+  uint32_t code = c;
+  uint32_t exc = 0;
+  if (HAS_EXC) {
+    exc = (s.ereg >> (i & 15u)) & 1u;
+    if (exc) code = 4u + (c & 1u);
+    s.n_acgt += (exc || choosing) ? 0u : 1u;
+  }
+  // state 0: gen::<f32>() > accuracy(q)  <=>  (w >> 8) > floor(acc * 2^24)
+  const bool mutate = (w >> 8) > thr[q] && !exc;
+  // state 1: choose(&[3 alternatives]) = gen_range(0..3u32), zone 0xBFFFFFFF
+  const uint64_t m = (uint64_t)w * 3u;
+  const bool drawn = (uint32_t)m <= 0xBFFFFFFFu;
+  const uint32_t k = (uint32_t)(m >> 32);
+  const uint32_t alt = k + (k >= c ? 1u : 0u);
+  const bool emit = choosing ? drawn : !mutate;
+  s.n_subst += (choosing && drawn) ? 1u : 0u;
+  s.st = choosing ? (drawn ? 0u : 1u) : (mutate ? 1u : 0u);
+  if (emit) m_emit<HAS_EXC>(s, choosing ? alt : code, ring);
 }
 
 #define LANES_WG 512
