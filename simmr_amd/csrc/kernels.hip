@@ -2224,6 +2224,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     const uint32_t ex = wg_exclusive_scan_u32<true>(g, lds4, &n_items, threadIdx.x);
     if (threadIdx.x < nr) recs[threadIdx.x].gs = ex;
     r_gs[threadIdx.x] = threadIdx.x < nr ? ex : 0xffffffffu;
+    if (threadIdx.x == 0) r_gs[PHILOX_READS] = 0xffffffffu;
     // short reads: every read writes its index over its items, so an item finds its read with one LDS load
     const bool use_map = n_items <= PHILOX_MAP_ITEMS;
     if (use_map && threadIdx.x < nr)
@@ -2234,10 +2235,17 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #else
     const uint32_t i_end = n_items;
 #endif
+    // long reads (64 items and more each on average): a lane's items ascend 256 apart, so its read moves on by one
+    // now and then — one look at the next read's first item instead of the eight dependent ones of the search
+    const bool walk = !use_map && n_items >= nr * 64u;
+    uint32_t r_walk = 0;
     for (uint32_t item = threadIdx.x; item < i_end; item += 256) {
       uint32_t r = 0;  // read of this item: last r with r_gs[r] <= item
       if (use_map) {
         r = owner[item];
+      } else if (walk) {
+        while (r_gs[r_walk + 1u] <= item) r_walk++;  // (r_gs[nr ..] = ~0)
+        r = r_walk;
       } else {
 #pragma unroll
         for (uint32_t step = PHILOX_READS / 2; step; step >>= 1)
