@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "kernels.hip"
+#include "emit_tile.hip"
 #include "fastq_kernels.hip"
 #include "custom_model.hpp"
 
@@ -87,6 +88,14 @@ struct simmr_engine {
   DevBuf scan_tmp, u_order, len_hist;
   bool plan_sorted = false;
   int emit_variant = 0;  // 0 = lane-per-read kernel for short reads, 1 = wave-per-unit kernel
+  // measurement knobs, read ONCE when the engine is made (a stray variable cannot change a running engine's launches)
+  int philox_form = 1;          // SIMMR_PHILOX_FORM: 1 = the item kernel (default), 2 = the tile kernel where it applies (emit_tile.hip; measured slower: profiles/r3/tile_form_*)
+  uint32_t philox_wgs_per_cu = 8;  // SIMMR_PHILOX_WGS_PER_CU (item kernel), clamped to 1..64
+  uint32_t tile_upb = 32;       // SIMMR_TILE_UPB: pairs per block of the tile kernel (1..32)
+  uint32_t tile_cap = 0;        // SIMMR_TILE_CAP: bytes per LDS tile (0 = from the profile's read length)
+  uint32_t tile_wgs_per_cu = 0; // SIMMR_TILE_WGS_PER_CU: 0 = what fits
+  int splice_variant = 0;       // SIMMR_SPLICE_VARIANT: 1 = the two-load splice kernel on every model
+  bool plan_tile_ok = false;    // the current paired plan has no read longer than TILE_MAXL
   // outer-stream scratch
   DevBuf o_last_idx, o_wg_sums, o_wg_prefix, o_result;
   // long-read runs
@@ -733,6 +742,12 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
   e->device = device_ordinal;
   e->n_cu = prop.multiProcessorCount;
   if (const char* v = getenv("SIMMR_EMIT_VARIANT")) e->emit_variant = atoi(v);
+  if (const char* v = getenv("SIMMR_PHILOX_FORM")) e->philox_form = atoi(v);
+  if (const char* v = getenv("SIMMR_PHILOX_WGS_PER_CU")) e->philox_wgs_per_cu = (uint32_t)std::min<unsigned long long>(64, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
+  if (const char* v = getenv("SIMMR_TILE_UPB")) e->tile_upb = (uint32_t)std::min<unsigned long long>(32, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
+  if (const char* v = getenv("SIMMR_TILE_CAP")) e->tile_cap = (uint32_t)std::min<unsigned long long>(16384, strtoull(v, nullptr, 10)) & ~15u;
+  if (const char* v = getenv("SIMMR_TILE_WGS_PER_CU")) e->tile_wgs_per_cu = (uint32_t)std::min<unsigned long long>(16, strtoull(v, nullptr, 10));
+  if (const char* v = getenv("SIMMR_SPLICE_VARIANT")) e->splice_variant = atoi(v);
   bool ok = e->d_tables.ensure(sizeof(Tables)) && e->d_counters.ensure(8 * SIMMR_N_COUNTERS) &&
             e->d_err.ensure(64) && e->d_scalars.ensure(256);
   ok = ok && hipEventCreate(&e->ev_a) == hipSuccess && hipEventCreate(&e->ev_b) == hipSuccess &&
@@ -1160,6 +1175,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   if (errw & SIMMR_ERRBIT_PDF)
     return e->fail(SIMMR_ERANGE, "a custom PDF selected a density without a bin range (the reference panics: index out of bounds)");
   (void)hipEventElapsedTime(&e->last_plan_ms, e->ev_a, e->ev_b);
+  e->plan_tile_ok = !(errw & SIMMR_NOTEBIT_LONGREAD);
   e->plan_kind = PLAN_PE;
   e->prof = prof;
   e->plan_genome = genome_idx;
@@ -1269,6 +1285,7 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
   if (errw & SIMMR_ERRBIT_SLICE)
     return e->fail(SIMMR_ERANGE, "a read would extend past its sequence (the reference panics on this slice)");
   (void)hipEventElapsedTime(&e->last_plan_ms, e->ev_a, e->ev_b);
+  e->plan_tile_ok = !(errw & SIMMR_NOTEBIT_LONGREAD);
   e->plan_kind = PLAN_PE;
   e->prof = prof;
   e->plan_genome = genome_idx[0];
@@ -1317,22 +1334,51 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->u_contig.as<uint32_t>(), out->seq,
                          out->qual, 60u + out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
     } else if (e->prof.rng_mode == SIMMR_RNG_PHILOX) {
-      const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
-      uint64_t per_cu = 8;
-      if (const char* s = getenv("SIMMR_PHILOX_WGS_PER_CU")) per_cu = std::max<uint64_t>(1, strtoull(s, nullptr, 10));  // measurement knob
-      const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * per_cu);
       bool exc = false;
       if (paired) exc = e->plan_any_exc;
       else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
       // pairs of one genome with few contigs: the contig bases live in LDS (no dependent load per record)
       const bool cached = paired && !e->plan_multi && e->plan_genome < e->genomes.size() &&
                           e->genomes[e->plan_genome].contigs.size() <= PHILOX_CBASE;
-      auto kern = cached ? (exc ? k_emit_philox<true, false, true> : k_emit_philox<false, false, true>)
-                         : (exc ? k_emit_philox<true, false, false> : k_emit_philox<false, false, false>);
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
-                         e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
-                         e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
-                         out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
+      if (paired && e->plan_tile_ok && e->philox_form == 2) {
+        // tile form (emit_tile.hip): the block's piece of both streams is built in LDS and flushed in whole lines
+        const uint32_t upb = e->tile_upb;  // (1..32: one lane of the prologue wave per read)
+        // tile capacity: the block's expected bytes plus slack (a block that does not fit stores directly)
+        uint32_t cap = e->tile_cap ? e->tile_cap : ((2 * upb * (e->prof.read_length + 12u) + 15u) & ~15u);
+        cap = std::min<uint32_t>(std::max<uint32_t>(cap, 256u), 16384u);
+        const uint32_t lds = 2 * (cap + 32u);
+        auto kern = cached ? (exc ? k_emit_philox_tile<true, true> : k_emit_philox_tile<false, true>)
+                           : (exc ? k_emit_philox_tile<true, false> : k_emit_philox_tile<false, false>);
+        int per_cu = (int)e->tile_wgs_per_cu;
+        if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1)) per_cu = 1;
+        const uint64_t blocks = (n_units + upb - 1) / upb;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * (uint64_t)per_cu);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), e->plan_genome,
+                           n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(),
+                           out->seq, out->qual, out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters, upb, cap);
+#if defined(TILE_DIAG)
+        {  // diagnostic build: cycles per phase, summed over waves (s_memtime runs at 100 MHz on gfx9: 10 ns units)
+          unsigned long long d[16];
+          (void)hipStreamSynchronize(e->stream);
+          (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(tile_diag), sizeof d);
+          const char* nm[6] = {"prologue", "items", "wait_A", "flush", "owner", "wait_B"};
+          fprintf(stderr, "tile_diag grid=%u per_cu=%d lds=%u:", grid, per_cu, lds);
+          for (int c = 0; c < 2; c++) { fprintf(stderr, " [%s n=%llu]", c ? "wave3" : "waves0-2", d[8 * c + 6]); for (int k = 0; k < 6; k++) fprintf(stderr, " %s=%.1f", nm[k], (double)d[8 * c + k] / (double)std::max(1ull, d[8 * c + 6])); }
+          fprintf(stderr, "\n");
+          unsigned long long z[16] = {0};
+          (void)hipMemcpyToSymbol(HIP_SYMBOL(tile_diag), z, sizeof z);
+        }
+#endif
+      } else {
+        const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * e->philox_wgs_per_cu);
+        auto kern = cached ? (exc ? k_emit_philox<true, false, true> : k_emit_philox<false, false, true>)
+                           : (exc ? k_emit_philox<true, false, false> : k_emit_philox<false, false, false>);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
+                           e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
+                           e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
+                           out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
+      }
     } else if (e->prof.kind == SIMMR_K_CUSTOM && !paired) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
       bool exc = false;
@@ -1344,7 +1390,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->u_off.as<uint64_t>(), e->u_seed.as<uint64_t>(), out->qual, out->qual_offset, counters,
                          e->d_err.as<uint32_t>());
       bool fast = e->prof.custom.kmer_stride != 0;
-      if (const char* s = getenv("SIMMR_SPLICE_VARIANT")) fast = fast && atoi(s) != 1;  // 1: the two-load kernel (A/B timing)
+      if (e->splice_variant == 1) fast = false;  // the two-load kernel (A/B timing)
       if (fast) {
         // one workgroup of 1024 lanes per CU around the LDS count table (kernels.hip section 9c)
         auto kern = exc ? k_custom_long_splice<true, true> : k_custom_long_splice<false, true>;

@@ -611,6 +611,7 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
   // Rust would panic on an out-of-range slice; never silently read out of bounds.
   const uint64_t len = G.contigs[u_contig[k]].len;
   if (fs + L > len || re + L > len) { atomicOr(err, SIMMR_ERRBIT_SLICE); L = 0; }
+  if (L > TILE_MAXL) atomicOr(err, SIMMR_NOTEBIT_LONGREAD);
   pl.len[k] = (uint32_t)L;
   pl.a[k] = fs;
   pl.b[k] = re;
