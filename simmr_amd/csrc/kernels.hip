@@ -2092,7 +2092,7 @@ SIMMR_DEV void philox_repair(const uint32_t k0, const uint32_t k1, const uint32_
 // CACHED: every pair comes from one genome (u_genome == null) with at most PHILOX_CBASE contigs, whose bases sit in
 // LDS: a record then needs no load that depends on another load's result.
 template <bool HAS_EXC, bool COPY_ONLY, bool CACHED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
               const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
@@ -2110,12 +2110,6 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ uint4 nmask[17];    // byte masks of the first n bytes of 16
   __shared__ uint32_t nmask2[17]; // the low 2n bits
   __shared__ uint32_t lds4[4];
-#if !defined(SIMMR_ABLATE_ROWDMA)
-  // the NEXT block's plan rows, one dword column each, fetched with global_load_lds_dword (memory -> LDS, no registers)
-  // while this block's items are drawn: lane l of wave w writes word 64 w + l
-  __shared__ uint32_t rw[10 * PHILOX_READS];  // columns: len, contig, flags word, genome, off lo / hi, pos lo / hi, key lo / hi
-  __shared__ uint32_t blk_out0[2];
-#endif
   const uint32_t qoff = qual_offset & 0xffu;
   {
     const uint32_t t = threadIdx.x;
@@ -2157,96 +2151,26 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   const bool q_nowrap = qoff + prof.philox_qmax <= 255u;  // then no encoded quality wraps
   const uint32_t rpu = paired ? 2u : 1u;
   const uint64_t n_blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
-#if !defined(SIMMR_ABLATE_ROWDMA)
-  typedef const __attribute__((address_space(1))) void* row_gptr;
-  typedef __attribute__((address_space(3))) void* row_lptr;
-  // one read per lane: the nine (ten) dwords of its plan row, asynchronously into the LDS columns
-  auto fetch_rows = [&](const uint64_t b) {
-    const uint64_t f0 = b * PHILOX_UNITS;
-    const uint32_t fnu = (n_units - f0) < PHILOX_UNITS ? (uint32_t)(n_units - f0) : PHILOX_UNITS;
-    uint32_t t = threadIdx.x;
-    asm volatile("" : "+v"(t));  // (opaque: the per-lane addresses are not to live across the item loop)
-    const uint32_t w64 = __builtin_amdgcn_readfirstlane(t & ~63u);
-    if (t < fnu * rpu) {
-      const uint64_t u = f0 + (paired ? (t >> 1) : t);
-      const uint32_t rev = paired ? (t & 1u) : 0u;
-      auto dma = [&](const void* g, uint32_t* col) { __builtin_amdgcn_global_load_lds((row_gptr)g, (row_lptr)(col + w64), 4, 0, 0); };
-      dma(pl.len + u, rw);
-      dma(u_contig + u, rw + PHILOX_READS);
-      dma(reinterpret_cast<const uint32_t*>(pl.flags) + (u >> 2), rw + 2 * PHILOX_READS);  // the aligned word that holds the unit's flag byte
-      dma((!CACHED && u_genome) ? u_genome + u : u_contig + u, rw + 3 * PHILOX_READS);
-      // forward mates fetch where the pair's bytes start, reverse mates where the next pair's do (u_off has n_units + 1 entries)
-      const uint32_t* po = reinterpret_cast<const uint32_t*>(u_off + u + rev);
-      dma(po, rw + 4 * PHILOX_READS); dma(po + 1, rw + 5 * PHILOX_READS);
-      const uint32_t* pp = reinterpret_cast<const uint32_t*>(rev ? pl.b + u : pl.a + u);
-      dma(pp, rw + 6 * PHILOX_READS); dma(pp + 1, rw + 7 * PHILOX_READS);
-      const uint32_t* pk = reinterpret_cast<const uint32_t*>(rev ? pl.qs2 + u : u_seed + u);
-      dma(pk, rw + 8 * PHILOX_READS); dma(pk + 1, rw + 9 * PHILOX_READS);
-    }
-    asm volatile("" ::: "memory");
-  };
-  bool rows_waited = false;  // (wave-uniform) false: nothing this wave did since it issued the rows proves they have landed
-  if (blockIdx.x < n_blocks) fetch_rows(blockIdx.x);
-#endif
   for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     const uint64_t u0 = blk * PHILOX_UNITS;
     const uint32_t nu = (n_units - u0) < PHILOX_UNITS ? (uint32_t)(n_units - u0) : PHILOX_UNITS;
     const uint32_t nr = nu * rpu;
-#if defined(SIMMR_ABLATE_ROWDMA)
     const uint64_t out0 = u_off[u0];  // the block's first output byte (same for every lane: a scalar load)
     uint8_t* const seq_blk = seq + out0;
     uint8_t* const qual_blk = qual + out0;
-#endif
     lds_barrier();  // the previous block's items are done with the records
-#if !defined(SIMMR_ABLATE_ROWDMA)
-    // Loads return in order: a wave that has consumed an item's plane word since it issued the rows has them.  Any
-    // other wave waits here (the first block; a wave without items in the previous block).
-    if (!rows_waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     uint32_t g = 0;
-    uint32_t dst_lo = 0;
     if (threadIdx.x < nr) {
       const uint32_t t = threadIdx.x;
       const uint64_t u = u0 + (paired ? (t >> 1) : t);
       const uint32_t rev = paired ? (t & 1u) : 0u;
-#if defined(SIMMR_ABLATE_ROWDMA)
       const uint32_t L = pl.len[u];
+      g = (L + 15u) >> 4;
       const uint32_t contig = u_contig[u];
       const uint32_t genome = (!CACHED && u_genome) ? u_genome[u] : genome_const;
       const uint64_t dst = u_off[u] + (rev ? L : 0u);
       const uint64_t pos = rev ? pl.b[u] : pl.a[u];  // first source base of this read on the contig
       const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
-      const uint32_t fl = pl.flags[u];
-      const uint64_t closing = u_off[n_units];
-      const uint64_t long_end = paired ? 0 : pl.b[u];
-#else
-      // The ten words of this read's row.  Read with ds_read_b32 in an asm statement: the compiler orders an LDS read it
-      // can see behind every outstanding global_load_lds with s_waitcnt vmcnt(0), which would also wait for the
-      // acknowledgements of the item loop's stores (one in-order counter) — the rows are known to be there (above).
-      uint32_t w0, w1, w2, w3, w4, w5, w6, w7, w8, w9;
-      {
-        const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)(rw + t);
-        asm volatile("ds_read_b32 %0, %10\n\tds_read_b32 %1, %10 offset:1024\n\tds_read_b32 %2, %10 offset:2048\n\t"
-                     "ds_read_b32 %3, %10 offset:3072\n\tds_read_b32 %4, %10 offset:4096\n\tds_read_b32 %5, %10 offset:5120\n\t"
-                     "ds_read_b32 %6, %10 offset:6144\n\tds_read_b32 %7, %10 offset:7168\n\tds_read_b32 %8, %10 offset:8192\n\t"
-                     "ds_read_b32 %9, %10 offset:9216\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4), "=&v"(w5), "=&v"(w6), "=&v"(w7), "=&v"(w8), "=&v"(w9)
-                     : "v"(a) : "memory");
-      }
-      static_assert(PHILOX_READS == 256u, "the offsets above are 4 * PHILOX_READS apart");
-      const uint32_t L = w0;
-      const uint32_t contig = w1;
-      const uint32_t genome = (!CACHED && u_genome) ? w3 : genome_const;
-      const uint64_t off = (uint64_t)w4 | ((uint64_t)w5 << 32);
-      const uint64_t dst = rev ? off - L : off;
-      const uint64_t pos = (uint64_t)w6 | ((uint64_t)w7 << 32);
-      const uint64_t key = (uint64_t)w8 | ((uint64_t)w9 << 32);
-      const uint32_t fl = (w2 >> (8u * ((uint32_t)u & 3u))) & 0xffu;
-      const uint64_t closing = dst + L;    // (only used by the shard's last read)
-      const uint64_t long_end = pos + L;   // simulate.rs:516: end - start = the slice's length
-      if (t == 0) { blk_out0[0] = (uint32_t)dst; blk_out0[1] = (uint32_t)(dst >> 32); }
-#endif
-      g = (L + 15u) >> 4;
       uint64_t cb;
       const uint32_t* packed;
       const uint32_t* mk = nullptr;
@@ -2263,12 +2187,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint64_t src = cb + pos;
       PhRec rc;
       rc.k0 = (uint32_t)key; rc.k1 = (uint32_t)(key >> 32);
-#if defined(SIMMR_ABLATE_ROWDMA)
       rc.dst = (uint32_t)(dst - out0);
-#else
-      rc.dst = 0;  // (set after the barrier below, when the block's first byte is known to every wave)
-      dst_lo = (uint32_t)dst;
-#endif
       rc.lw = (L & 0xffffu) | ((2u * (uint32_t)(src & 15u)) << 16) | (rev << 31);
       rc.wa = (uint64_t)(uintptr_t)(packed + (src >> 4));
       rc.gs = 0; rc.pad = 0;
@@ -2281,14 +2200,15 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #endif
         // metadata columns of this read (the other emit kernels leave them to k_write_meta)
         const uint64_t rd = paired ? 2 * u + rev : u;
+        const uint32_t fl = pl.flags[u];
         o.seq_off[rd] = dst;
-        if (rd + 1 == n_reads) o.seq_off[n_reads] = closing;  // closing CSR offset
+        if (rd + 1 == n_reads) o.seq_off[n_reads] = u_off[n_units];  // closing CSR offset
         if (paired) {
           if (o.start) o.start[rd] = rev ? pos + L : pos;  // simulate.rs:289,295
           if (o.end) o.end[rd] = rev ? pos : pos + L;      // simulate.rs:290,296
         } else {
           if (o.start) o.start[rd] = pos;                  // simulate.rs:515
-          if (o.end) o.end[rd] = long_end;                 // simulate.rs:516
+          if (o.end) o.end[rd] = pl.b[u];                  // simulate.rs:516
         }
         if (o.contig) o.contig[rd] = contig;
         if (o.genome) o.genome[rd] = genome;
@@ -2303,12 +2223,6 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     }
     uint32_t n_items;
     const uint32_t ex = wg_exclusive_scan_u32<true>(g, lds4, &n_items, threadIdx.x);
-#if !defined(SIMMR_ABLATE_ROWDMA)
-    const uint64_t out0 = (uint64_t)blk_out0[0] | ((uint64_t)blk_out0[1] << 32);  // the block's first output byte
-    uint8_t* const seq_blk = seq + out0;
-    uint8_t* const qual_blk = qual + out0;
-    if (threadIdx.x < nr) recs[threadIdx.x].dst = dst_lo - (uint32_t)out0;
-#endif
     if (threadIdx.x < nr) recs[threadIdx.x].gs = ex;
     r_gs[threadIdx.x] = threadIdx.x < nr ? ex : 0xffffffffu;
     if (threadIdx.x == 0) r_gs[PHILOX_READS] = 0xffffffffu;
@@ -2326,11 +2240,6 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     // now and then — one look at the next read's first item instead of the eight dependent ones of the search
     const bool walk = !use_map && n_items >= nr * 64u;
     uint32_t r_walk = 0;
-#if !defined(SIMMR_ABLATE_ROWDMA)
-    // the next block's rows: issued in front of this block's first plane load, so that load's wait covers them
-    if (blk + gridDim.x < n_blocks) fetch_rows(blk + gridDim.x);
-    rows_waited = (threadIdx.x & ~63u) < i_end;  // (uniform in a wave) its first lane has an item, i.e. a plane load to wait for
-#endif
     for (uint32_t item = threadIdx.x; item < i_end; item += 256) {
       uint32_t r = 0;  // read of this item: last r with r_gs[r] <= item
       if (use_map) {
