@@ -47,7 +47,10 @@ def main():
     ap.add_argument("--rng", default="philox", choices=["reference", "philox"],
                     help="philox: Philox4x32-10 counter mode for the per-base draws (north_star's design, tolerance "
                          "parity); reference: the reference's own ChaCha12 streams (bit-exact, slower)")
-    ap.add_argument("--no-other-mode", action="store_true", help="skip the untimed side measurement of the other rng mode")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the untimed side measurements (the other rng mode, the FASTQ text)")
+    ap.add_argument("--through-fastq", action="store_true",
+                    help="one step = plan + FASTQ sizing + emit straight into FASTQ text resident in HBM (simmr_fastq_plan_direct / "
+                         "simmr_emit_fastq: what the reference's run produces, main.rs:180-206), instead of the SoA columns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -130,6 +133,32 @@ def main():
     # sizes are a deterministic function of (seed, shard): plan once to allocate
     info = plan()
     out = Reads.allocate(info.n_reads, info.total_bases, eng.device, qual_offset=33)
+    # the reference's default read header (cli.rs:193-200) and ids for the synthetic genome
+    FQ_FMT = ("@{:read_id:}|{:genome_id:}/{:pair:} metadata:sid={:sequence_id:}|sp={:start_position:}"
+              "|ep={:end_position:}|rc={:reverse_complement:}")
+    FQ_NAMES = [(0, "0f8fad5b-d9cb-469f-a165-70867728950e", ["synth_%d" % args.genome_bases])]
+    fq = {"text": None, "bytes": 0, "plan_ms": [], "emit_ms": []}
+
+    def step_fastq(record):
+        eng.counters_reset()
+        plan()
+        total = eng.fastq_plan_direct(FQ_FMT, FQ_NAMES, 0)
+        if fq["text"] is None or fq["text"].numel() < total:
+            fq["text"] = torch.empty(total, dtype=torch.uint8, device=eng.device)
+        fq["bytes"] = total
+        eng.emit_fastq(fq["text"])
+        eng.counters_to(counters_dev)
+        if world > 1:
+            if args.backend == "nccl":
+                dist.all_reduce(counters_dev)
+            else:
+                c = counters_dev.cpu()
+                dist.all_reduce(c)
+                counters_dev.copy_(c)
+        if record:
+            emit_ms.append(eng.last_emit_kernel_ms())
+            plan_ms.append(eng.last_plan_ms())
+            fq["plan_ms"].append(eng.last_fastq_plan_ms())
 
     emit_ms, plan_ms = [], []
 
@@ -158,12 +187,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    the_step = step_fastq if args.through_fastq else step
+    if args.through_fastq:
+        step(False)  # (untimed) the columns once, for the read lengths behind `alg_bytes_per_launch`
     for _ in range(args.warmup):
-        step(False)
+        the_step(False)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        the_step(True)
     fence()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if args.backend == "nccl" else "cpu")
@@ -191,6 +223,23 @@ def main():
             "steps": 1, "note": "one step after one warm-up step, same shard, outside the timed region",
         }
         prof.rng_mode = keep_mode
+        counters_dev.copy_(keep_c)
+
+    # untimed side measurement: the same step through FASTQ text (N = 1, the default command only)
+    through = None
+    if world == 1 and not args.no_other_mode and not args.through_fastq and not long_mode and custom is None:
+        keep_c = counters_dev.clone()
+        step_fastq(False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step_fastq(False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        through = {"what": "plan + FASTQ sizing + emit into FASTQ text (simmr_fastq_plan_direct / simmr_emit_fastq), text resident in HBM",
+                   "value": info.n_reads / dt, "unit": "reads/s", "ms_per_step": dt * 1e3, "text_bytes": fq["bytes"],
+                   "emit_kernel_ms": eng.last_emit_kernel_ms(), "plan_ms": eng.last_plan_ms(), "fastq_plan_ms": eng.last_fastq_plan_ms(),
+                   "steps": 1, "note": "one step after one warm-up step, same shard, outside the timed region"}
+        fq["text"] = None
         counters_dev.copy_(keep_c)
 
     counters = counters_dev.cpu().numpy().astype(np.uint64)
@@ -276,6 +325,12 @@ def main():
             result["roofline"]["valu"] = valu
         if other is not None:
             result["other_rng_mode"] = other
+        if through is not None:
+            result["through_fastq"] = through
+        if args.through_fastq:
+            result["config"]["output"] = "FASTQ text in HBM (header format of cli.rs:193-200), no SoA columns"
+            result["fastq"] = {"text_bytes": fq["bytes"], "fastq_plan_ms_per_step": sum(fq["plan_ms"]) / max(len(fq["plan_ms"]), 1),
+                               "text_GBps": fq["bytes"] * args.steps / elapsed / 1e9}
         if world == 1 and not args.no_cpu_baseline and not long_mode:
             result["cpu_baseline"] = cpu_baseline(args, prof)
         print(json.dumps(result), flush=True)
@@ -284,46 +339,74 @@ def main():
         dist.destroy_process_group()
 
 
+PMC_RECORD = ROOT / "profiles" / "r3" / "pmc_traffic.json"
+KERNEL_SOURCES = ("simmr_amd/csrc/kernels.hip", "simmr_amd/csrc/rng_device.hpp", "simmr_amd/csrc/device_types.hpp")
+
+
+def kernel_source_hash():
+    """sha256 over the sources that define the emit kernels: the committed PMC record carries the hash of the sources it
+    was collected from (tools/make_pmc_traffic.py), and is only reported while they are unchanged."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update((ROOT / rel).read_bytes())
+    return h.hexdigest()
+
+
 def _profile_record(args, reads_per_gpu):
-    """The committed rocprofv3 PMC record of this very command (profiles/r2/pmc_traffic.json: one counter set per
-    run, no tracing); only for the workload it was measured on."""
+    """(record, why_not): the committed rocprofv3 PMC record of this very command (profiles/r3/pmc_traffic.json: one
+    counter set per run, no tracing) — only for the workload it was measured on and only if the kernel sources still
+    hash to what they were when it was collected."""
     try:
-        t = json.load(open(ROOT / "profiles" / "r2" / "pmc_traffic.json"))
+        t = json.load(open(PMC_RECORD))
     except OSError:
-        return None
+        return None, f"no {PMC_RECORD.relative_to(ROOT)}"
+    if t.get("source_sha256") != kernel_source_hash():
+        return None, (f"{PMC_RECORD.relative_to(ROOT)} was collected from other kernel sources "
+                      f"(sha256 {str(t.get('source_sha256'))[:12]}.. != {kernel_source_hash()[:12]}..): collect it again")
+    if args.through_fastq:
+        return None, "not collected for --through-fastq"
     if args.profile == "custom-long" and reads_per_gpu == 1_000_000 and args.genome_bases == 100_000_000:
-        return t.get("k_custom_long_splice")
+        return t.get("k_custom_long_splice"), None
     if reads_per_gpu != 100_000_000 or args.genome_bases != 100_000_000:
-        return None
+        return None, "collected at 100 M reads on 100 Mbp only"
     if args.profile == "minimal-short" and args.rng == "philox":
-        return t.get("k_emit_philox")
+        return t.get("k_emit_philox"), None
     if args.profile == "perfect-short":
-        return t.get("k_emit_perfect_pe")
-    return None
+        return t.get("k_emit_perfect_pe"), None
+    return None, "not collected for this profile"
 
 
 def measured_traffic(args, reads_per_gpu):
     """HBM bytes per launch of the dominant kernel: FETCH_SIZE + WRITE_SIZE of separate --pmc passes, raw (the guide's
     x2 correction of FETCH_SIZE applies to wide coalesced reads; this kernel reads 8-byte gathers and plan columns, so
     the raw figure is reported and the doubled one is in the file).  Not measured by this run: a constant from the
-    committed profile, null for any other workload."""
-    t = _profile_record(args, reads_per_gpu)
+    committed profile, null for any other workload or when the kernel sources have changed since."""
+    t, _ = _profile_record(args, reads_per_gpu)
     return None if t is None else t.get("bytes_raw")
 
 
 def measured_valu(args, reads_per_gpu, kernel_ms):
-    """VALU wave-instructions per launch (SQ_INSTS_VALU of the committed PMC pass) against the measured issue peak of
-    plain 32-bit integer VALU instructions (profiles/microbench/valu_asm_rates2_mi355x.txt: v_add_u32 8.4e11
-    wave-instructions/s on the whole chip; v_perm / v_alignbit / SDWA forms issue at 0.66 of that, v_mad_u64_u32 at
-    0.47): the time the instruction stream alone needs, as a share of the kernel's time."""
-    t = _profile_record(args, reads_per_gpu)
+    """VALU wave-instructions per launch (SQ_INSTS_VALU of the committed PMC pass) priced by instruction class with the
+    measured issue rates (profiles/microbench/valu_asm_rates*_mi355x.txt: plain 32-bit forms 8.4e11 wave-instructions/s
+    on the whole chip, the VOP3 / SDWA / DPP class 1.5 x slower, v_mad_u64_u32 2.1 x): the time the instruction stream
+    alone needs, as a share of the kernel's time."""
+    t, why = _profile_record(args, reads_per_gpu)
     if t is None or "SQ_INSTS_VALU" not in t or kernel_ms <= 0:
-        return None
+        return {"note": why} if why else None
     peak = 8.443e11
     need_ms = t["SQ_INSTS_VALU"] / peak * 1e3
-    return {"wave_instructions_per_launch": t["SQ_INSTS_VALU"], "issue_peak_per_s": peak, "unit": "wave-instructions",
-            "min_time_ms_at_peak": need_ms, "frac_of_kernel_time": need_ms / kernel_ms,
-            "source": "profiles/r2/pmc_traffic.json (committed PMC pass of this command), not measured by this run"}
+    out = {"wave_instructions_per_launch": t["SQ_INSTS_VALU"], "issue_peak_per_s": peak, "unit": "wave-instructions",
+           "min_time_ms_at_peak": need_ms, "frac_of_kernel_time": need_ms / kernel_ms,
+           "source": f"{PMC_RECORD.relative_to(ROOT)} (committed PMC pass of this command, kernel sources unchanged since), "
+                     "not measured by this run"}
+    mix = t.get("valu_class_mix")  # shares of the instruction stream by issue class, from the disassembly
+    if mix:
+        cost = mix.get("plain", 0.0) * 1.0 + mix.get("vop3_sdwa", 0.0) * 1.5 + mix.get("mad_u64", 0.0) * 2.1
+        out["class_priced_min_time_ms"] = need_ms * cost
+        out["class_priced_frac_of_kernel_time"] = need_ms * cost / kernel_ms
+        out["class_mix"] = mix
+    return out
 
 
 def usable_cores():

@@ -360,6 +360,23 @@ int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fas
                      const simmr_reads_out* reads, uint64_t n_reads, int paired, uint64_t* total_bytes);
 int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst, uint64_t dst_capacity);
 
+/* The same text without the columns in between: what main.rs:180-206 does as a whole — simulate, then
+ * fastq::write_to_fastq (fastq.rs:14-124) — for the shard of the CURRENT plan (simmr_pe_plan / simmr_pe_plan_at /
+ * simmr_pe_plan_multi / simmr_long_plan).  A header's length depends on plan columns only (decimal widths of read id,
+ * start and end; the lengths of the ids), so
+ *   simmr_fastq_plan_direct sizes every record from the plan and returns the total, and
+ *   simmr_emit_fastq writes the shard's records back to back into dst (device memory, >= total bytes): the emit kernel
+ *     stores bases and qualities (offset 33, util.rs:46-57) at their places in the text, a second kernel the headers
+ *     and line ends.  The run counters advance as simmr_*_emit advances them.
+ * The bytes are those of simmr_*_emit (qual_offset 33) + simmr_fastq_plan + simmr_fastq_emit with the same arguments,
+ * and the same cases are refused with SIMMR_ENOTSUP.  Profiles whose emit kernel cannot write into text (perfect-short,
+ * SIMMR_RNG_REFERENCE, custom models) are served through columns held by the engine: same result, no saving. */
+int simmr_fastq_plan_direct(simmr_engine* e, const char* header_format, const simmr_fastq_names* names,
+                            uint32_t read_id_base, uint64_t* total_bytes);
+int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity);
+/* HIP-event time (ms) of the last simmr_fastq_plan_direct's device work (size pass + scan). */
+int simmr_last_fastq_plan_ms(simmr_engine* e, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

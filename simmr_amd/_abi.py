@@ -148,6 +148,9 @@ SYMBOLS = {
     "simmr_fastq_plan": (C.c_int, [C.c_void_p, C.c_char_p, _P(FastqNames), _P(ReadsOut), C.c_uint64, C.c_int,
                                    _P(C.c_uint64)]),
     "simmr_fastq_emit": (C.c_int, [C.c_void_p, _P(ReadsOut), C.c_void_p, C.c_uint64]),
+    "simmr_fastq_plan_direct": (C.c_int, [C.c_void_p, C.c_char_p, _P(FastqNames), C.c_uint32, _P(C.c_uint64)]),
+    "simmr_emit_fastq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "simmr_last_fastq_plan_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
 }
 
 _lib = None

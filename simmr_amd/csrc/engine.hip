@@ -73,7 +73,7 @@ struct simmr_engine {
   DevBuf d_genomes;  // GenomeDev[genomes.size()]
   DevBuf d_tables, d_counters, d_err, d_scalars;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
-  float last_emit_ms = 0.f, last_plan_ms = 0.f;
+  float last_emit_ms = 0.f, last_plan_ms = 0.f, last_fastq_plan_ms = 0.f;
 
   // current plan
   int plan_kind = PLAN_NONE;
@@ -105,6 +105,7 @@ struct simmr_engine {
   // the custom model whose tables those buffers hold (make_custom_profile)
   bool custom_cached = false, custom_long = false;
   uint64_t custom_hash = 0, custom_bytes = 0;
+  std::vector<uint8_t> custom_model_copy;  // the bytes those tables were built from (a hash match is confirmed with memcmp)
   ProfileDev custom_prof{};
   // FASTQ framing
   DevBuf fq_blob, fq_gid_off, fq_gid_len, fq_cbase, fq_ncontig, fq_coff, fq_clen, fq_len, fq_off;
@@ -112,6 +113,11 @@ struct simmr_engine {
   uint64_t fq_reads = 0, fq_total = 0;
   uint32_t fq_slots = 0, fq_lit_bytes = 0, fq_hpitch = 272;
   bool fq_paired = false, fq_ready = false;
+  bool fq_direct = false;          // planned by simmr_fastq_plan_direct (sizes from the plan, for simmr_emit_fastq)
+  uint32_t fq_read_id_base = 0, fq_maxhdr = 0;
+  DevBuf fq_hlen;                  // header bytes per read (direct form)
+  DevBuf fq_tpl_dev;               // the compiled header template, read by the kernels through a pointer
+  DevBuf fd_seq, fd_qual, fd_seq_off, fd_start, fd_end, fd_contig, fd_genome, fd_read_id, fd_flags;  // columns of the unfused fallback
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -279,7 +285,9 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
   // (4 ms for the benchmark's model) is done once per model, not once per plan.  The tables live in buffers only
   // this function writes.
   const uint64_t mh = model_hash(p->custom_model, p->custom_model_bytes);
-  if (e->custom_cached && e->custom_hash == mh && e->custom_bytes == p->custom_model_bytes && e->custom_long == want_long) {
+  if (e->custom_cached && e->custom_hash == mh && e->custom_bytes == p->custom_model_bytes && e->custom_long == want_long &&
+      e->custom_model_copy.size() == p->custom_model_bytes &&
+      memcmp(e->custom_model_copy.data(), p->custom_model, p->custom_model_bytes) == 0) {
     ProfileDev d = e->custom_prof;
     if (want_long) {
       if (p->long_start_mode > SIMMR_START_UNIFORM) return e->fail(SIMMR_EINVAL, "unknown long_start_mode %u", p->long_start_mode);
@@ -367,6 +375,7 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
   e->custom_hash = mh;
   e->custom_bytes = p->custom_model_bytes;
   e->custom_long = want_long;
+  e->custom_model_copy.assign((const uint8_t*)p->custom_model, (const uint8_t*)p->custom_model + p->custom_model_bytes);
   e->custom_cached = true;
   *out = d;
   return SIMMR_OK;
@@ -1120,6 +1129,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
                         simmr_plan_info* info) {
   if (!e) return SIMMR_EINVAL;
   e->plan_kind = PLAN_NONE;
+  e->fq_direct = false;  // (a direct FASTQ plan belongs to the plan it was made for)
   HIP_TRY(e, hipSetDevice(e->device));
   int rc = check_genome(e, genome_idx);
   if (rc) return rc;
@@ -1203,6 +1213,7 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
                         simmr_plan_info* info) {
   if (!e) return SIMMR_EINVAL;
   e->plan_kind = PLAN_NONE;
+  e->fq_direct = false;  // (a direct FASTQ plan belongs to the plan it was made for)
   if (n_genomes == 0 || !genome_idx || !genome_reads) return e->fail(SIMMR_EINVAL, "simmr_pe_plan_multi: no genomes");
   HIP_TRY(e, hipSetDevice(e->device));
   int rc;
@@ -1377,7 +1388,8 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
                            e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                            e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
-                           out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
+                           out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters,
+                           (const uint64_t*)nullptr, (const uint8_t*)nullptr);
       }
     } else if (e->prof.kind == SIMMR_K_CUSTOM && !paired) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
@@ -1421,7 +1433,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       hipLaunchKernelGGL(copy, dim3(cgrid), dim3(256), 0, e->stream, e->prof, 1u, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
                          (const uint32_t*)nullptr, e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset,
-                         e->plan_first, read_id_base, out_cols(out), counters);
+                         e->plan_first, read_id_base, out_cols(out), counters, (const uint64_t*)nullptr, (const uint8_t*)nullptr);
     } else if (e->emit_variant == 0) {
       // lane-per-read kernel: template on (exception plane present, paired, perfect-long Phred)
       bool exc = false;
@@ -1486,6 +1498,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
                     uint64_t seed, simmr_range shard, simmr_plan_info* info) {
   if (!e) return SIMMR_EINVAL;
   e->plan_kind = PLAN_NONE;
+  e->fq_direct = false;  // (a direct FASTQ plan belongs to the plan it was made for)
   HIP_TRY(e, hipSetDevice(e->device));
   if (!genome_idx || !genome_reads || n_genomes == 0) return e->fail(SIMMR_EINVAL, "no genomes");
   int rc;
@@ -1685,15 +1698,9 @@ bool compile_header_format(const char* fmt, std::vector<uint8_t>* blob, FqTempla
 bool has_brace(const char* s) { return strchr(s, '{') || strchr(s, '}'); }
 }  // namespace
 
-int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fastq_names* names,
-                     const simmr_reads_out* reads, uint64_t n_reads, int paired, uint64_t* total_bytes) {
-  if (!e) return SIMMR_EINVAL;
-  e->fq_ready = false;
-  if (!header_format || !names || !reads || !total_bytes) return e->fail(SIMMR_EINVAL, "simmr_fastq_plan: NULL argument");
-  if (!reads->seq_off || !reads->start || !reads->end || !reads->contig || !reads->genome || !reads->read_id ||
-      !reads->flags || (n_reads > 0 && (!reads->seq || !reads->qual)))
-    return e->fail(SIMMR_EINVAL, "simmr_fastq_plan needs every column of simmr_reads_out");
-  HIP_TRY(e, hipSetDevice(e->device));
+// the header template and the id tables of simmr_fastq_plan / simmr_fastq_plan_direct, compiled and uploaded
+static int fq_prepare(simmr_engine* e, const char* header_format, const simmr_fastq_names* names, uint32_t* lit_bytes_out,
+                      uint32_t* n_slots_out) {
   std::vector<uint8_t> blob;
   bool risky = false;
   if (!compile_header_format(header_format, &blob, &e->fq_tpl, &risky))
@@ -1740,15 +1747,49 @@ int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fas
       (rc = upload_vec(e, e->fq_ncontig, ncontig)) || (rc = upload_vec(e, e->fq_coff, coff)) ||
       (rc = upload_vec(e, e->fq_clen, clen)))
     return rc;
+  if (!e->fq_tpl_dev.ensure(sizeof(FqTemplate))) return e->fail(SIMMR_ENOMEM, "template allocation failed");
+  HIP_TRY(e, hipMemcpyAsync(e->fq_tpl_dev.p, &e->fq_tpl, sizeof(FqTemplate), hipMemcpyHostToDevice, e->stream));
+  if ((rc = sync_check(e, "fastq table upload"))) return rc;  // the host vectors go out of scope
+  *lit_bytes_out = lit_bytes;
+  *n_slots_out = n_slots;
+  return SIMMR_OK;
+}
+
+// bytes between the LDS header slots of neighbouring lanes: an ODD number of words, so that the 64 lanes of a wave,
+// each writing byte k of its own header, hit 64 different banks (a multiple of 16 bytes made every byte store a
+// 4-way bank conflict: SQ_LDS_BANK_CONFLICT was 70 % of the LDS-busy cycles of the header kernel)
+static uint32_t fq_slot_pitch(uint32_t bytes) {
+  uint32_t p = (bytes + 3u) & ~3u;
+  if (((p >> 2) & 1u) == 0) p += 4u;
+  return p;
+}
+
+static FqTables fq_tables(const simmr_engine* e, uint32_t n_slots) {
+  return FqTables{e->fq_blob.as<uint8_t>(), e->fq_gid_off.as<uint32_t>(), e->fq_gid_len.as<uint32_t>(),
+                  e->fq_cbase.as<uint32_t>(), e->fq_ncontig.as<uint32_t>(), e->fq_coff.as<uint32_t>(),
+                  e->fq_clen.as<uint32_t>(), n_slots};
+}
+
+int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fastq_names* names,
+                     const simmr_reads_out* reads, uint64_t n_reads, int paired, uint64_t* total_bytes) {
+  if (!e) return SIMMR_EINVAL;
+  e->fq_ready = false;
+  e->fq_direct = false;
+  if (!header_format || !names || !reads || !total_bytes) return e->fail(SIMMR_EINVAL, "simmr_fastq_plan: NULL argument");
+  if (!reads->seq_off || !reads->start || !reads->end || !reads->contig || !reads->genome || !reads->read_id ||
+      !reads->flags || (n_reads > 0 && (!reads->seq || !reads->qual)))
+    return e->fail(SIMMR_EINVAL, "simmr_fastq_plan needs every column of simmr_reads_out");
+  HIP_TRY(e, hipSetDevice(e->device));
+  uint32_t lit_bytes = 0, n_slots = 0;
+  int rc;
+  if ((rc = fq_prepare(e, header_format, names, &lit_bytes, &n_slots))) return rc;
   if (!e->fq_len.ensure(std::max<uint64_t>(n_reads, 1) * 8)) return e->fail(SIMMR_ENOMEM, "record length allocation failed");
   HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
-  const FqTables tb{e->fq_blob.as<uint8_t>(), e->fq_gid_off.as<uint32_t>(), e->fq_gid_len.as<uint32_t>(),
-                    e->fq_cbase.as<uint32_t>(), e->fq_ncontig.as<uint32_t>(), e->fq_coff.as<uint32_t>(),
-                    e->fq_clen.as<uint32_t>(), n_slots};
+  const FqTables tb = fq_tables(e, n_slots);
   const FqReads rd{reads->seq, reads->qual, reads->seq_off, reads->start, reads->end, reads->contig, reads->genome,
                    reads->read_id, reads->flags};
   if (n_reads > 0)
-    hipLaunchKernelGGL(k_fastq_size, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, e->fq_tpl, tb, rd, n_reads,
+    hipLaunchKernelGGL(k_fastq_size, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, rd, n_reads,
                        e->fq_len.as<uint64_t>(), e->d_err.as<uint32_t>());
   uint64_t total = 0;
   if ((rc = scan_u64(e, e->fq_len, n_reads, e->fq_off, &total))) return rc;  // also waits for the uploads
@@ -1757,7 +1798,7 @@ int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fas
   if ((rc = sync_check(e, "fastq size readback"))) return rc;
   if (errw2[0] & SIMMR_ERRBIT_FASTQ)
     return e->fail(SIMMR_ENOTSUP, "a FASTQ header is longer than %u bytes, or a read names a genome / contig without an id", FQ_HMAX - 1);
-  e->fq_hpitch = (errw2[1] + 1u + 8u + 15u) & ~15u;  // header, '\n', slack of the 8-byte id copies and 16-byte window reads
+  e->fq_hpitch = fq_slot_pitch(errw2[1] + 1u + 8u + 16u);  // header, '\n', slack of the 8-byte id copies and 16-byte window reads
   e->fq_reads = n_reads;
   e->fq_total = total;
   e->fq_slots = n_slots;
@@ -1770,7 +1811,7 @@ int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fas
 
 int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst, uint64_t dst_capacity) {
   if (!e) return SIMMR_EINVAL;
-  if (!e->fq_ready) return e->fail(SIMMR_ESTATE, "simmr_fastq_emit called without simmr_fastq_plan");
+  if (!e->fq_ready || e->fq_direct) return e->fail(SIMMR_ESTATE, "simmr_fastq_emit called without simmr_fastq_plan");
   if (!reads) return e->fail(SIMMR_EINVAL, "reads is NULL");
   if (dst_capacity < e->fq_total)
     return e->fail(SIMMR_ERANGE, "dst_capacity %llu < %llu bytes planned", (unsigned long long)dst_capacity,
@@ -1778,10 +1819,7 @@ int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst
   if (e->fq_reads == 0) return SIMMR_OK;
   if (!dst) return e->fail(SIMMR_EINVAL, "dst is NULL");
   HIP_TRY(e, hipSetDevice(e->device));
-  const uint32_t n_slots = e->fq_slots;
-  const FqTables tb{e->fq_blob.as<uint8_t>(), e->fq_gid_off.as<uint32_t>(), e->fq_gid_len.as<uint32_t>(),
-                    e->fq_cbase.as<uint32_t>(), e->fq_ncontig.as<uint32_t>(), e->fq_coff.as<uint32_t>(),
-                    e->fq_clen.as<uint32_t>(), n_slots};
+  const FqTables tb = fq_tables(e, e->fq_slots);
   const FqReads rd{reads->seq, reads->qual, reads->seq_off, reads->start, reads->end, reads->contig, reads->genome,
                    reads->read_id, reads->flags};
   const uint64_t n_batches = (e->fq_reads + FQ_BATCH - 1) / FQ_BATCH;
@@ -1790,9 +1828,148 @@ int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst
   if (hdr_lds > 48 * 1024)
     HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fastq_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_lds));
   HIP_TRY(e, hipEventRecord(e->ev_c, e->stream));
-  hipLaunchKernelGGL(k_fastq_write, dim3(grid), dim3(256), hdr_lds, e->stream, e->fq_tpl, tb, rd,
+  hipLaunchKernelGGL(k_fastq_write, dim3(grid), dim3(256), hdr_lds, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, rd,
                      e->fq_reads, e->fq_paired ? 1u : 0u, e->fq_lit_bytes, e->fq_hpitch, e->fq_off.as<uint64_t>(), dst);
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
+  hipError_t s = hipGetLastError();
+  if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "fastq launch failed: %s", hipGetErrorString(s));
+  return SIMMR_OK;
+}
+
+// ---- FASTQ text straight from the plan (include/simmr_hip.h) --------------------------------------------------
+static FqPlan fq_plan_view(simmr_engine* e) {
+  const bool paired = e->plan_paired;
+  const bool seeds2 = paired && e->prof.kind != SIMMR_K_PERFECT_SHORT;
+  FqPlan pn;
+  pn.pl = plan_arrays(e, seeds2);
+  pn.u_contig = e->u_contig.as<uint32_t>();
+  pn.u_genome = (paired && !e->plan_multi) ? nullptr : e->u_genome.as<uint32_t>();
+  pn.first_unit = e->plan_first;
+  pn.read_id_base = e->fq_read_id_base;
+  pn.genome_const = e->plan_genome;
+  pn.paired = paired ? 1u : 0u;
+  return pn;
+}
+
+int simmr_fastq_plan_direct(simmr_engine* e, const char* header_format, const simmr_fastq_names* names,
+                            uint32_t read_id_base, uint64_t* total_bytes) {
+  if (!e) return SIMMR_EINVAL;
+  e->fq_ready = false;
+  e->fq_direct = false;
+  if (!header_format || !names || !total_bytes) return e->fail(SIMMR_EINVAL, "simmr_fastq_plan_direct: NULL argument");
+  if (e->plan_kind == PLAN_NONE) return e->fail(SIMMR_ESTATE, "simmr_fastq_plan_direct called without a plan");
+  HIP_TRY(e, hipSetDevice(e->device));
+  uint32_t lit_bytes = 0, n_slots = 0;
+  int rc;
+  if ((rc = fq_prepare(e, header_format, names, &lit_bytes, &n_slots))) return rc;
+  const uint64_t n_reads = e->plan_paired ? 2 * e->plan_units : e->plan_units;
+  if (!e->fq_len.ensure(std::max<uint64_t>(n_reads, 1) * 8) || !e->fq_hlen.ensure(std::max<uint64_t>(n_reads, 1)))
+    return e->fail(SIMMR_ENOMEM, "record length allocation failed");
+  HIP_TRY(e, hipEventRecord(e->ev_a, e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
+  e->fq_read_id_base = read_id_base;
+  const FqTables tb = fq_tables(e, n_slots);
+  if (n_reads > 0)
+    hipLaunchKernelGGL(k_fastq_size_plan, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, fq_plan_view(e),
+                       n_reads, e->fq_len.as<uint64_t>(), e->fq_hlen.as<uint8_t>(), e->d_err.as<uint32_t>());
+  uint64_t total = 0;
+  if ((rc = scan_u64(e, e->fq_len, n_reads, e->fq_off, &total))) return rc;
+  HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
+  uint32_t errw2[2] = {0, 0};  // error bits, longest header
+  HIP_TRY(e, hipMemcpyAsync(errw2, e->d_err.p, 8, hipMemcpyDeviceToHost, e->stream));
+  if ((rc = sync_check(e, "fastq size readback"))) return rc;
+  if (errw2[0] & SIMMR_ERRBIT_FASTQ)
+    return e->fail(SIMMR_ENOTSUP, "a FASTQ header is longer than %u bytes, or a read names a genome / contig without an id", FQ_HMAX - 1);
+  (void)hipEventElapsedTime(&e->last_fastq_plan_ms, e->ev_a, e->ev_b);
+  e->fq_hpitch = fq_slot_pitch(errw2[1] + 2u + 8u + 16u);  // the previous record's '\n', header, '\n', slack of the 8-byte id copies
+  e->fq_maxhdr = errw2[1];
+  e->fq_reads = n_reads;
+  e->fq_total = total;
+  e->fq_slots = n_slots;
+  e->fq_lit_bytes = lit_bytes;
+  e->fq_paired = e->plan_paired;
+  e->fq_ready = true;
+  e->fq_direct = true;
+  *total_bytes = total;
+  return SIMMR_OK;
+}
+
+int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
+  if (!e) return SIMMR_EINVAL;
+  if (!e->fq_ready || !e->fq_direct || e->plan_kind == PLAN_NONE)
+    return e->fail(SIMMR_ESTATE, "simmr_emit_fastq called without simmr_fastq_plan_direct on the current plan");
+  if (dst_capacity < e->fq_total)
+    return e->fail(SIMMR_ERANGE, "dst_capacity %llu < %llu bytes planned", (unsigned long long)dst_capacity,
+                   (unsigned long long)e->fq_total);
+  const uint64_t n_units = e->plan_units, n_reads = e->fq_reads;
+  if (n_reads == 0) return SIMMR_OK;
+  if (!dst) return e->fail(SIMMR_EINVAL, "dst is NULL");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const bool paired = e->plan_paired;
+  const bool direct_kernel = e->prof.kind != SIMMR_K_CUSTOM && e->prof.kind != SIMMR_K_PERFECT_SHORT && e->prof.rng_mode == SIMMR_RNG_PHILOX;
+  const FqTables tb = fq_tables(e, e->fq_slots);
+  if (!direct_kernel) {
+    // No emit kernel of this profile writes into text: the columns are built in buffers of the engine and framed from
+    // there (the same kernels as simmr_*_emit + simmr_fastq_emit; qualities with the FASTQ offset, util.rs:46-57).
+    const uint64_t tb_bytes = std::max<uint64_t>(e->plan_total_bases, 1), nr = std::max<uint64_t>(n_reads, 1);
+    if (!e->fd_seq.ensure(tb_bytes) || !e->fd_qual.ensure(tb_bytes) || !e->fd_seq_off.ensure((nr + 1) * 8) || !e->fd_start.ensure(nr * 8) ||
+        !e->fd_end.ensure(nr * 8) || !e->fd_contig.ensure(nr * 4) || !e->fd_genome.ensure(nr * 4) || !e->fd_read_id.ensure(nr * 4) ||
+        !e->fd_flags.ensure(nr))
+      return e->fail(SIMMR_ENOMEM, "column allocation failed (%llu bases, %llu reads)", (unsigned long long)tb_bytes, (unsigned long long)nr);
+    simmr_reads_out cols{};
+    cols.seq = e->fd_seq.as<uint8_t>(); cols.qual = e->fd_qual.as<uint8_t>(); cols.seq_off = e->fd_seq_off.as<uint64_t>();
+    cols.start = e->fd_start.as<uint64_t>(); cols.end = e->fd_end.as<uint64_t>(); cols.contig = e->fd_contig.as<uint32_t>();
+    cols.genome = e->fd_genome.as<uint32_t>(); cols.read_id = e->fd_read_id.as<uint32_t>(); cols.flags = e->fd_flags.as<uint8_t>();
+    cols.seq_capacity = tb_bytes; cols.reads_capacity = nr; cols.qual_offset = 33;
+    int rc = emit_common(e, e->fq_read_id_base, &cols);
+    if (rc) return rc;
+    const FqReads rd{cols.seq, cols.qual, cols.seq_off, cols.start, cols.end, cols.contig, cols.genome, cols.read_id, cols.flags};
+    const uint64_t n_batches = (n_reads + FQ_BATCH - 1) / FQ_BATCH;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 8);
+    const uint32_t hdr_lds = 4 * FQ_BATCH * e->fq_hpitch;
+    if (hdr_lds > 48 * 1024)
+      HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fastq_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_lds));
+    hipLaunchKernelGGL(k_fastq_write, dim3(grid), dim3(256), hdr_lds, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, rd, n_reads, paired ? 1u : 0u,
+                       e->fq_lit_bytes, e->fq_hpitch, e->fq_off.as<uint64_t>(), dst);
+    hipError_t s = hipGetLastError();
+    if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "fastq launch failed: %s", hipGetErrorString(s));
+    return SIMMR_OK;
+  }
+  const bool seeds2 = paired && e->prof.kind != SIMMR_K_PERFECT_SHORT;
+  PlanArrays pl = plan_arrays(e, seeds2);
+  const uint32_t* u_genome = (paired && !e->plan_multi) ? nullptr : e->u_genome.as<uint32_t>();
+  unsigned long long* counters = e->d_counters.as<unsigned long long>();
+  HIP_TRY(e, hipEventRecord(e->ev_c, e->stream));
+  {
+    const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * e->philox_wgs_per_cu);
+    bool exc = false;
+    if (paired) exc = e->plan_any_exc;
+    else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
+    const bool cached = paired && !e->plan_multi && e->plan_genome < e->genomes.size() &&
+                        e->genomes[e->plan_genome].contigs.size() <= PHILOX_CBASE;
+    auto kern = cached ? (exc ? k_emit_philox<true, false, true, true> : k_emit_philox<false, false, true, true>)
+                       : (exc ? k_emit_philox<true, false, false, true> : k_emit_philox<false, false, false, true>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(),
+                       e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome,
+                       e->u_seed.as<uint64_t>(), dst, dst, 33u, e->plan_first, e->fq_read_id_base, OutCols{}, counters,
+                       e->fq_off.as<uint64_t>(), e->fq_hlen.as<uint8_t>());
+  }
+  HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
+  {
+    const uint64_t n_batches = (n_reads + FQH_BATCH - 1) / FQH_BATCH;
+    const uint32_t hdr_lds = 4 * FQH_BATCH * e->fq_hpitch;
+    if (hdr_lds > 48 * 1024)
+      HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fastq_headers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_lds));
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fastq_headers, 256, hdr_lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * (uint64_t)per_cu * 2);
+    // windows per run: the power of two that covers the longest run ('\n' + header + '\n'), at most 16 (256 bytes)
+    uint32_t wshift = 0;
+    while ((16u << wshift) < e->fq_maxhdr + 2u) wshift++;
+    hipLaunchKernelGGL(k_fastq_headers, dim3(grid), dim3(256), hdr_lds, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, fq_plan_view(e), n_reads,
+                       e->fq_lit_bytes, e->fq_hpitch, wshift, e->fq_off.as<uint64_t>(), dst);
+  }
   hipError_t s = hipGetLastError();
   if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "fastq launch failed: %s", hipGetErrorString(s));
   return SIMMR_OK;
@@ -1822,6 +1999,12 @@ int simmr_last_emit_kernel_ms(simmr_engine* e, float* ms) {
   if (rc) return rc;
   HIP_TRY(e, hipEventElapsedTime(&e->last_emit_ms, e->ev_c, e->ev_d));
   *ms = e->last_emit_ms;
+  return SIMMR_OK;
+}
+
+int simmr_last_fastq_plan_ms(simmr_engine* e, float* ms) {
+  if (!e || !ms) return SIMMR_EINVAL;
+  *ms = e->last_fastq_plan_ms;
   return SIMMR_OK;
 }
 

@@ -57,34 +57,100 @@ struct FqReads {  // the SoA columns simmr_*_emit filled (device pointers)
   const uint8_t* flags;
 };
 
+// What a header can show of a read (fastq.rs:34-56), from the emitted columns or straight from the plan.
+struct FqFields {
+  uint64_t start, end;  // ReadMetadata.start_pos / end_pos
+  uint32_t genome, contig, read_id, flags;
+  uint32_t L;           // bases
+};
+SIMMR_DEV FqFields fq_fields(const FqReads& rd, uint64_t r) {
+  return FqFields{rd.start[r], rd.end[r], rd.genome[r], rd.contig[r], rd.read_id[r], rd.flags[r],
+                  (uint32_t)(rd.seq_off[r + 1] - rd.seq_off[r])};
+}
+// The plan of the shard about to be emitted (simmr_fastq_plan_direct): the same values simmr_*_emit would write into
+// the columns (k_write_meta / the emit kernels' prologues; simulate.rs:274,289-296,515-516).
+struct FqPlan {
+  PlanArrays pl;
+  const uint32_t* u_contig;
+  const uint32_t* u_genome;  // null: genome_const
+  uint64_t first_unit;
+  uint32_t read_id_base, genome_const, paired;
+};
+SIMMR_DEV FqFields fq_fields(const FqPlan& p, uint64_t r) {
+  const uint64_t u = p.paired ? (r >> 1) : r;
+  const uint32_t rev = p.paired ? (uint32_t)(r & 1u) : 0u;
+  const uint32_t L = p.pl.len[u];
+  FqFields f;
+  if (p.paired) {
+    const uint64_t pos = rev ? p.pl.b[u] : p.pl.a[u];
+    f.start = rev ? pos + L : pos;
+    f.end = rev ? pos : pos + L;
+    f.flags = rev ? p.pl.flags[u] : 0u;
+  } else {
+    f.start = p.pl.a[u];
+    f.end = p.pl.b[u];
+    f.flags = p.pl.flags[u];
+  }
+  f.genome = p.u_genome ? p.u_genome[u] : p.genome_const;
+  f.contig = p.u_contig[u];
+  f.read_id = p.read_id_base + (uint32_t)(p.first_unit + u);
+  f.L = L;
+  return f;
+}
+
 SIMMR_DEV uint32_t dec_digits(uint64_t v) {
+  if ((v >> 32) == 0) {  // the usual case: nine compares, no division
+    const uint32_t x = (uint32_t)v;
+    return 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) +
+           (x >= 10000000u) + (x >= 100000000u) + (x >= 1000000000u);
+  }
   uint32_t n = 1;
   while (v >= 10u) { v /= 10u; n++; }
   return n;
 }
 
 // bytes of the header of read r (without the '\n'); 0xffffffff if a table index is out of range
-SIMMR_DEV uint32_t fq_header_len(const FqTemplate& tp, const FqTables& tb, const FqReads& rd, uint64_t r) {
-  const uint32_t g = rd.genome[r];
-  if (g >= tb.n_slots || rd.contig[r] >= tb.g_ncontig[g]) return 0xffffffffu;
+// (the template is read through a pointer to device memory: indexing a by-value kernel argument with a loop counter
+// makes every thread copy the whole struct to scratch first — 58 GB of traffic per 100 M reads, 17 ms, measured)
+SIMMR_DEV uint32_t fq_header_len(const FqTemplate* __restrict__ tp, const FqTables& tb, const FqFields& f) {
+  const uint32_t g = f.genome;
+  if (g >= tb.n_slots || f.contig >= tb.g_ncontig[g]) return 0xffffffffu;
   uint32_t n = 0;
-  for (uint32_t s = 0; s < tp.n_segs; s++) {
-    const FqSeg sg = tp.segs[s];
+  const uint32_t n_segs = tp->n_segs;
+  for (uint32_t s = 0; s < n_segs; s++) {
+    const FqSeg sg = tp->segs[s];
     switch (sg.kind) {
       case FQ_LITERAL: n += sg.len; break;
       case FQ_GENOME_ID: n += tb.g_id_len[g]; break;
-      case FQ_READ_ID: n += dec_digits(rd.read_id[r]); break;
-      case FQ_SEQUENCE_ID: n += tb.c_len[tb.g_cbase[g] + rd.contig[r]]; break;
-      case FQ_START: n += dec_digits(rd.start[r]); break;
-      case FQ_END: n += dec_digits(rd.end[r]); break;
+      case FQ_READ_ID: n += dec_digits(f.read_id); break;
+      case FQ_SEQUENCE_ID: n += tb.c_len[tb.g_cbase[g] + f.contig]; break;
+      case FQ_START: n += dec_digits(f.start); break;
+      case FQ_END: n += dec_digits(f.end); break;
       default: n += 1; break;  // 't' / 'f', '1' / '2'
     }
   }
   return n;
 }
 
+// Decimal digits of v at dst[at ...] (LDS).  Below 10^8 — every position of a genome under 100 Mbp, most read ids — the
+// eight digits are made in registers and go out as ONE 8-byte store with the leading zeros shifted off (the bytes
+// behind the number are overwritten by the next piece of the header; every slot has that much slack).
+SIMMR_DEV uint32_t fq_four_digits(uint32_t y) {  // y < 10000 -> its four digits as bytes, most significant first in memory
+  const uint32_t a = y / 100u, b = y - a * 100u;
+  const uint32_t a1 = a / 10u, a0 = a - a1 * 10u, b1 = b / 10u, b0 = b - b1 * 10u;
+  return a1 | (a0 << 8) | (b1 << 16) | (b0 << 24);
+}
 SIMMR_DEV uint32_t fq_put_dec(uint8_t* dst, uint32_t at, uint64_t v) {
-  if ((v >> 32) == 0) {  // the usual case: no 64-bit division
+  if (v < 100000000ull) {
+    const uint32_t x = (uint32_t)v;
+    const uint32_t hi = x / 10000u, lo = x - hi * 10000u;
+    uint64_t p = ((uint64_t)fq_four_digits(hi) | ((uint64_t)fq_four_digits(lo) << 32)) + 0x3030303030303030ull;
+    const uint32_t n = dec_digits(x);
+    p >>= 8u * (8u - n);
+    *reinterpret_cast<u64_unaligned*>(dst + at) = p;
+    return at + n;
+  }
+  if ((v >> 32) == 0) {  // no 64-bit division
     uint32_t x = (uint32_t)v, n = 1;
     for (uint32_t t = x; t >= 10u; t /= 10u) n++;
     for (uint32_t i = n; i-- > 0;) { dst[at + i] = (uint8_t)('0' + x % 10u); x /= 10u; }
@@ -94,30 +160,112 @@ SIMMR_DEV uint32_t fq_put_dec(uint8_t* dst, uint32_t at, uint64_t v) {
   for (uint32_t i = n; i-- > 0;) { dst[at + i] = (uint8_t)('0' + (uint32_t)(v % 10u)); v /= 10u; }
   return at + n;
 }
-// LDS -> LDS
+// LDS -> LDS, eight bytes at a time (src is the same for every lane: one broadcast read per piece; both buffers have
+// eight spare bytes, and what is written past n is overwritten by the header's next piece)
 SIMMR_DEV uint32_t fq_put_bytes(uint8_t* dst, uint32_t at, const uint8_t* src, uint32_t n) {
-  for (uint32_t i = 0; i < n; i++) dst[at + i] = src[i];
+  for (uint32_t i = 0; i < n; i += 8) *reinterpret_cast<u64_unaligned*>(dst + at + i) = *reinterpret_cast<const u64_unaligned*>(src + i);
   return at + n;
 }
-// device memory -> LDS in 8-byte pieces (the blob is padded; the slot has FQ_HPITCH - FQ_HMAX spare bytes)
+// device memory -> LDS in 8-byte pieces (the blob is padded; the slot has spare bytes behind the longest header).
+// The first 48 bytes are fetched before the first is stored: one memory latency for an id, not one per piece (a
+// header has two ids; piece by piece they were a third of the header kernel's time).
 SIMMR_DEV uint32_t fq_put_global(uint8_t* dst, uint32_t at, const uint8_t* __restrict__ src, uint32_t n) {
-  for (uint32_t i = 0; i < n; i += 8) {
-    const uint64_t v = *(global_u64_unaligned_ptr)(src + i);
-    *reinterpret_cast<u64_unaligned*>(dst + at + i) = v;
+  uint64_t v[6];
+#pragma unroll
+  for (uint32_t k = 0; k < 6; k++) v[k] = (8u * k < n) ? *(global_u64_unaligned_ptr)(src + 8u * k) : 0ull;
+#pragma unroll
+  for (uint32_t k = 0; k < 6; k++) if (8u * k < n) *reinterpret_cast<u64_unaligned*>(dst + at + 8u * k) = v[k];
+  for (uint32_t i = 48; i < n; i += 8) {
+    const uint64_t w = *(global_u64_unaligned_ptr)(src + i);
+    *reinterpret_cast<u64_unaligned*>(dst + at + i) = w;
   }
   return at + n;
 }
 
+#if defined(FQH_ABLATE_FORMAT)
+SIMMR_DEV uint32_t fq_header_len_lds(const FqSeg* segs, uint32_t n_segs, const FqTables& tb, const FqFields& f) {
+  const uint32_t g = f.genome;
+  uint32_t n = 0;
+  for (uint32_t s = 0; s < n_segs; s++) {
+    const FqSeg sg = segs[s];
+    switch (sg.kind) {
+      case FQ_LITERAL: n += sg.len; break;
+      case FQ_GENOME_ID: n += tb.g_id_len[g]; break;
+      case FQ_READ_ID: n += dec_digits(f.read_id); break;
+      case FQ_SEQUENCE_ID: n += tb.c_len[tb.g_cbase[g] + f.contig]; break;
+      case FQ_START: n += dec_digits(f.start); break;
+      case FQ_END: n += dec_digits(f.end); break;
+      default: n += 1; break;
+    }
+  }
+  return n;
+}
+#endif
+
+// the header of a read into an LDS slot at h[at ...] (fastq.rs:34-56); returns the position behind it
+// `segs` / `n_segs`: the template's pieces, staged in LDS by the caller (fq_stage_template)
+SIMMR_DEV uint32_t fq_format_header(uint8_t* h, uint32_t at, const FqSeg* segs, uint32_t n_segs, const FqTables& tb, const uint8_t* lit,
+                                    const FqFields& f, uint8_t pair_char) {
+  const uint32_t g = f.genome;
+  const uint32_t row = tb.g_cbase[g] + f.contig;
+  const uint32_t gid_off = tb.g_id_off[g], gid_len = tb.g_id_len[g], sid_off = tb.c_off[row], sid_len = tb.c_len[row];
+  for (uint32_t s = 0; s < n_segs; s++) {
+    const FqSeg sg = segs[s];
+    switch (sg.kind) {
+      case FQ_LITERAL: at = fq_put_bytes(h, at, lit + sg.off, sg.len); break;
+      case FQ_GENOME_ID: at = fq_put_global(h, at, tb.blob + gid_off, gid_len); break;
+      case FQ_READ_ID: at = fq_put_dec(h, at, f.read_id); break;
+      case FQ_SEQUENCE_ID: at = fq_put_global(h, at, tb.blob + sid_off, sid_len); break;
+      case FQ_START: at = fq_put_dec(h, at, f.start); break;
+      case FQ_END: at = fq_put_dec(h, at, f.end); break;
+      case FQ_REVCOMP: h[at++] = (f.flags & SIMMR_FLAG_REVCOMP) ? 't' : 'f'; break;
+      default: h[at++] = pair_char; break;  // mates are interleaved
+    }
+  }
+  return at;
+}
+
+// the template's pieces from device memory into LDS, once per workgroup (a scalar load per piece and header was a chain of
+// fourteen memory latencies per batch of 64 headers)
+SIMMR_DEV uint32_t fq_stage_template(const FqTemplate* __restrict__ tp, FqSeg* segs) {
+  const uint32_t n = tp->n_segs < FQ_MAX_SEGS ? tp->n_segs : FQ_MAX_SEGS;
+  if (threadIdx.x < n) segs[threadIdx.x] = tp->segs[threadIdx.x];
+  return n;
+}
+
 extern "C" __global__ void __launch_bounds__(256)
-k_fastq_size(FqTemplate tp, FqTables tb, FqReads rd, uint64_t n_reads, uint64_t* __restrict__ rec_len,
+k_fastq_size(const FqTemplate* __restrict__ tp, FqTables tb, FqReads rd, uint64_t n_reads, uint64_t* __restrict__ rec_len,
              uint32_t* __restrict__ err) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n_reads) return;
-  const uint32_t h = fq_header_len(tp, tb, rd, r);
+  const FqFields f = fq_fields(rd, r);
+  const uint32_t h = fq_header_len(tp, tb, f);
   if (h >= FQ_HMAX) { atomicOr(err, SIMMR_ERRBIT_FASTQ); rec_len[r] = 0; return; }  // header + '\n' must fit the LDS slot
-  atomicMax(err + 1, h);  // the longest header sizes the LDS slots of k_fastq_write
-  const uint64_t L = rd.seq_off[r + 1] - rd.seq_off[r];
+  // the longest header sizes the LDS slots of k_fastq_write (an atomic only when this one is longer than any seen so
+  // far: atomics on one address are served one at a time, 1.5 M of them took 15 ms)
+  if (h > *(volatile uint32_t*)(err + 1)) atomicMax(err + 1, h);
+  const uint64_t L = f.L;
   rec_len[r] = (uint64_t)h + 1u + L + 3u + L + 1u;
+}
+
+// The same from the plan (simmr_fastq_plan_direct); hlen[r] = the header's bytes, for the emit kernel that writes into the text.
+extern "C" __global__ void __launch_bounds__(256)
+k_fastq_size_plan(const FqTemplate* __restrict__ tp, FqTables tb, FqPlan pn, uint64_t n_reads, uint64_t* __restrict__ rec_len,
+                  uint8_t* __restrict__ hlen, uint32_t* __restrict__ err) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool on = r < n_reads;
+  uint32_t h = 0;
+  FqFields f{};
+  if (on) { f = fq_fields(pn, r); h = fq_header_len(tp, tb, f); }
+  const bool bad = h >= FQ_HMAX;  // (also a genome / contig without a name)
+  uint32_t wmax = bad ? 0u : h;  // the longest header sizes the LDS slots of k_fastq_headers: one atomic per wave
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d, 64); wmax = o > wmax ? o : wmax; }
+  if ((threadIdx.x & 63u) == 0 && wmax > *(volatile uint32_t*)(err + 1)) atomicMax(err + 1, wmax);  // (rarely: see k_fastq_size)
+  if (!on) return;
+  if (bad) { atomicOr(err, SIMMR_ERRBIT_FASTQ); rec_len[r] = 0; hlen[r] = 0; return; }
+  hlen[r] = (uint8_t)h;
+  rec_len[r] = (uint64_t)h + 1u + (uint64_t)f.L + 3u + (uint64_t)f.L + 1u;
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -145,15 +293,17 @@ struct FqRead {  // what the copy phase needs to know about a record
 #define FQ_UNROLL 4 /* windows per lane in flight */
 
 extern "C" __global__ void __launch_bounds__(256)
-k_fastq_write(FqTemplate tp, FqTables tb, FqReads rd, uint64_t n_reads, uint32_t paired, uint32_t lit_bytes,
+k_fastq_write(const FqTemplate* __restrict__ tp, FqTables tb, FqReads rd, uint64_t n_reads, uint32_t paired, uint32_t lit_bytes,
               uint32_t hpitch, const uint64_t* __restrict__ rec_off, uint8_t* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t hdr_all[];  // [4 waves][FQ_BATCH][hpitch], hpitch % 16 == 0
+  extern __shared__ __attribute__((aligned(16))) uint8_t hdr_all[];  // [4 waves][FQ_BATCH][hpitch], hpitch = 4 * an odd number (fq_slot_pitch)
   __shared__ __attribute__((aligned(16))) uint8_t lit[FQ_LIT_MAX + 8];
   __shared__ FqRead recs[4][FQ_BATCH];
   __shared__ uint32_t wpre[4][FQ_BATCH + 1];  // first window of each record of the batch
+  __shared__ FqSeg segs[FQ_MAX_SEGS];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint8_t* hdr = hdr_all + (size_t)wave * FQ_BATCH * hpitch;
   for (uint32_t i = threadIdx.x; i < lit_bytes; i += 256) lit[i] = tb.blob[i];
+  const uint32_t n_segs = fq_stage_template(tp, segs);
   __syncthreads();
   const uint64_t n_batches = (n_reads + FQ_BATCH - 1) / FQ_BATCH;
   const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + wave, n_waves = (uint64_t)gridDim.x * 4;
@@ -165,27 +315,11 @@ k_fastq_write(FqTemplate tp, FqTables tb, FqReads rd, uint64_t n_reads, uint32_t
     if (lane < nb) {
       const uint64_t r = r0 + lane;
       uint8_t* h = hdr + lane * hpitch;
-      const uint32_t g = rd.genome[r];
-      const uint32_t row = tb.g_cbase[g] + rd.contig[r];
-      const uint32_t gid_off = tb.g_id_off[g], gid_len = tb.g_id_len[g], sid_off = tb.c_off[row], sid_len = tb.c_len[row];
-      const uint64_t start = rd.start[r], end = rd.end[r], so = rd.seq_off[r], so1 = rd.seq_off[r + 1];
-      const uint32_t id = rd.read_id[r], fl = rd.flags[r];
-      uint32_t at = 0;
-      for (uint32_t s = 0; s < tp.n_segs; s++) {
-        const FqSeg sg = tp.segs[s];
-        switch (sg.kind) {
-          case FQ_LITERAL: at = fq_put_bytes(h, at, lit + sg.off, sg.len); break;
-          case FQ_GENOME_ID: at = fq_put_global(h, at, tb.blob + gid_off, gid_len); break;
-          case FQ_READ_ID: at = fq_put_dec(h, at, id); break;
-          case FQ_SEQUENCE_ID: at = fq_put_global(h, at, tb.blob + sid_off, sid_len); break;
-          case FQ_START: at = fq_put_dec(h, at, start); break;
-          case FQ_END: at = fq_put_dec(h, at, end); break;
-          case FQ_REVCOMP: h[at++] = (fl & SIMMR_FLAG_REVCOMP) ? 't' : 'f'; break;
-          default: h[at++] = (paired && (r & 1u)) ? '2' : '1'; break;  // mates are interleaved
-        }
-      }
+      const uint64_t so = rd.seq_off[r];
+      const FqFields f = fq_fields(rd, r);
+      uint32_t at = fq_format_header(h, 0u, segs, n_segs, tb, lit, f, (paired && (r & 1u)) ? '2' : '1');
       h[at] = '\n';
-      const uint32_t H = at + 1, L = (uint32_t)(so1 - so);
+      const uint32_t H = at + 1, L = f.L;
       recs[wave][lane] = FqRead{rec_off[r], so, H, L};
       // windows: runs shorter than 16 bytes are one bytewise "window"
       nwin = (H >= 16u ? (H + 15u) >> 4 : 1u) + (L >= 16u ? ((L + 3u + 15u) >> 4) + ((L + 1u + 15u) >> 4) : 2u);
@@ -198,7 +332,7 @@ k_fastq_write(FqTemplate tp, FqTables tb, FqReads rd, uint64_t n_reads, uint32_t
     }
     if (lane < FQ_BATCH) wpre[wave][lane + 1] = inc;
     if (lane == 0) wpre[wave][0] = 0;
-    __builtin_amdgcn_s_waitcnt(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS only: s_waitcnt 0 would also wait for the previous batch's stores to be acknowledged)
     __builtin_amdgcn_wave_barrier();
     const uint32_t total = wpre[wave][FQ_BATCH];
     // ---- phase 2: every lane moves windows of the batch's records.  A window of a run of n_src source
@@ -263,6 +397,77 @@ k_fastq_write(FqTemplate tp, FqTables tb, FqReads rd, uint64_t n_reads, uint32_t
           for (uint32_t j = 0; j < R.L; j++) recC[j] = rd.qual[R.so + j];
           recC[R.L] = '\n';
         }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the next batch overwrites the LDS slots
+  }
+}
+
+// Headers and line ends of a text whose bases and qualities the emit kernel writes itself (simmr_emit_fastq).  The
+// run of read r is the '\n' that ends record r - 1, the header, and its '\n' — so the only bytes of a record no 16-byte
+// window of some run covers are "\n+\n" (written by the emit kernel's lane that holds the read's first qualities) and
+// the last record's final '\n'.  A read without bases has no such lane: its "\n+\n" is written here.
+#define FQH_BATCH 64u /* headers per wave and step (32, for twice the waves per CU, measured no faster: 10.7 vs 10.0 ms) */
+extern "C" __global__ void __launch_bounds__(256)
+k_fastq_headers(const FqTemplate* __restrict__ tp, FqTables tb, FqPlan pn, uint64_t n_reads, uint32_t lit_bytes, uint32_t hpitch,
+                uint32_t wshift, const uint64_t* __restrict__ rec_off, uint8_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t hdr_all[];  // [4 waves][FQH_BATCH][hpitch]
+  __shared__ __attribute__((aligned(16))) uint8_t lit[FQ_LIT_MAX + 8];
+  __shared__ uint64_t run_at[4][FQH_BATCH];     // where the run starts in the output
+  __shared__ uint32_t run_len[4][FQH_BATCH];
+  __shared__ FqSeg segs[FQ_MAX_SEGS];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint8_t* hdr = hdr_all + (size_t)wave * FQH_BATCH * hpitch;
+  for (uint32_t i = threadIdx.x; i < lit_bytes; i += 256) lit[i] = tb.blob[i];
+  const uint32_t n_segs = fq_stage_template(tp, segs);
+  __syncthreads();
+  const uint64_t n_batches = (n_reads + FQH_BATCH - 1) / FQH_BATCH;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + wave, n_waves = (uint64_t)gridDim.x * 4;
+  for (uint64_t batch = wave_id; batch < n_batches; batch += n_waves) {
+    const uint64_t r0 = batch * FQH_BATCH;
+    const uint32_t nb = (n_reads - r0) < FQH_BATCH ? (uint32_t)(n_reads - r0) : FQH_BATCH;
+    if (lane < nb) {
+      const uint64_t r = r0 + lane;
+      uint8_t* h = hdr + lane * hpitch;
+      const FqFields f = fq_fields(pn, r);
+      const uint32_t lead = r > 0 ? 1u : 0u;
+      h[0] = '\n';  // ends record r - 1
+#if defined(FQH_ABLATE_FORMAT)
+      uint32_t at = lead + fq_header_len_lds(segs, n_segs, tb, f);  // timing only: the slot keeps whatever it held
+#else
+      uint32_t at = fq_format_header(h, lead, segs, n_segs, tb, lit, f, (pn.paired && (r & 1u)) ? '2' : '1');
+#endif
+      h[at++] = '\n';
+      const uint64_t rec = rec_off[r];
+      run_at[wave][lane] = rec - lead;
+      run_len[wave][lane] = at;
+      if (f.L == 0) { uint8_t* p = out + rec + (at - lead); p[0] = '\n'; p[1] = '+'; p[2] = '\n'; }
+      if (r + 1 == n_reads) out[rec_off[n_reads] - 1] = '\n';
+    }
+    // Windows: every run of the batch gets the same number of 16-byte windows, W = a power of two that covers the
+    // longest header (`wshift` from the host), so lane -> (run, window) is a shift and a mask: no search, no prefix; the
+    // lanes whose window lies past their run's end idle.  64 >> wshift runs per step.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS only: s_waitcnt 0 would also wait for the previous batch's stores to be acknowledged)
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t per_step = 64u >> wshift, piece = lane & ((1u << wshift) - 1u);
+    for (uint32_t i0 = 0; i0 < nb; i0 += per_step) {
+      const uint32_t i = i0 + (lane >> wshift);
+      if (i >= nb) continue;
+      const uint32_t n = run_len[wave][i];
+      uint8_t* dst = out + run_at[wave][i];
+      const uint8_t* src = hdr + i * hpitch;
+      if (n >= 16u) {  // the last window ends where the run ends (it overlaps its neighbour with the same bytes)
+        if (piece * 16u < n) {
+          const uint32_t w = (piece + 1u) * 16u <= n ? piece * 16u : n - 16u;
+#if defined(FQH_ABLATE_STORES)
+          const u32x4 val = *reinterpret_cast<const u32x4_unaligned*>(src + w);
+          asm volatile("" :: "v"(val), "v"(dst));  // timing only
+#else
+          *reinterpret_cast<u32x4_unaligned*>(dst + w) = *reinterpret_cast<const u32x4_unaligned*>(src + w);
+#endif
+        }
+      } else if (piece == 0u) {
+        for (uint32_t j = 0; j < n; j++) dst[j] = src[j];
       }
     }
     __builtin_amdgcn_wave_barrier();  // the next batch overwrites the LDS slots

@@ -2091,14 +2091,19 @@ SIMMR_DEV void philox_repair(const uint32_t k0, const uint32_t k1, const uint32_
 // with coalesced stores, for the profiles whose qualities another kernel writes (custom-short).
 // CACHED: every pair comes from one genome (u_genome == null) with at most PHILOX_CBASE contigs, whose bases sit in
 // LDS: a record then needs no load that depends on another load's result.
-template <bool HAS_EXC, bool COPY_ONLY, bool CACHED>
+// TEXT: bases and qualities go straight into FASTQ text (simmr_emit_fastq; fastq.rs:58-66): `seq` is the text, read rd's
+// record starts at rec_off[rd] with a header of hlen[rd] bytes, so its bases start at rec_off[rd] + hlen[rd] + 1 and its
+// qualities L + 3 bytes further ("\n+\n"); the lane that holds a read's first qualities also writes those three bytes
+// (one 4-byte store that ends in its own first quality); headers and the other line ends are k_fastq_headers' job.
+template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false>
 __global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
               const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
               const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
               uint32_t qual_offset, uint64_t first_unit, uint32_t read_id_base, OutCols o,
-              unsigned long long* __restrict__ counters) {
+              unsigned long long* __restrict__ counters, const uint64_t* __restrict__ rec_off = nullptr,
+              const uint8_t* __restrict__ hlen = nullptr) {
   __shared__ uint2 jtab[COPY_ONLY ? 1 : 1024];  // level-1 columns (philox_pick)
   __shared__ uint32_t asc[256];  // four 2-bit codes -> four ASCII bytes
   __shared__ PhRec recs[PHILOX_READS];
@@ -2155,9 +2160,10 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     const uint64_t u0 = blk * PHILOX_UNITS;
     const uint32_t nu = (n_units - u0) < PHILOX_UNITS ? (uint32_t)(n_units - u0) : PHILOX_UNITS;
     const uint32_t nr = nu * rpu;
-    const uint64_t out0 = u_off[u0];  // the block's first output byte (same for every lane: a scalar load)
+    // the block's first output byte (same for every lane: a scalar load)
+    const uint64_t out0 = TEXT ? rec_off[paired ? 2 * u0 : u0] : u_off[u0];
     uint8_t* const seq_blk = seq + out0;
-    uint8_t* const qual_blk = qual + out0;
+    uint8_t* const qual_blk = (TEXT ? seq : qual) + out0;
     lds_barrier();  // the previous block's items are done with the records
     uint32_t g = 0;
     if (threadIdx.x < nr) {
@@ -2168,7 +2174,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       g = (L + 15u) >> 4;
       const uint32_t contig = u_contig[u];
       const uint32_t genome = (!CACHED && u_genome) ? u_genome[u] : genome_const;
-      const uint64_t dst = u_off[u] + (rev ? L : 0u);
+      const uint64_t rd = paired ? 2 * u + rev : u;
+      const uint64_t dst = TEXT ? rec_off[rd] + hlen[rd] + 1u : u_off[u] + (rev ? L : 0u);
       const uint64_t pos = rev ? pl.b[u] : pl.a[u];  // first source base of this read on the contig
       const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
       uint64_t cb;
@@ -2199,21 +2206,22 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       if (!COPY_ONLY) {
 #endif
         // metadata columns of this read (the other emit kernels leave them to k_write_meta)
-        const uint64_t rd = paired ? 2 * u + rev : u;
         const uint32_t fl = pl.flags[u];
-        o.seq_off[rd] = dst;
-        if (rd + 1 == n_reads) o.seq_off[n_reads] = u_off[n_units];  // closing CSR offset
-        if (paired) {
-          if (o.start) o.start[rd] = rev ? pos + L : pos;  // simulate.rs:289,295
-          if (o.end) o.end[rd] = rev ? pos : pos + L;      // simulate.rs:290,296
-        } else {
-          if (o.start) o.start[rd] = pos;                  // simulate.rs:515
-          if (o.end) o.end[rd] = pl.b[u];                  // simulate.rs:516
+        if (!TEXT) {
+          o.seq_off[rd] = dst;
+          if (rd + 1 == n_reads) o.seq_off[n_reads] = u_off[n_units];  // closing CSR offset
+          if (paired) {
+            if (o.start) o.start[rd] = rev ? pos + L : pos;  // simulate.rs:289,295
+            if (o.end) o.end[rd] = rev ? pos : pos + L;      // simulate.rs:290,296
+          } else {
+            if (o.start) o.start[rd] = pos;                  // simulate.rs:515
+            if (o.end) o.end[rd] = pl.b[u];                  // simulate.rs:516
+          }
+          if (o.contig) o.contig[rd] = contig;
+          if (o.genome) o.genome[rd] = genome;
+          if (o.read_id) o.read_id[rd] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
+          if (o.flags) o.flags[rd] = (paired && !rev) ? 0 : (uint8_t)fl;
         }
-        if (o.contig) o.contig[rd] = contig;
-        if (o.genome) o.genome[rd] = genome;
-        if (o.read_id) o.read_id[rd] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
-        if (o.flags) o.flags[rd] = (paired && !rev) ? 0 : (uint8_t)fl;
         if (!rev) {
           p_bases += paired ? 2ull * L : (uint64_t)L;
           p_redrawn += (fl & SIMMR_FLAG_REDRAWN) ? 1u : 0u;
@@ -2315,8 +2323,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
               (((codes & 0xccccccccu) + (ss & 0xccccccccu)) & 0xccccccccu);
       // qualities are already offset-encoded, forward order
       const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
-      const uint32_t o_q = ra.z + b0;
-      uint32_t o_s = o_q;
+      uint32_t o_s = ra.z + b0;
+      const uint32_t o_q = TEXT ? o_s + L + 3u : o_s;  // (TEXT: the qualities' line follows the bases' line and "+\n")
       if (rev) {
         // mate 2 is reverse-complemented after mutation (simulate.rs:283), still in the code domain:
         // base b0+j -> byte L-1-(b0+j); the 16-n dead groups fall off the low end
@@ -2354,6 +2362,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       uint8_t* qd = qual_blk + o_q;
       uint8_t* sd = seq_blk + o_s;
 #endif
+      if (TEXT && ci == 0u)  // "\n+\n" and, once more, the first quality
+        *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(qd - 3) = 0x000a2b0au | ((uint32_t)q_lo << 24);
 #if defined(SIMMR_ABLATE_ALL16)
       if (true) {  // timing only: partial groups store 16 bytes too (they overwrite the head of the next read)
 #else

@@ -271,6 +271,42 @@ class Engine:
         self._check(self.lib.simmr_fastq_emit(self._h, C.byref(pod), C.c_void_p(out.data_ptr()), total.value))
         return out[: total.value]
 
+    def _fastq_names(self, names):
+        n = len(names)
+        gi = (C.c_uint32 * max(n, 1))(*[int(x[0]) for x in names])
+        gid = (C.c_char_p * max(n, 1))(*[str(x[1]).encode() for x in names])
+        nc = (C.c_uint32 * max(n, 1))(*[len(x[2]) for x in names])
+        flat = [str(sid).encode() for x in names for sid in x[2]]
+        sids = (C.c_char_p * max(len(flat), 1))(*flat)
+        fn = _abi.FastqNames(n, gi, gid, nc, sids)
+        fn._keep = (gi, gid, nc, sids)
+        return fn
+
+    def fastq_plan_direct(self, header_format: str, names, read_id_base: int = 0) -> int:
+        """Sizes the FASTQ text of the CURRENT plan's shard (simmr_fastq_plan_direct); returns its bytes."""
+        fn = self._fastq_names(names)
+        total = C.c_uint64(0)
+        self._check(self.lib.simmr_fastq_plan_direct(self._h, header_format.encode(), C.byref(fn), int(read_id_base),
+                                                     C.byref(total)))
+        return int(total.value)
+
+    def emit_fastq(self, out):
+        """Writes the text planned by fastq_plan_direct into the CUDA uint8 tensor `out` (simmr_emit_fastq)."""
+        self._check(self.lib.simmr_emit_fastq(self._h, C.c_void_p(out.data_ptr()), int(out.numel())))
+
+    def fastq_direct(self, header_format: str, names, read_id_base: int = 0):
+        """FASTQ text of the current plan's shard without the columns in between, as a CUDA uint8 tensor."""
+        torch = _torch()
+        total = self.fastq_plan_direct(header_format, names, read_id_base)
+        out = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+        self.emit_fastq(out)
+        return out[:total]
+
+    def last_fastq_plan_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.simmr_last_fastq_plan_ms(self._h, C.byref(ms)))
+        return ms.value
+
     # -- counters / timing --------------------------------------------------------
     def counters(self) -> np.ndarray:
         host = (C.c_uint64 * _abi.N_COUNTERS)()

@@ -116,3 +116,85 @@ def test_fastq_random_templates(engine, genome_multi):
             _check(engine, reads, names, fmt, True)
         except SimmrError as ex:  # more than 24 pieces / 256 literal bytes: left to the host
             assert ex.code == _abi.ENOTSUP
+
+
+# ---- simmr_fastq_plan_direct / simmr_emit_fastq: the text straight from the plan ------------------------------------
+def _two_step(engine, reads, names, fmt, paired):
+    return engine.fastq(reads, fmt, names, paired).cpu().numpy().tobytes()
+
+
+def _same_text(got, want, what=""):
+    assert len(got) == len(want), (what, len(got), len(want))
+    if got != want:
+        g, w = np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8)
+        i = int(np.flatnonzero(g != w)[0])
+        raise AssertionError(f"{what}first difference at byte {i}: {got[max(0, i - 70):i + 20]!r} vs {want[max(0, i - 70):i + 20]!r}")
+
+
+PE_NAMES = lambda g: [(1, "genome-one", ["chrA something long", "b", "c c", "d" * 40][: len(g.contigs)] +
+                       ["x%d" % i for i in range(max(0, len(g.contigs) - 4))])]
+
+
+@pytest.mark.parametrize("fmt", [FMT, "@{:read_id:}", "", "{:pair:}{:pair:}x{:reverse_complement:}{:genome_id:} {:end_position:}-{:start_position:} {:sequence_id:}{:"])
+def test_fastq_direct_pe_equals_two_steps(engine, genome_multi, fmt):
+    """Counter mode (the emit kernel writes into the text) and the profiles served through the engine's own columns:
+    the same bytes as simmr_pe_emit + simmr_fastq_plan + simmr_fastq_emit, the same counters."""
+    names = PE_NAMES(genome_multi)
+    profs = [(MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod(), 6001, 0),
+             (MinimalShortErrorProfile(read_length=37, insert_size=80, rng_mode=_abi.RNG_PHILOX).pod(), 1500, 0),
+             (MinimalShortErrorProfile(read_length=9, insert_size=5, rng_mode=_abi.RNG_PHILOX).pod(), 333, 4_294_000_000),
+             (MinimalShortErrorProfile(read_length=16, insert_size=16, rng_mode=_abi.RNG_PHILOX).pod(), 700, 9),
+             (MinimalShortErrorProfile(read_length=333, insert_size=100, mean_phred_score=2, rng_mode=_abi.RNG_PHILOX).pod(), 900, 0),
+             (PerfectShortErrorProfile().pod(), 2001, 0),
+             (MinimalShortErrorProfile(read_length=37, insert_size=80).pod(), 800, 3)]
+    for prof, n, idb in profs:
+        engine.counters_reset()
+        reads = engine.simulate_pe_reads_from_genome(1, prof, n, 11, first=2, count=n // 2 - 5, read_id_base=idb, qual_offset=33)
+        c2 = engine.counters()
+        want = _two_step(engine, reads, names, fmt, True)
+        engine.counters_reset()
+        engine.pe_plan(1, prof, n, 11, 2, n // 2 - 5)
+        got = engine.fastq_direct(fmt, names, idb).cpu().numpy().tobytes()
+        _same_text(got, want, f"L={prof.read_length} ")
+        assert np.array_equal(engine.counters(), c2)
+
+
+def test_fastq_direct_long_and_multi_genome(engine, genome_multi, genome_1m):
+    names = [(1, "g1", ["ctg%d" % i for i in range(len(genome_multi.contigs))]), (0, "7700123", ["synth_1M"])]
+    for lp in (MinimalLongErrorProfile(gamma_mean=2500.0, gamma_std=2000.0, length_mode=_abi.LEN_PER_READ, rng_mode=_abi.RNG_PHILOX).pod(),
+               MinimalLongErrorProfile(gamma_mean=2500.0, gamma_std=2000.0, length_mode=_abi.LEN_PER_READ).pod()):
+        reads = engine.simulate_long_reads([1, 0], [70, 45], lp, 5, first=3, count=100, read_id_base=17, qual_offset=33)
+        for fmt in (FMT, "@{:sequence_id:}"):
+            want = _two_step(engine, reads, names, fmt, False)
+            engine.long_plan([1, 0], [70, 45], lp, 5, 3, 100)
+            got = engine.fastq_direct(fmt, names, 17).cpu().numpy().tobytes()
+            _same_text(got, want)
+    # pairs of two genomes in one plan
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()
+    reads = engine.simulate_pe_reads_multi([1, 0], [3000, 2000], prof, 17, qual_offset=33)
+    want = _two_step(engine, reads, names, FMT, True)
+    engine.pe_plan_multi([1, 0], [3000, 2000], prof, 17)
+    _same_text(engine.fastq_direct(FMT, names, 0).cpu().numpy().tobytes(), want)
+
+
+def test_fastq_direct_longest_headers_and_refusals(engine, genome_multi):
+    n = len(genome_multi.contigs)
+    prof = MinimalShortErrorProfile(read_length=40, insert_size=60, rng_mode=_abi.RNG_PHILOX).pod()
+    names = [(1, "g" * 60, ["contig %d " % i + "x" * 100 for i in range(n)])]
+    reads = engine.simulate_pe_reads_from_genome(1, prof, 3000, 2, qual_offset=33)
+    want = _two_step(engine, reads, names, FMT, True)
+    engine.pe_plan(1, prof, 3000, 2)
+    _same_text(engine.fastq_direct(FMT, names).cpu().numpy().tobytes(), want)
+    for bad_names, fmt in (([(1, "id{with}braces", ["c"] * n)], FMT), ([(1, "g", ["c" * 300] * n)], FMT),
+                           ([(1, "g", ["c"] * n)], "{:pair:}x" * 13), ([(0, "wrong slot", ["c"])], FMT)):
+        with pytest.raises(SimmrError) as ei:
+            engine.fastq_direct(fmt, bad_names)
+        assert ei.value.code == _abi.ENOTSUP
+    # an empty shard is an empty file; emit without a direct plan is a state error
+    engine.pe_plan(1, prof, 100, 1, 50, 0)
+    assert engine.fastq_direct(FMT, [(1, "g", ["c"] * n)]).numel() == 0
+    engine.pe_plan(1, prof, 100, 1)
+    import torch
+    with pytest.raises(SimmrError) as ei:
+        engine.emit_fastq(torch.empty(16, dtype=torch.uint8, device=engine.device))
+    assert ei.value.code in (_abi.ESTATE, _abi.ERANGE)

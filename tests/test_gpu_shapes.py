@@ -152,47 +152,54 @@ def test_c5_share_of_one_gpu(engine):
 
 
 def test_engine_set_stream_puts_the_work_on_that_stream(engine):
-    """simmr_engine_set_stream: the emit kernels queue up behind earlier work of the stream the engine was given (a
-    100 ms spin on that stream delays them), and not behind work of a stream it was not given."""
-    import time
+    """simmr_engine_set_stream: the emit kernels queue up behind earlier work of the stream the engine was given and not
+    behind work of a stream it was not given.  Decided by stream ORDER, not by wall-clock thresholds: with a long spin
+    ahead of the emit on the engine's stream, a copy of the output enqueued on the other stream right after the emit call
+    still sees the zeros the buffer was filled with (the spin is measured with events and must dwarf that copy); with the
+    spin on the stream the engine does not use, the same copy — now behind the emit in its own stream — sees the reads."""
     import torch
     from simmr_amd.engine import Reads
     eng = engine
     eng.stage_synthetic(7, [5_000_000], 9)
     prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()
-    side = torch.cuda.Stream()
+    side, main = torch.cuda.Stream(), torch.cuda.default_stream()
     info = eng.pe_plan(7, prof, 2_000_000, 3)
     out = Reads.allocate(info.n_reads, info.total_bases, eng.device, qual_offset=33)
-    spin = 400_000_000  # device clock cycles: well over 100 ms
+    spin = 400_000_000  # device clock cycles
+    peek = torch.empty(4096, dtype=torch.uint8).pin_memory()
 
-    def emit_behind_a_spin_on_side():
+    def emit_with_a_spin_on_side():
+        """zero the output, spin on `side`, emit on the engine's stream, copy the head of seq[] through `main`;
+        returns (what that copy saw, the spin's duration in ms)"""
+        out.seq.zero_()
         torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(side):
+            s0.record(side)
             torch.cuda._sleep(spin)
-        t0 = time.perf_counter()
+            s1.record(side)
         eng.pe_emit(0, out)  # on the engine's stream
-        done = torch.cuda.Event()
-        done.record(side if on_side else torch.cuda.current_stream())
-        done.synchronize()  # the emit kernels are through
-        dt = time.perf_counter() - t0
+        with torch.cuda.stream(main):
+            peek.copy_(out.seq[:4096], non_blocking=True)
+        main.synchronize()
+        seen = peek.numpy().copy()
         torch.cuda.synchronize()
-        return dt
+        return seen, s0.elapsed_time(s1)
 
     try:
-        on_side = True
         with torch.cuda.stream(side):
             eng.use_current_torch_stream()
         eng.pe_plan(7, prof, 2_000_000, 3)
-        dt = emit_behind_a_spin_on_side()
-        assert dt > 0.08, dt                            # the kernels waited for the spin
+        seen, spin_ms = emit_with_a_spin_on_side()
+        if spin_ms > 20.0:  # (else the spin is no cover for a 4 KB copy on this box: nothing to conclude)
+            assert not seen.any(), "the emit kernels did not wait for the earlier work of the engine's stream"
         first = out.to_host()
-        on_side = False
-        with torch.cuda.stream(torch.cuda.default_stream()):
+        assert first["seq"][:4096].all()                 # ... and ran after it
+        with torch.cuda.stream(main):
             eng.use_current_torch_stream()
         eng.pe_plan(7, prof, 2_000_000, 3)
-        out.seq.zero_()
-        dt = emit_behind_a_spin_on_side()
-        assert dt < 0.08, dt                            # nothing of the engine's is behind the other stream's spin
+        seen, _ = emit_with_a_spin_on_side()
+        assert np.array_equal(seen, first["seq"][:4096])  # behind the emit in its own stream, whatever `side` is doing
         again = out.to_host()
         for col in ("seq", "qual", "seq_off", "read_id"):
             assert np.array_equal(first[col], again[col]), col

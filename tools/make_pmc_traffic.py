@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""profiles/r3/pmc_traffic.json from the PMC summaries of tools/profile_round.sh, stamped with the hash of the kernel
+sources it was collected from (bench.py reports its numbers only while that hash still matches).
+
+usage: tools/make_pmc_traffic.py <dir with pmc_default.txt [pmc_perfect.txt pmc_custom_long.txt]> [--mix plain,vop3_sdwa,mad_u64]"""
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+
+
+def read(path):
+    d = {}
+    for line in Path(path).read_text().splitlines():
+        parts = line.split()
+        if len(parts) == 2 and not line.startswith("#"):
+            try:
+                d[parts[0]] = float(parts[1])
+            except ValueError:
+                pass
+    return d
+
+
+def record(d, workload, note):
+    r = {"workload": workload}
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        r["FETCH_SIZE_KB"], r["WRITE_SIZE_KB"] = d["FETCH_SIZE"], d["WRITE_SIZE"]
+        r["bytes_raw"] = (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+        r["bytes_fetch_doubled"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+    for k, v in d.items():
+        if k.startswith("SQ_") or k.startswith("GRBM_"):
+            r[k] = v
+    r["note"] = note
+    return r
+
+
+def main():
+    src = Path(sys.argv[1])
+    out = {"source_sha256": bench.kernel_source_hash(), "sources": list(bench.KERNEL_SOURCES)}
+    mix = None
+    if "--mix" in sys.argv:
+        a, b, c = (float(x) for x in sys.argv[sys.argv.index("--mix") + 1].split(","))
+        mix = {"plain": a, "vop3_sdwa": b, "mad_u64": c}
+    for name, key, workload in (("pmc_default.txt", "k_emit_philox", "bench.py default (minimal-short 150 bp PE, 100 Mbp, 100 M reads, counter mode)"),
+                                ("pmc_perfect.txt", "k_emit_perfect_pe", "bench.py --profile perfect-short"),
+                                ("pmc_custom_long.txt", "k_custom_long_splice", "bench.py --profile custom-long --reads 1000000")):
+        f = src / name
+        if f.exists():
+            out[key] = record(read(f), workload, "separate --pmc passes of the bench command with --steps 1 --warmup 0 "
+                                                 "(tools/profile_round.sh), per launch")
+            if key == "k_emit_philox" and mix:
+                out[key]["valu_class_mix"] = mix
+    dst = ROOT / "profiles" / "r3" / "pmc_traffic.json"
+    dst.parent.mkdir(parents=True, exist_ok=True)
+    dst.write_text(json.dumps(out, indent=1) + "\n")
+    print(dst, out["source_sha256"][:12])
+
+
+if __name__ == "__main__":
+    main()

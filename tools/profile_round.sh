@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's rocprofv3 evidence in one go (run on the GPU box through gpurun): per-kernel stats of the bench
 # commands and the PMC passes of the default and perfect-short benches.  Output: gpurun_out/prof_<tag>/ .
-tag="${1:-r2}"; out="gpurun_out/prof_$tag"; mkdir -p "$out"
+tag="${1:-r3}"; out="gpurun_out/prof_$tag"; mkdir -p "$out"
 export TMPDIR=/tmp
 stats() {  # name, bench args...
   name="$1"; shift
