@@ -1407,7 +1407,11 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
         // one workgroup of 1024 lanes per CU around the LDS count table (kernels.hip section 9c)
         auto kern = exc ? k_custom_long_splice<true, true> : k_custom_long_splice<false, true>;
         const uint32_t lds = splice_fast_lds_bytes(e->prof.custom.kmer_size);
-        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static bool attr_set[2] = {false, false};  // once per kernel variant and process, not once per emit
+        if (!attr_set[exc ? 1 : 0]) {
+          HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          attr_set[exc ? 1 : 0] = true;
+        }
         const uint32_t fgrid = (uint32_t)std::min<uint64_t>((n_reads + SPLICE_FAST_LANES - 1) / SPLICE_FAST_LANES, (uint64_t)e->n_cu * 8);
         hipLaunchKernelGGL(kern, dim3(fgrid), dim3(SPLICE_FAST_LANES), lds, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
                            n_units, order, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),

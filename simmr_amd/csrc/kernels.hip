@@ -1958,11 +1958,12 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
 // (no table lookups), SIMMR_ABLATE_STORES (no global stores of bases / qualities), SIMMR_ABLATE_CODES
 // (no load from the reference plane), SIMMR_ABLATE_META (no metadata columns), SIMMR_ABLATE_ITEMS (one
 // round of items per block), SIMMR_ABLATE_ALL16 / SIMMR_ABLATE_ALIGN16 (partial groups stored as
-// 16 bytes / every store aligned down to 16 bytes: wrong bytes, inside the buffers), SIMMR_ABLATE_NOP
+// 16 bytes, except the shard's last ones / every store aligned down to 16 bytes: wrong bytes, inside the buffers), SIMMR_ABLATE_NOP
 // (without the wait states between the compare and the select), SIMMR_ABLATE_HOTSTORE (the same store
 // instructions, all landing in the first 64 KB of the two streams: store issue without the DRAM write
-// path), SIMMR_ABLATE_LINES (every store instruction of a wave writes sixteen whole 64-byte lines).  None
-// of them changes an index, a pointer into a table or a loop bound.
+// path), SIMMR_ABLATE_LINES (every store instruction of a wave writes sixteen whole 64-byte lines, clamped to the
+// streams' total_bases).  None of them changes an index, a pointer into a table or a loop bound; the two that
+// move stores are bounded by the planned size (tests/test_gpu_shapes.py runs them between canaries when built).
 // ===========================================================================
 SIMMR_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
@@ -2285,17 +2286,17 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         for (int g4 = 0; g4 < 4; g4++) {
           const uint32_t w0 = w[3 * g4], w1 = w[3 * g4 + 1], w2 = w[3 * g4 + 2];
           const uint32_t R[4] = {w0 << 8, __builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 8), w2};
+          uint32_t x[4];
 #pragma unroll
           for (int h = 0; h < 4; h++) {
-            const uint32_t x = philox_pick(R[h], jtab);
-            ss = __builtin_amdgcn_alignbit(x, ss, 2);  // ascending, so base j ends at bits 2j of ss
-            ea |= x;
-            // byte h of qr[g4] = enc(q) = byte 1 of x
-            if (h == 0) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[g4]) : "v"(x));
-            else if (h == 1) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[g4]) : "v"(x));
-            else if (h == 2) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[g4]) : "v"(x));
-            else asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(qr[g4]) : "v"(x));
+            x[h] = philox_pick(R[h], jtab);
+            ss = __builtin_amdgcn_alignbit(x[h], ss, 2);  // ascending, so base j ends at bits 2j of ss
+            ea |= x[h];
           }
+          // the four quality bytes (byte 1 of each x) with two v_perm_b32 and an or: no SDWA write into a partly
+          // preserved register (four of those in a row on one VGPR need a wait state each on gfx940+, which the
+          // compiler cannot see inside asm statements)
+          qr[g4] = __builtin_amdgcn_perm(x[1], x[0], 0x0c0c0501u) | __builtin_amdgcn_perm(x[3], x[2], 0x05010c0cu);
         }
         if (ea & 4u) philox_repair(k0, k1, ci, prof.philox_t1, prof.philox_t2, qoff, ss, qr);
       }
@@ -2347,9 +2348,17 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #else
 #if defined(SIMMR_ABLATE_LINES)
       // timing only: every 16-byte store instruction of a wave writes sixteen WHOLE 64-byte lines (the wave's first
-      // lane's place rounded down to 1 KB, then lane by lane); wrong places, inside the buffers
-      uint8_t* qd = qual + (((uint64_t)__builtin_amdgcn_readfirstlane(o_q) + out0) & ~1023ull) + 16u * (threadIdx.x & 63u);
-      uint8_t* sd = seq + (((uint64_t)__builtin_amdgcn_readfirstlane(o_s) + out0) & ~1023ull) + 16u * (threadIdx.x & 63u);
+      // lane's place rounded down to 1 KB, then lane by lane); wrong places, and clamped so that the 1 KB stays
+      // inside the total_bases bytes of the streams (a shard of less than 1 KB writes nothing at all)
+      const uint64_t abl_total = u_off[n_units];
+      const uint64_t abl_last = abl_total >= 1024u ? ((abl_total - 1024u) & ~1023ull) : 0u;
+      uint64_t abl_q = ((uint64_t)__builtin_amdgcn_readfirstlane(o_q) + out0) & ~1023ull;
+      uint64_t abl_s = ((uint64_t)__builtin_amdgcn_readfirstlane(o_s) + out0) & ~1023ull;
+      abl_q = abl_q < abl_last ? abl_q : abl_last;
+      abl_s = abl_s < abl_last ? abl_s : abl_last;
+      if (abl_total < 1024u) continue;
+      uint8_t* qd = qual + abl_q + 16u * (threadIdx.x & 63u);
+      uint8_t* sd = seq + abl_s + 16u * (threadIdx.x & 63u);
 #elif defined(SIMMR_ABLATE_HOTSTORE)
       // timing only: every store lands in the first 64 KB of the buffers (same instructions, no DRAM write traffic)
       uint8_t* qd = qual + ((o_q + (uint32_t)out0) & 0xffffu);
@@ -2364,8 +2373,12 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #endif
       if (TEXT && ci == 0u)  // "\n+\n" and, once more, the first quality
         *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(qd - 3) = 0x000a2b0au | ((uint32_t)q_lo << 24);
-#if defined(SIMMR_ABLATE_ALL16)
-      if (true) {  // timing only: partial groups store 16 bytes too (they overwrite the head of the next read)
+#if defined(SIMMR_ABLATE_ALL16) && defined(SIMMR_ABLATE_LINES)
+      if (true) {  // timing only (the clamped whole-line places above hold 16 bytes for every lane)
+#elif defined(SIMMR_ABLATE_ALL16)
+      // timing only: partial groups store 16 bytes too (they overwrite the head of the next read) — except where those
+      // 16 bytes would leave the streams: the last groups of the shard keep their exact stores
+      if (n == 16u || (uint64_t)(o_q > o_s ? o_q : o_s) + out0 + 16u <= u_off[n_units]) {
 #else
       if (n == 16u) {
 #endif

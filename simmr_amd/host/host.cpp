@@ -387,7 +387,7 @@ std::string usage() {
          "  --seed <N>                    Random seed\n"
          "  --size-adjusted               Adjust by genome size\n"
          "  --contiguous                  Treat separate sequences in a genome as one contiguous sequence\n"
-         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths  --uniform-start  --host-fastq  --host-normalize\n";
+         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths  --uniform-start  --host-fastq  --host-normalize  --device-chunk-reads <N>\n";
 }
 
 static bool parse_u64(const std::string& s, uint64_t max, uint64_t* out) {
@@ -447,6 +447,7 @@ bool parse_cli_args(int argc, const char* const* argv, CliArgs* a, std::string* 
     else if (arg == "--contiguous") a->contiguous = true;
     else if (arg == "--host-fastq") a->host_fastq = true;
     else if (arg == "--host-normalize") a->host_normalize = true;
+    else if (arg == "--device-chunk-reads") { if (!need(&v) || !parse_u64(v, UINT64_MAX, &u) || u == 0) { *err = "invalid value for --device-chunk-reads"; return false; } a->device_chunk_reads = u; }
     else if (arg == "--device") { if (!need(&v) || !parse_u64(v, 1023, &u)) { *err = "invalid value for --device"; return false; } a->device = (int)u; }
     else if (arg == "--gamma") {
       if (!need(&v)) return false;

@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -52,54 +53,170 @@ struct DeviceOut {
   }
 };
 
-// FASTQ text built on the device (simmr_fastq_plan / simmr_fastq_emit), appended to `output`.
-// Returns 1 when the library leaves this input to the host writer (SIMMR_ENOTSUP), -1 on error.
-static int write_fastq_device(simmr_engine* eng, const std::string& fmt, const std::vector<Genome>& genomes, size_t g0,
-                              size_t g1, const simmr_reads_out& reads, uint64_t n_reads, bool paired,
-                              const std::string& output, std::string* err) {
-  std::vector<uint32_t> idx, ncontigs;
-  std::vector<const char*> gids, sids;
-  for (size_t gi = g0; gi < g1; gi++) {
-    idx.push_back((uint32_t)gi);
-    gids.push_back(genomes[gi].uuid.c_str());
-    ncontigs.push_back((uint32_t)genomes[gi].sequence.size());
-    for (const Seq& s : genomes[gi].sequence) sids.push_back(s.id.c_str());
-  }
-  const simmr_fastq_names names{(uint32_t)idx.size(), idx.data(), gids.data(), ncontigs.data(), sids.data()};
-  uint64_t total = 0;
-  int rc = simmr_fastq_plan(eng, fmt.c_str(), &names, &reads, n_reads, paired ? 1 : 0, &total);
-  if (rc == SIMMR_ENOTSUP) return 1;
-  if (rc != SIMMR_OK) { *err = simmr_last_error(eng); return -1; }
-  void* dev = nullptr;
-  // no room for the framed text next to the reads (it is about 1.2 x their size): not the reference's failure mode,
-  // so no output may be lost over it — the host writer takes over
-  if (hipMalloc(&dev, total ? total : 1) != hipSuccess) { (void)hipGetLastError(); return 1; }
-  rc = simmr_fastq_emit(eng, &reads, (uint8_t*)dev, total);
-  if (rc != SIMMR_OK) { *err = simmr_last_error(eng); (void)hipFree(dev); return -1; }
-  FILE* f = fopen(output.c_str(), "ab");
-  if (!f) { *err = "cannot open " + output; (void)hipFree(dev); return -1; }
-  // drain through two pinned buffers: the copy of chunk i + 1 runs while chunk i is written to the file
-  const size_t chunk = 256u << 20;
+// ---- output of one planned range ------------------------------------------------------------------------------------
+// A run is generated range by range of its units (pairs / long reads): the reference holds every read of a run in RAM
+// before it writes (main.rs:180-206, readme.md:219-220); here a range is what fits the device next to the reference
+// (--device-chunk-reads, or a share of the free memory), and the FASTQ text of range k is copied out and written
+// while range k + 1 is planned and emitted.  The text of a range comes straight from its plan
+// (simmr_fastq_plan_direct / simmr_emit_fastq: no SoA columns in between).
+struct TextDrain {
+  // two device buffers for the text and two pinned buffers for the copy out; the file is appended to in order
+  void* dev[2] = {nullptr, nullptr};
+  uint64_t cap[2] = {0, 0}, len[2] = {0, 0};
   void* pin[2] = {nullptr, nullptr};
   hipStream_t cs = nullptr;
-  bool ok = hipHostMalloc(&pin[0], chunk, hipHostMallocDefault) == hipSuccess &&
-            hipHostMalloc(&pin[1], chunk, hipHostMallocDefault) == hipSuccess && hipStreamCreate(&cs) == hipSuccess &&
-            hipDeviceSynchronize() == hipSuccess;
-  const uint64_t n_chunks = (total + chunk - 1) / chunk;
-  auto len_of = [&](uint64_t i) { return (size_t)std::min<uint64_t>(chunk, total - i * chunk); };
-  if (ok && n_chunks > 0) ok = hipMemcpyAsync(pin[0], (const char*)dev, len_of(0), hipMemcpyDeviceToHost, cs) == hipSuccess;
-  for (uint64_t i = 0; ok && i < n_chunks; i++) {
-    ok = hipStreamSynchronize(cs) == hipSuccess;  // chunk i is in pin[i & 1]
-    if (ok && i + 1 < n_chunks)
-      ok = hipMemcpyAsync(pin[(i + 1) & 1], (const char*)dev + (i + 1) * chunk, len_of(i + 1), hipMemcpyDeviceToHost, cs) == hipSuccess;
-    if (ok && fwrite(pin[i & 1], 1, len_of(i), f) != len_of(i)) { *err = "short write to " + output; ok = false; }
+  hipEvent_t emitted = nullptr;
+  FILE* f = nullptr;
+  static constexpr size_t CHUNK = 256u << 20;
+  int pending = -1;  // buffer whose text still has to go to the file
+  bool open(const std::string& output, std::string* err) {
+    f = fopen(output.c_str(), "ab");
+    if (!f) { *err = "cannot open " + output; return false; }
+    if (hipHostMalloc(&pin[0], CHUNK, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&pin[1], CHUNK, hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&emitted, hipEventDisableTiming) != hipSuccess) {
+      *err = "pinned buffer / stream allocation failed";
+      return false;
+    }
+    return true;
   }
-  if (!ok && err->empty()) *err = "copy back failed";
-  fclose(f);
-  if (cs) (void)hipStreamDestroy(cs);
-  for (void* q : pin) if (q) (void)hipHostFree(q);
-  (void)hipFree(dev);
-  return ok ? 0 : -1;
+  // a device buffer of at least `bytes` for the next range; the buffer is free again: its previous text was drained
+  // two ranges ago.  nullptr if the device has no room.
+  uint8_t* buffer(int b, uint64_t bytes) {
+    if (cap[b] < bytes) {
+      if (dev[b]) (void)hipFree(dev[b]);
+      dev[b] = nullptr; cap[b] = 0;
+      if (hipMalloc(&dev[b], bytes + bytes / 16 + 256) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      cap[b] = bytes + bytes / 16 + 256;
+    }
+    return (uint8_t*)dev[b];
+  }
+  // the text in buffer b (written by work queued on the null stream up to now) goes to the file; returns at once after
+  // queueing the first copy, the rest happens in flush()
+  bool submit(int b, uint64_t bytes, std::string* err) {
+    if (!flush(err)) return false;
+    len[b] = bytes;
+    if (hipEventRecord(emitted, nullptr) != hipSuccess || hipStreamWaitEvent(cs, emitted, 0) != hipSuccess) { *err = "event failed"; return false; }
+    if (bytes > 0 && hipMemcpyAsync(pin[0], dev[b], std::min<uint64_t>(CHUNK, bytes), hipMemcpyDeviceToHost, cs) != hipSuccess) { *err = "copy back failed"; return false; }
+    pending = b;
+    return true;
+  }
+  // write the pending text: the copy of chunk i + 1 runs while chunk i is written to the file
+  bool flush(std::string* err) {
+    if (pending < 0) return true;
+    const int b = pending;
+    pending = -1;
+    const uint64_t total = len[b], n_chunks = (total + CHUNK - 1) / CHUNK;
+    auto len_of = [&](uint64_t i) { return (size_t)std::min<uint64_t>(CHUNK, total - i * CHUNK); };
+    for (uint64_t i = 0; i < n_chunks; i++) {
+      if (hipStreamSynchronize(cs) != hipSuccess) { *err = "copy back failed"; return false; }  // chunk i is in pin[i & 1]
+      if (i + 1 < n_chunks && hipMemcpyAsync(pin[(i + 1) & 1], (const char*)dev[b] + (i + 1) * CHUNK, len_of(i + 1), hipMemcpyDeviceToHost, cs) != hipSuccess) {
+        *err = "copy back failed";
+        return false;
+      }
+      if (fwrite(pin[i & 1], 1, len_of(i), f) != len_of(i)) { *err = "short write"; return false; }
+    }
+    return true;
+  }
+  ~TextDrain() {
+    if (f) fclose(f);
+    if (cs) (void)hipStreamDestroy(cs);
+    if (emitted) (void)hipEventDestroy(emitted);
+    for (void* q : pin) if (q) (void)hipHostFree(q);
+    for (void* q : dev) if (q) (void)hipFree(q);
+  }
+};
+
+struct NameTables {  // simmr_fastq_names of genomes [g0, g1)
+  std::vector<uint32_t> idx, ncontigs;
+  std::vector<const char*> gids, sids;
+  simmr_fastq_names names{};
+  NameTables(const std::vector<Genome>& genomes, size_t g0, size_t g1) {
+    for (size_t gi = g0; gi < g1; gi++) {
+      idx.push_back((uint32_t)gi);
+      gids.push_back(genomes[gi].uuid.c_str());
+      ncontigs.push_back((uint32_t)genomes[gi].sequence.size());
+      for (const Seq& s : genomes[gi].sequence) sids.push_back(s.id.c_str());
+    }
+    names = simmr_fastq_names{(uint32_t)idx.size(), idx.data(), gids.data(), ncontigs.data(), sids.data()};
+  }
+};
+
+// One scope of the run = one plan function over a range of units: all genomes' pairs in one plan, one genome's pairs
+// (custom profiles), or all long reads.  `genome_units[g - g0]` = units of genome g, in generation order.
+struct Scope {
+  bool paired;
+  size_t g0, g1;
+  std::vector<uint64_t> genome_units;
+  uint32_t id_base;
+  // plans units [first, first + count) of the scope; SIMMR_* code
+  std::function<int(simmr_range, simmr_plan_info*)> plan;
+  std::function<int(uint32_t, const simmr_reads_out*)> emit;  // columns (host writer only)
+};
+
+// Generates the scope range by range and appends its FASTQ to args.output.  0, or 1 after die().
+static int run_scope(simmr_engine* eng, const CliArgs& args, const std::vector<Genome>& genomes, const Scope& sc, uint64_t chunk_units) {
+  uint64_t total_units = 0;
+  for (uint64_t u : sc.genome_units) total_units += u;
+  const uint32_t rpu = sc.paired ? 2u : 1u;
+  if (chunk_units == 0 || chunk_units > total_units) chunk_units = std::max<uint64_t>(total_units, 1);
+  NameTables nt(genomes, sc.g0, sc.g1);
+  std::string err;
+  bool use_device_text = !args.host_fastq;
+  TextDrain drain;
+  if (use_device_text && !drain.open(args.output, &err)) return die(err);
+  int buf = 0;
+  for (uint64_t first = 0; first < total_units || (first == 0 && total_units == 0); first += chunk_units) {
+    const simmr_range rg{first, std::min<uint64_t>(chunk_units, total_units - first)};
+    simmr_plan_info pi{};
+    if (sc.plan(rg, &pi) != SIMMR_OK) return die(simmr_last_error(eng));  // the reference unwrap()s this Err (simulate.rs:137)
+    bool written = false;
+    if (use_device_text) {
+      uint64_t bytes = 0;
+      const int rc = simmr_fastq_plan_direct(eng, args.read_header_format.c_str(), &nt.names, sc.id_base, &bytes);
+      if (rc == SIMMR_ENOTSUP) {
+        use_device_text = false;  // an id with a brace, a header over 255 bytes: the host writer frames this run
+        if (!drain.flush(&err)) return die(err);
+        fclose(drain.f); drain.f = nullptr;
+      } else if (rc != SIMMR_OK) {
+        return die(simmr_last_error(eng));
+      } else {
+        uint8_t* dst = drain.buffer(buf, bytes);
+        if (!dst) return die("no device memory for " + std::to_string(bytes) + " bytes of FASTQ text: use a smaller --device-chunk-reads");
+        if (simmr_emit_fastq(eng, dst, bytes) != SIMMR_OK) return die(simmr_last_error(eng));
+        if (!drain.submit(buf, bytes, &err)) { fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str()); }
+        buf ^= 1;
+        written = true;
+      }
+    }
+    if (!written) {  // columns to the host, framed by the restatement of fastq.rs in host.cpp, genome by genome
+      DeviceOut d;
+      if (!d.init(pi.n_reads, pi.total_bases)) return die("device allocation failed");
+      if (sc.emit(sc.id_base, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
+      HostReads h;
+      if (!d.to_host(pi.n_reads, pi.total_bases, sc.paired, &h)) return die("copy back failed");
+      uint64_t g_first = 0;  // first unit of genome gi in the scope
+      for (size_t gi = sc.g0; gi < sc.g1; gi++) {
+        const uint64_t g_units = sc.genome_units[gi - sc.g0];
+        const uint64_t lo = std::max(first, g_first), hi = std::min(first + rg.count, g_first + g_units);
+        if (hi > lo &&
+            !write_to_fastq(genomes[gi].uuid, genomes[gi], h, (lo - first) * rpu, (hi - lo) * rpu, args.output, args.read_header_format, true, &err))
+          fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+        g_first += g_units;
+      }
+    }
+    if (total_units == 0) break;
+  }
+  if (use_device_text && !drain.flush(&err)) fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+  return 0;
+}
+
+// units per range when --device-chunk-reads is not given: what a third of the free device memory holds, at
+// `text_bytes_per_unit` of FASTQ text (two buffers) plus the plan's columns per unit
+static uint64_t auto_chunk_units(uint64_t text_bytes_per_unit) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  const uint64_t per_unit = 2 * text_bytes_per_unit + 96;
+  return std::max<uint64_t>((uint64_t)free_b / 3 / per_unit, 1024);
 }
 
 // Genome::from_fasta (genome.rs:89-162) with the sequences going straight to the device: the host only finds
@@ -267,80 +384,71 @@ static int run_main(int argc, char** argv) {
   const simmr_error_profile pod = eprofile->pod();
   const int has_seed = args.seed ? 1 : 0;
   const uint64_t seed = args.seed.value_or(0);
-  const simmr_range all{0, UINT64_MAX};
 
+  const uint64_t chunk_reads = args.device_chunk_reads;
   if (!is_long) {
     info("Simulating short reads");
+    const uint64_t text_per_pair = 2 * (2 * (uint64_t)args.read_length + 4 + 160);
+    const uint64_t chunk_units = chunk_reads ? std::max<uint64_t>(chunk_reads / 2, 1) : auto_chunk_units(text_per_pair);
     // all genomes in one device plan (simulate_pe_reads, simulate.rs:110-150); the library leaves
     // custom profiles to the genome-by-genome loop below
     std::vector<uint32_t> all_idx(genomes.size());
     std::vector<uint64_t> all_reads(genomes.size());
     for (size_t gi = 0; gi < genomes.size(); gi++) { all_idx[gi] = (uint32_t)gi; all_reads[gi] = ab[gi].first; }
-    simmr_plan_info mpi{};
-    const int mrc = simmr_pe_plan_multi(eng, (uint32_t)genomes.size(), all_idx.data(), all_reads.data(), &pod, has_seed, seed, all, &mpi);
+    simmr_plan_info probe{};
+    const int mrc = simmr_pe_plan_multi(eng, (uint32_t)genomes.size(), all_idx.data(), all_reads.data(), &pod, has_seed, seed,
+                                        simmr_range{0, 0}, &probe);  // (an empty range: does the library take this profile in one plan?)
     if (mrc != SIMMR_OK && mrc != SIMMR_ENOTSUP) return die(simmr_last_error(eng));
+    // without --seed every plan call would draw its own seed (simulate.rs:174): draw the run's here, so that the ranges
+    // of one genome continue one stream
+    const uint64_t run_seed = has_seed ? seed : probe.seed_used;
     if (mrc == SIMMR_OK) {
-      DeviceOut d;
-      if (!d.init(mpi.n_reads, mpi.total_bases)) return die("device allocation failed");
-      if (simmr_pe_emit(eng, 0, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
-      int fq = args.host_fastq ? 1 : write_fastq_device(eng, args.read_header_format, genomes, 0, genomes.size(), d.o, mpi.n_reads,
-                                                      true, args.output, &err);
-      if (fq < 0) fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
-      if (fq > 0) {  // host writer (fastq.rs restated in host.cpp), genome by genome
-        HostReads h;
-        if (!d.to_host(mpi.n_reads, mpi.total_bases, true, &h)) return die("copy back failed");
-        uint64_t first_read = 0;
-        for (size_t gi = 0; gi < genomes.size(); gi++) {
-          const uint64_t n = ab[gi].first / 2 * 2;
-          if (!write_to_fastq(genomes[gi].uuid, genomes[gi], h, first_read, n, args.output, args.read_header_format, true, &err))
-            fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
-          first_read += n;
-        }
-      }
+      Scope sc{true, 0, genomes.size(), {}, 0, nullptr, nullptr};
+      for (size_t gi = 0; gi < genomes.size(); gi++) sc.genome_units.push_back(ab[gi].first / 2);  // simulate.rs:179
+      sc.plan = [&](simmr_range rg, simmr_plan_info* pi) {
+        return simmr_pe_plan_multi(eng, (uint32_t)genomes.size(), all_idx.data(), all_reads.data(), &pod, 1, run_seed, rg, pi);
+      };
+      sc.emit = [&](uint32_t idb, const simmr_reads_out* o) { return simmr_pe_emit(eng, idb, o); };
+      if (int rc = run_scope(eng, args, genomes, sc, chunk_units)) return rc;
     }
     uint32_t id_base = 0;  // the global AtomicU32 of simulate.rs:85-89
     for (size_t gi = 0; mrc == SIMMR_ENOTSUP && gi < genomes.size(); gi++) {
-      simmr_plan_info pi{};
-      if (simmr_pe_plan(eng, (uint32_t)gi, &pod, ab[gi].first, has_seed, seed, all, &pi) != SIMMR_OK)
-        return die(simmr_last_error(eng));  // the reference unwrap()s this Err (simulate.rs:137)
-      DeviceOut d;
-      if (!d.init(pi.n_reads, pi.total_bases)) return die("device allocation failed");
-      if (simmr_pe_emit(eng, id_base, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
-      int fq = args.host_fastq ? 1 : write_fastq_device(eng, args.read_header_format, genomes, gi, gi + 1, d.o, pi.n_reads, true,
-                                                      args.output, &err);
-      if (fq < 0) fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
-      if (fq > 0) {  // host writer (fastq.rs restated in host.cpp)
-        HostReads h;
-        if (!d.to_host(pi.n_reads, pi.total_bases, true, &h)) return die("copy back failed");
-        if (!write_to_fastq(genomes[gi].uuid, genomes[gi], h, 0, pi.n_reads, args.output, args.read_header_format, true, &err))
-          fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+      // the reference draws a fresh entropy seed per genome when there is no --seed (simulate.rs:174)
+      uint64_t g_seed = seed;
+      if (!has_seed) {
+        simmr_plan_info p0{};
+        if (simmr_pe_plan(eng, (uint32_t)gi, &pod, ab[gi].first, 0, 0, simmr_range{0, 0}, &p0) != SIMMR_OK) return die(simmr_last_error(eng));
+        g_seed = p0.seed_used;
       }
-      id_base += (uint32_t)pi.n_units;
+      Scope sc{true, gi, gi + 1, {ab[gi].first / 2}, id_base, nullptr, nullptr};
+      sc.plan = [&, gi, g_seed](simmr_range rg, simmr_plan_info* pi) { return simmr_pe_plan(eng, (uint32_t)gi, &pod, ab[gi].first, 1, g_seed, rg, pi); };
+      sc.emit = [&](uint32_t idb, const simmr_reads_out* o) { return simmr_pe_emit(eng, idb, o); };
+      if (int rc = run_scope(eng, args, genomes, sc, chunk_units)) return rc;
+      id_base += (uint32_t)(ab[gi].first / 2);
     }
   } else {
     info("Simulating long reads");
     std::vector<uint32_t> idx(genomes.size());
     std::vector<uint64_t> reads(genomes.size());
     for (size_t gi = 0; gi < genomes.size(); gi++) { idx[gi] = (uint32_t)gi; reads[gi] = ab[gi].first; }
-    simmr_plan_info pi{};
-    if (simmr_long_plan(eng, (uint32_t)genomes.size(), idx.data(), reads.data(), &pod, has_seed, seed, all, &pi) != SIMMR_OK)
-      return die(simmr_last_error(eng));
-    DeviceOut d;
-    if (!d.init(pi.n_reads, pi.total_bases)) return die("device allocation failed");
-    if (simmr_long_emit(eng, 0, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
-    int fq = args.host_fastq ? 1 : write_fastq_device(eng, args.read_header_format, genomes, 0, genomes.size(), d.o, pi.n_reads,
-                                                    false, args.output, &err);
-    if (fq < 0) fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
-    if (fq > 0) {
-      HostReads h;
-      if (!d.to_host(pi.n_reads, pi.total_bases, false, &h)) return die("copy back failed");
-      uint64_t first = 0;
-      for (size_t gi = 0; gi < genomes.size(); gi++) {
-        if (!write_to_fastq(genomes[gi].uuid, genomes[gi], h, first, reads[gi], args.output, args.read_header_format, true, &err))
-          fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
-        first += reads[gi];
-      }
+    uint64_t run_seed = seed;
+    if (!has_seed) {
+      simmr_plan_info p0{};
+      if (simmr_long_plan(eng, (uint32_t)genomes.size(), idx.data(), reads.data(), &pod, 0, 0, simmr_range{0, 0}, &p0) != SIMMR_OK)
+        return die(simmr_last_error(eng));
+      run_seed = p0.seed_used;
     }
+    // a long read is up to 65 535 bases (u16 lengths); the gamma profiles average 20 000 (minimal_long.rs:64-65)
+    const uint64_t chunk_units = chunk_reads ? chunk_reads : auto_chunk_units(2 * 24000 + 260);
+    Scope sc{false, 0, genomes.size(), reads, 0, nullptr, nullptr};
+    sc.plan = [&](simmr_range rg, simmr_plan_info* pi) {
+      // (without --seed the library selects per-read lengths by itself; the ranges then share the seed drawn above)
+      simmr_error_profile p = pod;
+      if (!has_seed) p.length_mode = SIMMR_LEN_PER_READ;
+      return simmr_long_plan(eng, (uint32_t)genomes.size(), idx.data(), reads.data(), &p, 1, run_seed, rg, pi);
+    };
+    sc.emit = [&](uint32_t idb, const simmr_reads_out* o) { return simmr_long_emit(eng, idb, o); };
+    if (int rc = run_scope(eng, args, genomes, sc, chunk_units)) return rc;
   }
   info(("Writing simulated reads to " + args.output).c_str());
 

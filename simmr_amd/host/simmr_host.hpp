@@ -193,6 +193,7 @@ struct CliArgs {  // cli.rs:93-220, same flags and defaults
   int device = 0;
   bool host_normalize = false;  // --host-normalize: normalise FASTA on the host instead of the device
   bool host_fastq = false;  // --host-fastq: frame the FASTQ on the host instead of the device
+  uint64_t device_chunk_reads = 0;  // --device-chunk-reads: reads generated per device pass (0: what fits the free device memory)
   std::optional<std::pair<float, float>> gamma;  // --gamma mean,std
   bool uniform_start = false;                    // --uniform-start (SIMMR_START_UNIFORM)
   bool per_read_lengths = false;                 // --per-read-lengths (SIMMR_LEN_PER_READ)

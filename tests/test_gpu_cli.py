@@ -205,3 +205,38 @@ def test_cli_device_and_host_normalize_agree(workdir, tmp_path):
                                    "--error-profile", "minimal-short"] + extra_common + extra)
             outs.append(out.read_bytes())
         assert len(outs[0]) > 900_000 and outs[0] == outs[1]
+
+
+def test_cli_device_chunks_do_not_change_the_output(workdir):
+    """--device-chunk-reads: a run generated range by range (here a thousand, 334 and 7 reads at a time — the production
+    default is what fits the free device memory) writes the same FASTQ and metadata as the run generated in one pass:
+    perfect-short, minimal-short in both generators' modes, a custom short-read model (planned genome by genome),
+    long reads with a seed (one run-wide length, simulate.rs:358) and per-read lengths, and a custom long-read model
+    with abundances (BASELINE config 5's shape); with the device text and with the host writer."""
+    from tests import _model
+    d, _ = workdir
+    (d / "long_model2.bin").write_bytes(_model.synthetic_long_model(kmer_size=6, n_positions=400, seed=8, n_kmers=4 ** 6, lengths=(1500, 6000, 100)))
+    (d / "short_model2.bin").write_bytes(_model.synthetic_short_model())
+    (d / "abund2.tsv").write_text("path\tid\tabundance\n" + f"{d}/g0.fna\tgA\t0.7\n{d}/g1.fna\tgB\t0.3\n")
+    runs = [
+        (["--genome-file", str(d / "genomes.tsv"), "--num-reads", "5001", "--seed", "7", "--error-profile", "perfect-short"], ["1000", "334"]),
+        (["--genome-file", str(d / "genomes.tsv"), "--num-reads", "5001", "--seed", "7", "--error-profile", "minimal-short"], ["1000", "7"]),
+        (["--genome-file", str(d / "genomes.tsv"), "--num-reads", "3000", "--seed", "7", "--error-profile", "minimal-short", "--host-fastq"], ["1000"]),
+        # (genome ids from the TSV: a genome given with --genome gets a random uuid per run, util.rs:124-129)
+        (["--genome-file", str(d / "genomes.tsv"), "--num-reads", "1200", "--seed", "3", "--error-profile", "custom-short",
+          "--custom-profile", str(d / "short_model2.bin")], ["334"]),
+        (["--genome-file", str(d / "genomes.tsv"), "--num-reads", "61", "--seed", "11", "--error-profile", "minimal-long"], ["7"]),
+        (["--genome-file", str(d / "genomes.tsv"), "--num-reads", "61", "--seed", "11", "--error-profile", "perfect-long",
+          "--per-read-lengths", "--gamma", "3000,2500"], ["7", "20"]),
+        (["--genome-file", str(d / "abund2.tsv"), "--num-reads", "41", "--seed", "19", "--error-profile", "custom-long",
+          "--custom-profile", str(d / "long_model2.bin"), "--abundance-profile", "custom"], ["7"]),
+    ]
+    for i, (argv, chunks) in enumerate(runs):
+        whole = d / f"chunk_ref_{i}.fq"
+        subprocess.check_call([str(EXE), "--output", str(whole), "--device-chunk-reads", "1000000000"] + argv)
+        assert whole.stat().st_size > 0
+        for c in chunks:
+            out = d / f"chunk_{i}_{c}.fq"
+            subprocess.check_call([str(EXE), "--output", str(out), "--device-chunk-reads", c] + argv)
+            assert out.read_bytes() == whole.read_bytes(), (argv, c)
+            assert (d / f"chunk_{i}_{c}.fq.tsv").read_text() == (d / f"chunk_ref_{i}.fq.tsv").read_text()

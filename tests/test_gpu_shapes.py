@@ -13,6 +13,8 @@ from simmr_amd.simulate import GenomeRef, determine_reads, split_range
 from tests import _oracle, _synth
 from tests.test_gpu_fullsize import checksum_range, colsum256
 
+ROOT = __import__("pathlib").Path(__file__).resolve().parent.parent
+
 pytestmark = pytest.mark.gpu
 
 
@@ -288,3 +290,43 @@ def test_emit_stays_inside_exact_capacity(engine, genome_multi, path, monkeypatc
     finally:
         if eng is not engine:
             eng.close()
+
+
+@pytest.mark.parametrize("variant", ["ablate_lines", "ablate_all16"])
+def test_store_moving_ablation_builds_stay_inside_the_streams(variant):
+    """The two measurement builds of k_emit_philox that MOVE stores (make -C simmr_amd/csrc ablate: whole-line stores,
+    partial groups as 16 bytes) write wrong bytes by design, but never outside the total_bases bytes of seq / qual: run
+    once between canaries of exactly that size, in a process of its own (the library is chosen per process).  Skipped
+    when the variant libraries are not built (they are not part of the product)."""
+    import subprocess
+    import sys
+    lib = ROOT / "simmr_amd" / "csrc" / "variants" / f"libsimmr_hip_{variant}.so"
+    if not lib.exists():
+        pytest.skip(f"{lib.name} is not built (make -C simmr_amd/csrc ablate)")
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from simmr_amd import MinimalShortErrorProfile, _abi
+from simmr_amd.engine import Engine, Reads
+eng = Engine(0)
+eng.stage_synthetic(0, [400_000], 5)
+for reads, L in ((2601, 41), (20001, 150), (9, 150), (3, 20)):
+    pod = MinimalShortErrorProfile(read_length=L, insert_size=60, rng_mode=_abi.RNG_PHILOX).pod()
+    info = eng.pe_plan(0, pod, reads, 7)
+    PAD, tb = 4096, int(info.total_bases)
+    r = Reads.allocate(info.n_reads, tb, eng.device, 33)
+    bufs = []
+    for name in ("seq", "qual"):
+        buf = torch.full((tb + 2 * PAD,), 0xA5, dtype=torch.uint8, device=eng.device)
+        setattr(r, name, buf[PAD:PAD + tb])
+        bufs.append(buf)
+    eng.pe_emit(0, r)
+    torch.cuda.synchronize()
+    for b in bufs:
+        assert bool((b[:PAD] == 0xA5).all()) and bool((b[PAD + tb:] == 0xA5).all()), (reads, L)
+print("inside")
+''' % str(ROOT)
+    import os
+    env = dict(os.environ, SIMMR_HIP_LIB=str(lib))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "inside" in out.stdout, out.stderr[-2000:]
