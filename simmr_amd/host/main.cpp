@@ -19,6 +19,7 @@ static void info(const char* msg) { fprintf(stderr, " INFO simmr-hip: %s\n", msg
 static void warn(const std::string& msg) { fprintf(stderr, " WARN simmr-hip: %s\n", msg.c_str()); }
 static int die(const std::string& msg) { fprintf(stderr, "ERROR simmr-hip: %s\n", msg.c_str()); return 1; }
 static bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+static bool is_regular_file(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
 
 struct DeviceOut {
   simmr_reads_out o{};
@@ -162,6 +163,7 @@ static int run_scope(simmr_engine* eng, const CliArgs& args, const std::vector<G
   NameTables nt(genomes, sc.g0, sc.g1);
   std::string err;
   bool use_device_text = !args.host_fastq;
+  uint64_t text_bytes = 0, n_ranges = 0;
   TextDrain drain;
   if (use_device_text && !drain.open(args.output, &err)) return die(err);
   int buf = 0;
@@ -186,6 +188,8 @@ static int run_scope(simmr_engine* eng, const CliArgs& args, const std::vector<G
         if (!drain.submit(buf, bytes, &err)) { fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str()); }
         buf ^= 1;
         written = true;
+        text_bytes += bytes;
+        n_ranges++;
       }
     }
     if (!written) {  // columns to the host, framed by the restatement of fastq.rs in host.cpp, genome by genome
@@ -207,6 +211,8 @@ static int run_scope(simmr_engine* eng, const CliArgs& args, const std::vector<G
     if (total_units == 0) break;
   }
   if (use_device_text && !drain.flush(&err)) fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
+  if (n_ranges > 1)
+    info((std::to_string(total_units * rpu) + " reads in " + std::to_string(n_ranges) + " device passes, " + std::to_string(text_bytes) + " bytes of FASTQ").c_str());
   return 0;
 }
 
@@ -377,7 +383,7 @@ static int run_main(int argc, char** argv) {
   if (aprofile->is_size_aware()) ab = aprofile->adjust_for_size(genomes, ab, is_long ? 20000 : args.read_length, !is_long);
 
   // main.rs:191-198: remove previous outputs
-  if (exists(args.output)) remove(args.output.c_str());
+  if (is_regular_file(args.output)) remove(args.output.c_str());  // (a pipe or a device given as the output is written to, not replaced)
   const std::string meta_path = args.output + ".tsv";
   if (exists(meta_path)) remove(meta_path.c_str());
 
