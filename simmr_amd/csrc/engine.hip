@@ -1383,8 +1383,12 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       } else {
         const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * e->philox_wgs_per_cu);
-        auto kern = cached ? (exc ? k_emit_philox<true, false, true> : k_emit_philox<false, false, true>)
-                           : (exc ? k_emit_philox<true, false, false> : k_emit_philox<false, false, false>);
+        // an escaped base is noticed through its quality byte when no real one has bit 7 set (kernels.hip: esc_q)
+        const bool escq = (out->qual_offset & 0xffu) + e->prof.philox_qmax <= 127u;
+        auto kern = escq ? (cached ? (exc ? k_emit_philox<true, false, true, false, true> : k_emit_philox<false, false, true, false, true>)
+                                   : (exc ? k_emit_philox<true, false, false, false, true> : k_emit_philox<false, false, false, false, true>))
+                         : (cached ? (exc ? k_emit_philox<true, false, true> : k_emit_philox<false, false, true>)
+                                   : (exc ? k_emit_philox<true, false, false> : k_emit_philox<false, false, false>));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
                            e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                            e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
@@ -1952,8 +1956,11 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
     else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
     const bool cached = paired && !e->plan_multi && e->plan_genome < e->genomes.size() &&
                         e->genomes[e->plan_genome].contigs.size() <= PHILOX_CBASE;
-    auto kern = cached ? (exc ? k_emit_philox<true, false, true, true> : k_emit_philox<false, false, true, true>)
-                       : (exc ? k_emit_philox<true, false, false, true> : k_emit_philox<false, false, false, true>);
+    const bool escq = 33u + e->prof.philox_qmax <= 127u;
+    auto kern = escq ? (cached ? (exc ? k_emit_philox<true, false, true, true, true> : k_emit_philox<false, false, true, true, true>)
+                               : (exc ? k_emit_philox<true, false, false, true, true> : k_emit_philox<false, false, false, true, true>))
+                     : (cached ? (exc ? k_emit_philox<true, false, true, true> : k_emit_philox<false, false, true, true>)
+                               : (exc ? k_emit_philox<true, false, false, true> : k_emit_philox<false, false, false, true>));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(),
                        e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome,
                        e->u_seed.as<uint64_t>(), dst, dst, 33u, e->plan_first, e->fq_read_id_base, OutCols{}, counters,

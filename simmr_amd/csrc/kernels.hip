@@ -7,6 +7,7 @@
 //   simmr/src/util.rs:15-37 (reverse complement), :69-111 (Phred conversions)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "device_types.hpp"
 #include "rng_device.hpp"
@@ -2096,7 +2097,8 @@ SIMMR_DEV void philox_repair(const uint32_t k0, const uint32_t k1, const uint32_
 // record starts at rec_off[rd] with a header of hlen[rd] bytes, so its bases start at rec_off[rd] + hlen[rd] + 1 and its
 // qualities L + 3 bytes further ("\n+\n"); the lane that holds a read's first qualities also writes those three bytes
 // (one 4-byte store that ends in its own first quality); headers and the other line ends are k_fastq_headers' job.
-template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false>
+// ESCQ: see `esc_q` below (the host checks the condition: qual_offset + philox_qmax <= 127)
+template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false, bool ESCQ = false>
 __global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
@@ -2117,6 +2119,11 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ uint32_t nmask2[17]; // the low 2n bits
   __shared__ uint32_t lds4[4];
   const uint32_t qoff = qual_offset & 0xffu;
+  // Where an escaped base (one item in 9 000) is noticed.  When every encoded quality the tables can answer is below
+  // 128 (the usual case: Phred + 33), an escape cell answers the byte 0xff and one test of the item's four quality
+  // words finds it; otherwise the answers carry a flag bit that is or-ed together base by base (sixteen more
+  // instructions per item).
+  constexpr bool esc_q = ESCQ;
   {
     const uint32_t t = threadIdx.x;
 #pragma unroll
@@ -2126,7 +2133,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint32_t A = e >> 16;
       uint32_t B = prof.philox_t1[1024u + c];
       if (T >= 16384u) { T = 0u; B = A; }
-      auto res = [&](uint32_t oc) { return oc == PHILOX_ESC ? ((qoff << 8) | 4u) : (((((oc & 0xffu) + qoff) & 0xffu) << 8) | (oc >> 8)); };
+      // an escape cell answers quality byte 0xff when no real answer has bit 7 set (esc_q), else flag bit 2 next to s
+      auto res = [&](uint32_t oc) { return oc == PHILOX_ESC ? (esc_q ? 0xff00u : ((qoff << 8) | 4u)) : (((((oc & 0xffu) + qoff) & 0xffu) << 8) | (oc >> 8)); };
       jtab[c] = make_uint2((c << 22) | (T << 8), res(A) | (res(B) << 16));
     }
     if (t <= 16u) {
@@ -2149,7 +2157,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     if (threadIdx.x < nc) cbase[threadIdx.x] = ((global_contig_ptr)G0->contigs)[threadIdx.x].base;
   }
   const uint4* rec4 = reinterpret_cast<const uint4*>(recs);
-  uint64_t qsum = 0, n_live = 0;  // qsum adds encoded qualities; the offset is taken off at the end
+  uint64_t qsum = 0;  // adds encoded qualities; the offset is taken off at the end (every base is drawn exactly once: p_bases)
   uint32_t n_subst = 0, n_acgt = 0, n_wrap = 0;
   uint64_t p_bases = 0;  // plan-derived counters, gathered while the read records are written
   uint32_t p_redrawn = 0, p_seedsubst = 0;
@@ -2249,18 +2257,47 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     // now and then — one look at the next read's first item instead of the eight dependent ones of the search
     const bool walk = !use_map && n_items >= nr * 64u;
     uint32_t r_walk = 0;
-    for (uint32_t item = threadIdx.x; item < i_end; item += 256) {
-      uint32_t r = 0;  // read of this item: last r with r_gs[r] <= item
+    // read of an item: last r with r_gs[r] <= item (items are asked for in ascending order per lane)
+    auto locate = [&](const uint32_t it) -> uint32_t {
+      uint32_t r = 0;
       if (use_map) {
-        r = owner[item];
+        r = owner[it];
       } else if (walk) {
-        while (r_gs[r_walk + 1u] <= item) r_walk++;  // (r_gs[nr ..] = ~0)
+        while (r_gs[r_walk + 1u] <= it) r_walk++;  // (r_gs[nr ..] = ~0)
         r = r_walk;
       } else {
 #pragma unroll
         for (uint32_t step = PHILOX_READS / 2; step; step >>= 1)
-          if (r_gs[r + step] <= item) r += step;
+          if (r_gs[r + step] <= it) r += step;
       }
+      return r;
+    };
+    // the plane word of an item: two 32-bit words at the read's word address + 4 * (item's group)
+    auto plane_word = [&](const uint32_t it, const uint32_t r) -> uint64_t {
+      const uint4 rb = rec4[2 * r + 1];
+      const uint64_t wa = ((uint64_t)rb.x | ((uint64_t)rb.y << 32)) + 4ull * (it - rb.z);
+#if defined(SIMMR_ABLATE_CODES)
+      return wa * 0x9E3779B97F4A7C15ull;  // timing only: no load from the plane
+#else
+      return *reinterpret_cast<global_u64_unaligned_ptr>(wa);
+#endif
+    };
+#if defined(SIMMR_PREFETCH_CODES)
+    // One item ahead (lever b of the round-2 verdict, -DSIMMR_PREFETCH_CODES): the NEXT item's read and plane word are
+    // fetched before this item's stores are issued, so the wait for that load no longer stands behind them in the
+    // in-order counter.  Measured: no gain (13.34 vs 13.22 ms, long reads 50.5 vs 49.6: profiles/r3/ab_prefetch_*), off.
+    uint32_t r_next = 0;
+    uint64_t raw_next = 0;
+    if (threadIdx.x < i_end) { r_next = locate(threadIdx.x); raw_next = plane_word(threadIdx.x, r_next); }
+#endif
+    for (uint32_t item = threadIdx.x; item < i_end; item += 256) {
+#if defined(SIMMR_PREFETCH_CODES)
+      const uint32_t r = r_next;
+      const uint64_t raw = raw_next;
+#else
+      const uint32_t r = locate(item);
+      const uint64_t raw = plane_word(item, r);
+#endif
       const uint4 ra = rec4[2 * r], rb = rec4[2 * r + 1];
       const uint32_t k0 = ra.x, k1 = ra.y, lw = ra.w;
       const uint32_t L = lw & 0xffffu, rev = lw >> 31;
@@ -2268,37 +2305,38 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint32_t b0 = ci << 4;
       const uint32_t n = (L - b0) < 16u ? (L - b0) : 16u;
       // the 16 source bases: 32 bits at bit offset 2 * (source position & 15) of two plane words
-      const uint64_t wa = ((uint64_t)rb.x | ((uint64_t)rb.y << 32)) + 4ull * ci;
-#if defined(SIMMR_ABLATE_CODES)
-      uint32_t codes = (uint32_t)((wa * 0x9E3779B97F4A7C15ull) >> ((lw >> 16) & 31u));  // timing only: no load from the plane
-#else
-      uint32_t codes = (uint32_t)(*reinterpret_cast<global_u64_unaligned_ptr>(wa) >> ((lw >> 16) & 31u));
-#endif
+      uint32_t codes = (uint32_t)(raw >> ((lw >> 16) & 31u));
       uint32_t exc = 0u;
       if (HAS_EXC) { const uint32_t* mk = x_mask[r]; if (mk) exc = fetch_mask16(mk, (int64_t)(x_src[r] + b0)); }
       // per base: 24 bits -> (Phred, substitution shift s); qualities packed as bytes, s as 2-bit fields
-      uint32_t qr[4] = {0, 0, 0, 0}, ss = 0, ea = 0;
+      uint32_t qr[4] = {0, 0, 0, 0}, ss = 0;
       if (!COPY_ONLY) {
         uint32_t w[12];
 #pragma unroll
         for (int c = 0; c < 3; c++) philox4x32_10(3u * ci + (uint32_t)c, 0u, k0, k1, w + 4 * c);
+        bool escaped;
+        {  // the sixteen lookups
+          constexpr bool FLAGGED = !ESCQ;
+          uint32_t ea = 0;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) {
-          const uint32_t w0 = w[3 * g4], w1 = w[3 * g4 + 1], w2 = w[3 * g4 + 2];
-          const uint32_t R[4] = {w0 << 8, __builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 8), w2};
-          uint32_t x[4];
+          for (int g4 = 0; g4 < 4; g4++) {
+            const uint32_t w0 = w[3 * g4], w1 = w[3 * g4 + 1], w2 = w[3 * g4 + 2];
+            const uint32_t R[4] = {w0 << 8, __builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 8), w2};
+            uint32_t x[4];
 #pragma unroll
-          for (int h = 0; h < 4; h++) {
-            x[h] = philox_pick(R[h], jtab);
-            ss = __builtin_amdgcn_alignbit(x[h], ss, 2);  // ascending, so base j ends at bits 2j of ss
-            ea |= x[h];
+            for (int h = 0; h < 4; h++) {
+              x[h] = philox_pick(R[h], jtab);
+              ss = __builtin_amdgcn_alignbit(x[h], ss, 2);  // ascending, so base j ends at bits 2j of ss
+              if (FLAGGED) ea |= x[h];
+            }
+            // the four quality bytes (byte 1 of each x) with two v_perm_b32 and an or: no SDWA write into a partly
+            // preserved register (four of those in a row on one VGPR need a wait state each on gfx940+, which the
+            // compiler cannot see inside asm statements)
+            qr[g4] = __builtin_amdgcn_perm(x[1], x[0], 0x0c0c0501u) | __builtin_amdgcn_perm(x[3], x[2], 0x05010c0cu);
           }
-          // the four quality bytes (byte 1 of each x) with two v_perm_b32 and an or: no SDWA write into a partly
-          // preserved register (four of those in a row on one VGPR need a wait state each on gfx940+, which the
-          // compiler cannot see inside asm statements)
-          qr[g4] = __builtin_amdgcn_perm(x[1], x[0], 0x0c0c0501u) | __builtin_amdgcn_perm(x[3], x[2], 0x05010c0cu);
+          escaped = FLAGGED ? (ea & 4u) != 0u : ((qr[0] | qr[1] | qr[2] | qr[3]) & 0x80808080u) != 0u;
         }
-        if (ea & 4u) philox_repair(k0, k1, ci, prof.philox_t1, prof.philox_t2, qoff, ss, qr);
+        if (escaped) philox_repair(k0, k1, ci, prof.philox_t1, prof.philox_t2, qoff, ss, qr);
       }
       // only live ACGT bases mutate (minimal_short.rs:120-128)
       // masks of the n live bases of the item: byte masks for the four quality words, 2-bit-field mask
@@ -2307,14 +2345,15 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       if (HAS_EXC) ss &= ~spread16(exc);
       ss &= live2;
       n_subst += __builtin_popcount((ss | (ss >> 1)) & 0x55555555u);
-      n_acgt += HAS_EXC ? __builtin_popcount(~spread16(exc) & live2 & 0x55555555u) : n;
+      // (without exception bases and outside the copy-only form, ACGT bases = bases = p_bases: nothing to count per item)
+      if (HAS_EXC) n_acgt += __builtin_popcount(~spread16(exc) & live2 & 0x55555555u);
+      else if (COPY_ONLY) n_acgt += n;
       if (!COPY_ONLY) {
         uint32_t qs = __builtin_amdgcn_sad_u8(qr[0] & bm.x, 0u, 0u);
         qs = __builtin_amdgcn_sad_u8(qr[1] & bm.y, 0u, qs);
         qs = __builtin_amdgcn_sad_u8(qr[2] & bm.z, 0u, qs);
         qs = __builtin_amdgcn_sad_u8(qr[3] & bm.w, 0u, qs);
         qsum += qs;
-        n_live += n;
       }
       if (!COPY_ONLY && !q_nowrap) {
         for (uint32_t j = 0; j < n; j++) n_wrap += ((qr[j >> 2] >> (8 * (j & 3u))) & 0xffu) < qoff ? 1u : 0u;
@@ -2343,6 +2382,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         s0 = asc[codes & 0xffu]; s1 = asc[(codes >> 8) & 0xffu]; s2 = asc[(codes >> 16) & 0xffu]; s3 = asc[codes >> 24];
       }
       const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
+#if defined(SIMMR_PREFETCH_CODES)
+      if (item + 256u < i_end) { r_next = locate(item + 256u); raw_next = plane_word(item + 256u, r_next); }
+#endif
 #if defined(SIMMR_ABLATE_STORES)
       asm volatile("" :: "v"(q_lo), "v"(q_hi), "v"(s_lo), "v"(s_hi), "v"(o_q), "v"(o_s));  // alive, not stored
 #else
@@ -2391,22 +2433,25 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #endif
     }
   }
-  qsum = qsum + 256ull * n_wrap - (uint64_t)qoff * n_live;  // sum of the raw Phred values
+  // sum of the raw Phred values (per lane modulo 2^64: a lane that wrote records but drew few bases goes "negative";
+  // the sum over the lanes is exact)
+  qsum = qsum + 256ull * n_wrap - (uint64_t)qoff * p_bases;
+  uint64_t acgt = (HAS_EXC || COPY_ONLY) ? (uint64_t)n_acgt : p_bases;
   for (int d = 32; d > 0; d >>= 1) {
     n_subst += __shfl_down(n_subst, d, 64);
-    n_acgt += __shfl_down(n_acgt, d, 64);
+    acgt += __shfl_down(acgt, d, 64);
     qsum += __shfl_down(qsum, d, 64);
     p_bases += __shfl_down(p_bases, d, 64);
     p_redrawn += __shfl_down(p_redrawn, d, 64);
     p_seedsubst += __shfl_down(p_seedsubst, d, 64);
   }
   if (COPY_ONLY) {
-    if ((threadIdx.x & 63u) == 0 && counters) atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
+    if ((threadIdx.x & 63u) == 0 && counters) atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)acgt);
     return;
   }
   if ((threadIdx.x & 63u) == 0 && counters) {
     atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
-    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
+    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)acgt);
     atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
     if (p_bases) atomicAdd(&counters[SIMMR_CNT_BASES], (unsigned long long)p_bases);
     if (p_redrawn) atomicAdd(&counters[SIMMR_CNT_REDRAWN], (unsigned long long)p_redrawn);
