@@ -95,6 +95,7 @@ struct simmr_engine {
   uint32_t tile_cap = 0;        // SIMMR_TILE_CAP: bytes per LDS tile (0 = from the profile's read length)
   uint32_t tile_wgs_per_cu = 0; // SIMMR_TILE_WGS_PER_CU: 0 = what fits
   int splice_variant = 0;       // SIMMR_SPLICE_VARIANT: 1 = the two-load splice kernel on every model
+  int fastq_headers_form = 0;   // SIMMR_FASTQ_HEADERS: 0 = simmr_emit_fastq's emit kernel writes the headers, 1 = k_fastq_headers does
   bool plan_tile_ok = false;    // the current paired plan has no read longer than TILE_MAXL
   // outer-stream scratch
   DevBuf o_last_idx, o_wg_sums, o_wg_prefix, o_result;
@@ -757,6 +758,7 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
   if (const char* v = getenv("SIMMR_TILE_CAP")) e->tile_cap = (uint32_t)std::min<unsigned long long>(16384, strtoull(v, nullptr, 10)) & ~15u;
   if (const char* v = getenv("SIMMR_TILE_WGS_PER_CU")) e->tile_wgs_per_cu = (uint32_t)std::min<unsigned long long>(16, strtoull(v, nullptr, 10));
   if (const char* v = getenv("SIMMR_SPLICE_VARIANT")) e->splice_variant = atoi(v);
+  if (const char* v = getenv("SIMMR_FASTQ_HEADERS")) e->fastq_headers_form = atoi(v);
   bool ok = e->d_tables.ensure(sizeof(Tables)) && e->d_counters.ensure(8 * SIMMR_N_COUNTERS) &&
             e->d_err.ensure(64) && e->d_scalars.ensure(256);
   ok = ok && hipEventCreate(&e->ev_a) == hipSuccess && hipEventCreate(&e->ev_b) == hipSuccess &&
@@ -1393,7 +1395,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                            e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                            e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
                            out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters,
-                           (const uint64_t*)nullptr, (const uint8_t*)nullptr);
+                           (const uint64_t*)nullptr, (const uint8_t*)nullptr, (const FqTemplate*)nullptr, FqTables{}, 0u, 0u, 0u);
       }
     } else if (e->prof.kind == SIMMR_K_CUSTOM && !paired) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
@@ -1441,7 +1443,8 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       hipLaunchKernelGGL(copy, dim3(cgrid), dim3(256), 0, e->stream, e->prof, 1u, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
                          (const uint32_t*)nullptr, e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset,
-                         e->plan_first, read_id_base, out_cols(out), counters, (const uint64_t*)nullptr, (const uint8_t*)nullptr);
+                         e->plan_first, read_id_base, out_cols(out), counters, (const uint64_t*)nullptr, (const uint8_t*)nullptr,
+                         (const FqTemplate*)nullptr, FqTables{}, 0u, 0u, 0u);
     } else if (e->emit_variant == 0) {
       // lane-per-read kernel: template on (exception plane present, paired, perfect-long Phred)
       bool exc = false;
@@ -1961,13 +1964,19 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
                                : (exc ? k_emit_philox<true, false, false, true, true> : k_emit_philox<false, false, false, true, true>))
                      : (cached ? (exc ? k_emit_philox<true, false, true, true> : k_emit_philox<false, false, true, true>)
                                : (exc ? k_emit_philox<true, false, false, true> : k_emit_philox<false, false, false, true>));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(),
+    // windows per run: the power of two that covers the longest run ('\n' + header + '\n'), at most 32 (512 bytes)
+    uint32_t wshift = 0;
+    while ((16u << wshift) < e->fq_maxhdr + 2u) wshift++;
+    const bool own_headers = e->fastq_headers_form == 0;  // the emit kernel writes the headers itself
+    const uint32_t slots_lds = own_headers ? FQ_GROUP * e->fq_hpitch : 0u;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), slots_lds, e->stream, e->prof, paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(),
                        e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome,
                        e->u_seed.as<uint64_t>(), dst, dst, 33u, e->plan_first, e->fq_read_id_base, OutCols{}, counters,
-                       e->fq_off.as<uint64_t>(), e->fq_hlen.as<uint8_t>());
+                       e->fq_off.as<uint64_t>(), e->fq_hlen.as<uint8_t>(),
+                       own_headers ? e->fq_tpl_dev.as<FqTemplate>() : (const FqTemplate*)nullptr, tb, e->fq_lit_bytes, e->fq_hpitch, wshift);
   }
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
-  {
+  if (e->fastq_headers_form != 0) {  // SIMMR_FASTQ_HEADERS=1: headers by a kernel of their own (measurement)
     const uint64_t n_batches = (n_reads + FQH_BATCH - 1) / FQH_BATCH;
     const uint32_t hdr_lds = 4 * FQH_BATCH * e->fq_hpitch;
     if (hdr_lds > 48 * 1024)

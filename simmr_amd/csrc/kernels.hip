@@ -1966,6 +1966,8 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
 // streams' total_bases).  None of them changes an index, a pointer into a table or a loop bound; the two that
 // move stores are bounded by the planned size (tests/test_gpu_shapes.py runs them between canaries when built).
 // ===========================================================================
+#include "fastq_format.hpp"  // (inside namespace simmr) header formatting, for the TEXT form of k_emit_philox
+
 SIMMR_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
 SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -1989,6 +1991,7 @@ SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1,
 #define PHILOX_READS 256u  /* 128 pairs x 2 mates */
 #define PHILOX_MAP_ITEMS 4096u
 #define PHILOX_CBASE 64u /* contig bases kept in LDS by the CACHED kernels */
+#define FQ_GROUP 64u /* TEXT: headers formatted at a time (LDS slots) */
 
 // bytes a + b with per-byte wrap-around (u8 add of util.rs:46-50)
 SIMMR_DEV uint32_t add_bytes(uint32_t a, uint32_t b) {
@@ -2096,7 +2099,11 @@ SIMMR_DEV void philox_repair(const uint32_t k0, const uint32_t k1, const uint32_
 // TEXT: bases and qualities go straight into FASTQ text (simmr_emit_fastq; fastq.rs:58-66): `seq` is the text, read rd's
 // record starts at rec_off[rd] with a header of hlen[rd] bytes, so its bases start at rec_off[rd] + hlen[rd] + 1 and its
 // qualities L + 3 bytes further ("\n+\n"); the lane that holds a read's first qualities also writes those three bytes
-// (one 4-byte store that ends in its own first quality); headers and the other line ends are k_fastq_headers' job.
+// (one 4-byte store that ends in its own first quality).  The headers are written here as well, block by block: after
+// the prologue the threads that hold the block's reads format them into LDS slots, 128 at a time, and all 256 copy the
+// slots out in 16-byte windows — the run of a read is the '\n' that ends the record before it, its header and the
+// header's '\n' (fq_tp != null; with fq_tp == null the headers are left to k_fastq_headers: the two-kernel form, kept
+// for measurement: 10 ms per 100 M reads against the ~2 ms this costs here).
 // ESCQ: see `esc_q` below (the host checks the condition: qual_offset + philox_qmax <= 127)
 template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false, bool ESCQ = false>
 __global__ void __launch_bounds__(256)
@@ -2106,7 +2113,19 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
               const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
               uint32_t qual_offset, uint64_t first_unit, uint32_t read_id_base, OutCols o,
               unsigned long long* __restrict__ counters, const uint64_t* __restrict__ rec_off = nullptr,
-              const uint8_t* __restrict__ hlen = nullptr) {
+              const uint8_t* __restrict__ hlen = nullptr, const FqTemplate* __restrict__ fq_tp = nullptr, FqTables fq_tb = FqTables{},
+              uint32_t fq_lit_bytes = 0, uint32_t fq_hpitch = 0, uint32_t fq_wshift = 0) {
+  // TEXT: header slots of FQ_GROUP reads at a time (dynamic LDS, FQ_GROUP * fq_hpitch bytes), the template and its literals
+  extern __shared__ __attribute__((aligned(16))) uint8_t fq_slots[];
+  __shared__ __attribute__((aligned(16))) uint8_t fq_lit[TEXT ? FQ_LIT_MAX + 8 : 1];
+  __shared__ FqSeg fq_segs[TEXT ? FQ_MAX_SEGS : 1];
+  __shared__ uint64_t fq_run_at[TEXT ? FQ_GROUP : 1];
+  __shared__ uint32_t fq_run_len[TEXT ? FQ_GROUP : 1];
+  uint32_t fq_n_segs = 0;
+  if (TEXT && fq_tp) {
+    for (uint32_t i = threadIdx.x; i < fq_lit_bytes; i += 256) fq_lit[i] = fq_tb.blob[i];
+    fq_n_segs = fq_stage_template(fq_tp, fq_segs);
+  }
   __shared__ uint2 jtab[COPY_ONLY ? 1 : 1024];  // level-1 columns (philox_pick)
   __shared__ uint32_t asc[256];  // four 2-bit codes -> four ASCII bytes
   __shared__ PhRec recs[PHILOX_READS];
@@ -2175,6 +2194,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     uint8_t* const qual_blk = (TEXT ? seq : qual) + out0;
     lds_barrier();  // the previous block's items are done with the records
     uint32_t g = 0;
+    FqFields hf{};           // TEXT: what this thread's read shows in its header
+    uint64_t h_rec = 0, h_rd = 0;
     if (threadIdx.x < nr) {
       const uint32_t t = threadIdx.x;
       const uint64_t u = u0 + (paired ? (t >> 1) : t);
@@ -2216,6 +2237,15 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #endif
         // metadata columns of this read (the other emit kernels leave them to k_write_meta)
         const uint32_t fl = pl.flags[u];
+        if (TEXT) {  // the same values, for the header (fastq.rs:34-56)
+          hf.start = paired ? (rev ? pos + L : pos) : pos;   // simulate.rs:289,295 / :515
+          hf.end = paired ? (rev ? pos : pos + L) : pl.b[u];  // simulate.rs:290,296 / :516
+          hf.genome = genome; hf.contig = contig;
+          hf.read_id = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
+          hf.flags = (paired && !rev) ? 0u : fl;
+          hf.L = L;
+          h_rec = rec_off[rd]; h_rd = rd;
+        }
         if (!TEXT) {
           o.seq_off[rd] = dst;
           if (rd + 1 == n_reads) o.seq_off[n_reads] = u_off[n_units];  // closing CSR offset
@@ -2235,6 +2265,41 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           p_bases += paired ? 2ull * L : (uint64_t)L;
           p_redrawn += (fl & SIMMR_FLAG_REDRAWN) ? 1u : 0u;
           p_seedsubst += ((fl & SIMMR_FLAG_QSEED_SUBST) ? 1u : 0u) + ((fl & SIMMR_FLAG_MSEED_SUBST) ? 1u : 0u);
+        }
+      }
+    }
+    if (TEXT && fq_tp) {
+      // headers of the block's reads, FQ_GROUP at a time (one wave's worth: with 128 the slots would cost the fourth
+      // workgroup per CU): the threads that hold them format, everybody copies
+      const uint32_t W = 1u << fq_wshift;  // 16-byte windows per run (covers the longest)
+      for (uint32_t half = 0; half * FQ_GROUP < nr; half++) {
+        lds_barrier();  // the slots are free (and, the first time, template and literals are staged)
+        if (threadIdx.x < nr && (threadIdx.x / FQ_GROUP) == half) {
+          uint8_t* h = fq_slots + (threadIdx.x & (FQ_GROUP - 1u)) * fq_hpitch;
+          const uint32_t lead = h_rd > 0 ? 1u : 0u;
+          h[0] = '\n';  // ends the record before this one
+          uint32_t at = fq_format_header(h, lead, fq_segs, fq_n_segs, fq_tb, fq_lit, hf, (paired && (threadIdx.x & 1u)) ? '2' : '1');
+          h[at++] = '\n';
+          fq_run_at[threadIdx.x & (FQ_GROUP - 1u)] = h_rec - lead;
+          fq_run_len[threadIdx.x & (FQ_GROUP - 1u)] = at;
+          if (hf.L == 0) { uint8_t* p = seq + h_rec + (at - lead); p[0] = '\n'; p[1] = '+'; p[2] = '\n'; }  // (no item writes it)
+          if (h_rd + 1 == n_reads) seq[rec_off[n_reads] - 1] = '\n';
+        }
+        lds_barrier();
+        const uint32_t n_runs = nr - FQ_GROUP * half < FQ_GROUP ? nr - FQ_GROUP * half : FQ_GROUP;
+        for (uint32_t wi = threadIdx.x; wi < (n_runs << fq_wshift); wi += 256u) {
+          const uint32_t i = wi >> fq_wshift, piece = wi & (W - 1u);
+          const uint32_t n = fq_run_len[i];
+          uint8_t* d = seq + fq_run_at[i];
+          const uint8_t* sl = fq_slots + i * fq_hpitch;
+          if (n >= 16u) {  // the last window ends where the run ends (it overlaps its neighbour with the same bytes)
+            if (piece * 16u < n) {
+              const uint32_t w0 = (piece + 1u) * 16u <= n ? piece * 16u : n - 16u;
+              *reinterpret_cast<v4u32_unaligned*>(d + w0) = *reinterpret_cast<const v4u32_unaligned*>(sl + w0);
+            }
+          } else if (piece == 0u) {
+            for (uint32_t j = 0; j < n; j++) d[j] = sl[j];
+          }
         }
       }
     }
