@@ -301,7 +301,8 @@ def main():
                             if custom is not None else
                             "VALU issue (ChaCha12 and the per-base state machines of the reference's streams)"
                             if args.rng == "reference" else
-                            "VALU issue (integer RNG and table lookups) next to the HBM write path: see `valu`"),
+                            "VALU issue (integer RNG and table lookups) next to the issue of the store instructions and the "
+                            "HBM write path behind them: see `valu` and DESIGN.md section 4"),
                 "kernel": ("k_emit_perfect_pe" if args.profile == "perfect-short" else
                            "k_emit_custom_pe" if args.profile == "custom-short" else
                            "k_custom_long_qual + k_custom_long_splice" if custom is not None else
@@ -316,8 +317,9 @@ def main():
                 "note": ("HBM-write bound data movement" if args.profile == "perfect-short" else
                          "see DESIGN.md section 4 (kernel table)" if (custom is not None or args.profile == "custom-short"
                                                                      or args.rng == "reference") else
-                         "see DESIGN.md section 4 and profiles/r2: differential timing (make ablate) puts the stores at "
-                         "a third of the kernel and the instruction stream at two thirds"),
+                         "see DESIGN.md section 4 (profiles/r2, profiles/r3): the instruction stream and the store path add up "
+                         "instead of overlapping; neither fewer VALU instructions, nor prefetching the plan rows or the plane "
+                         "word, nor an LDS-tiled form with whole-line stores moved the 13 ms in round 3"),
             },
         }
         valu = measured_valu(args, 2 * pairs_per_gpu, emit_avg_ms)
