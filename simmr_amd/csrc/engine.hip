@@ -646,6 +646,34 @@ int scan_scaled(simmr_engine* e, DevBuf& in, uint64_t n, uint32_t scale, DevBuf&
   return sync_check(e, "offset scan");
 }
 int scan_u64(simmr_engine* e, DevBuf& in, uint64_t n, DevBuf& out, uint64_t* total) { return scan_scaled<uint64_t>(e, in, n, 1u, out, total); }
+
+// The same scan when the kernel that PRODUCED in[] has already added every entry (times scale) to the sum of its tile:
+// tile_sums_begin() zeroes the tile sums and hands them to the producer, scan_presummed() runs the two remaining passes.
+unsigned long long* tile_sums_begin(simmr_engine* e, uint64_t n) {
+  const uint32_t per_wg = SCAN_THREADS * SCAN_ITEMS;
+  const uint64_t n_wg = (std::max<uint64_t>(n, 1) + per_wg - 1) / per_wg;
+  if (!e->scan_tmp.ensure((n_wg + 2) * 8)) return nullptr;
+  if (hipMemsetAsync(e->scan_tmp.p, 0, (n_wg + 2) * 8, e->stream) != hipSuccess) return nullptr;
+  return e->scan_tmp.as<unsigned long long>();
+}
+template <typename T>
+int scan_presummed(simmr_engine* e, DevBuf& in, uint64_t n, uint32_t scale, DevBuf& out, uint64_t* total) {
+  if (!out.ensure((n + 1) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
+  if (n == 0) {
+    HIP_TRY(e, hipMemsetAsync(out.p, 0, 8, e->stream));
+    *total = 0;
+    return SIMMR_OK;
+  }
+  const uint32_t per_wg = SCAN_THREADS * SCAN_ITEMS;
+  const uint64_t n_wg = (n + per_wg - 1) / per_wg;
+  uint64_t* wg_tot = e->scan_tmp.as<uint64_t>();
+  uint64_t* grand = wg_tot + n_wg;
+  hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_THREADS), 0, e->stream, wg_tot, n_wg, grand);
+  hipLaunchKernelGGL(k_scan_apply<T>, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
+                     (const T*)in.as<T>(), n, scale, (const uint64_t*)wg_tot, out.as<uint64_t>());
+  HIP_TRY(e, hipMemcpyAsync(total, grand, 8, hipMemcpyDeviceToHost, e->stream));
+  return sync_check(e, "offset scan");
+}
 // exclusive scan of the bytes each unit writes (reads_per_unit * u_len) -> u_off
 int scan_offsets(simmr_engine* e, uint64_t n, uint32_t reads_per_unit, uint64_t* total) {
   return scan_scaled<uint32_t>(e, e->u_len, n, reads_per_unit, e->u_off, total);
@@ -1156,6 +1184,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   HIP_TRY(e, hipEventRecord(e->ev_a, e->stream));
   HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
   uint64_t end_slot = 0, total = 0;
+  bool presummed = false;
   if (count > 0) {
     // the stream is entered at pair start_unit (slot start_slot): units are counted from there
     rc = run_outer(e, seed, g.contigs.size(), start_slot, first - start_unit + count, first - start_unit, count,
@@ -1164,10 +1193,15 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     PlanArrays pw = plan_arrays(e, seeds2);
     // the mutation seed of mate 2 is only read by the kernels that walk the reference's mutation stream
     if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode == SIMMR_RNG_PHILOX) pw.ms2 = nullptr;
+    // the plan kernel adds each pair's bytes to its tile of the offset scan (sort_by_length uses the same scratch first)
+    presummed = prof.kind != SIMMR_K_PERFECT_SHORT &&
+                !(prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0);
+    unsigned long long* tiles = presummed ? tile_sums_begin(e, count) : nullptr;
+    if (presummed && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
     hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                        e->d_genomes.as<GenomeDev>(), genome_idx, count, e->u_contig.as<uint32_t>(),
                        e->u_seed.as<uint64_t>(), (const uint32_t*)nullptr, pw,
-                       e->d_tables.as<Tables>(), e->d_err.as<uint32_t>());
+                       e->d_tables.as<Tables>(), e->d_err.as<uint32_t>(), tiles);
   }
   e->plan_sorted = false;
   if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0 &&
@@ -1175,7 +1209,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     return rc;
   if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
     total = count * 2ull * prof.read_length;  // constant lengths (perfect_short.rs:22-40): read r starts at r * L
-  } else if ((rc = scan_offsets(e, count, 2u, &total))) {
+  } else if ((rc = presummed ? scan_presummed<uint32_t>(e, e->u_len, count, 2u, e->u_off, &total) : scan_offsets(e, count, 2u, &total))) {
     return rc;
   }
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
@@ -1267,6 +1301,7 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
   HIP_TRY(e, hipEventRecord(e->ev_a, e->stream));
   HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
   uint64_t end_slot = 0, total = 0;
+  bool presummed = false;
   for (const Cls& c : classes) {  // run_outer synchronises, so `mg` has been uploaded when it returns
     if ((rc = run_outer(e, seed, c.range, 0, c.need, 0, c.need, e->m_contig.as<uint32_t>() + c.off,
                         e->m_seed.as<uint64_t>() + c.off, &end_slot)))
@@ -1278,17 +1313,20 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
                        e->u_genome.as<uint32_t>(), e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>());
     PlanArrays pw = plan_arrays(e, seeds2);
     if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode == SIMMR_RNG_PHILOX) pw.ms2 = nullptr;
+    presummed = prof.kind != SIMMR_K_PERFECT_SHORT && !(prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE);
+    unsigned long long* tiles = presummed ? tile_sums_begin(e, count) : nullptr;
+    if (presummed && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
     hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                        e->d_genomes.as<GenomeDev>(), 0u, count, e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(),
                        e->u_genome.as<uint32_t>(), pw, e->d_tables.as<Tables>(),
-                       e->d_err.as<uint32_t>());
+                       e->d_err.as<uint32_t>(), tiles);
   }
   e->plan_sorted = false;
   if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && (rc = sort_by_length(e, count, 0)))
     return rc;
   if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
     total = count * 2ull * prof.read_length;
-  } else if ((rc = scan_offsets(e, count, 2u, &total))) {
+  } else if ((rc = presummed ? scan_presummed<uint32_t>(e, e->u_len, count, 2u, e->u_off, &total) : scan_offsets(e, count, 2u, &total))) {
     return rc;
   }
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
@@ -1880,11 +1918,13 @@ int simmr_fastq_plan_direct(simmr_engine* e, const char* header_format, const si
   HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
   e->fq_read_id_base = read_id_base;
   const FqTables tb = fq_tables(e, n_slots);
+  unsigned long long* tiles = tile_sums_begin(e, n_reads);
+  if (!tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
   if (n_reads > 0)
     hipLaunchKernelGGL(k_fastq_size_plan, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, fq_plan_view(e),
-                       n_reads, e->fq_len.as<uint64_t>(), e->fq_hlen.as<uint8_t>(), e->d_err.as<uint32_t>());
+                       n_reads, e->fq_len.as<uint64_t>(), e->fq_hlen.as<uint8_t>(), e->d_err.as<uint32_t>(), tiles);
   uint64_t total = 0;
-  if ((rc = scan_u64(e, e->fq_len, n_reads, e->fq_off, &total))) return rc;
+  if ((rc = scan_presummed<uint64_t>(e, e->fq_len, n_reads, 1u, e->fq_off, &total))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw2[2] = {0, 0};  // error bits, longest header
   HIP_TRY(e, hipMemcpyAsync(errw2, e->d_err.p, 8, hipMemcpyDeviceToHost, e->stream));

@@ -557,14 +557,35 @@ k_multi_units(const MultiGenome* __restrict__ mg, uint32_t n_genomes, uint64_t f
   u_seed[k] = cls_seed[g.cls_off + p];
 }
 
+SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t k,
+                                  const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
+                                  const uint32_t* __restrict__ u_genome, const PlanArrays& pl, const Tables* __restrict__ T,
+                                  uint32_t* __restrict__ err, uint32_t* rows);
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8 /* per thread */
+
 extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
 k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
           const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
           const uint32_t* __restrict__ u_genome, PlanArrays pl, const Tables* __restrict__ T,
-          uint32_t* __restrict__ err) {
+          uint32_t* __restrict__ err, unsigned long long* __restrict__ tile_bytes) {
   __shared__ uint32_t rows[PLAN_THREADS * 17];
   uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
-  if (k >= n_units) return;
+  const uint32_t planned = k < n_units ? k_plan_pe_unit(prof, genomes, genome, k, u_contig, u_seed, u_genome, pl, T, err, rows) : 0u;
+  // The bytes this workgroup's pairs will write, added to the sum of their tile of the offset scan (SCAN_THREADS *
+  // SCAN_ITEMS units: a multiple of this workgroup's 256), so that the scan needs no pass of its own to reduce them.
+  if (tile_bytes) {
+    unsigned long long s = 2ull * planned;
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&tile_bytes[((uint64_t)blockIdx.x * PLAN_THREADS) / (SCAN_THREADS * SCAN_ITEMS)], s);
+  }
+}
+
+// one pair (the body of k_plan_pe); returns its read length L, 0 for a pair that cannot be planned
+SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t k,
+                                  const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
+                                  const uint32_t* __restrict__ u_genome, const PlanArrays& pl, const Tables* __restrict__ T,
+                                  uint32_t* __restrict__ err, uint32_t* rows) {
   const GenomeDev G = genomes[u_genome ? u_genome[k] : genome];  // u_genome: several genomes in one plan
   const uint64_t size = G.contigs[u_contig[k]].size;
   const uint64_t pe_seed = u_seed[k];
@@ -591,7 +612,7 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
     rng.restart();
   }
   const uint64_t required = prof.required;
-  if (size <= required) { atomicOr(err, SIMMR_ERRBIT_GENOME); return; }
+  if (size <= required) { atomicOr(err, SIMMR_ERRBIT_GENOME); return 0u; }
   uint8_t flags = SIMMR_FLAG_REVCOMP;
   uint64_t fs = rng.gen_range_u64(0, size - required);  // simulate.rs:233
   uint64_t re;
@@ -619,6 +640,7 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
   pl.flags[k] = flags;
   if (pl.qs2) pl.qs2[k] = qs;
   if (pl.ms2) pl.ms2[k] = ms;  // not kept when no kernel will read it (counter mode, custom profiles)
+  return (uint32_t)L;
 }
 
 // the run of consecutive long reads that holds global read index gi: the last r with runs[r].first_read <= gi
@@ -736,9 +758,6 @@ extern "C" __global__ void k_const_length(ProfileDev prof, uint64_t seed,
 // ===========================================================================
 // 4. Exclusive scan of per-unit byte counts -> CSR unit offsets
 // ===========================================================================
-#define SCAN_THREADS 256
-#define SCAN_ITEMS 8 /* per thread */
-
 SIMMR_DEV uint64_t wg_exclusive_scan_u64(uint64_t v, uint64_t* lds4, uint64_t* total) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint64_t inc = v;
@@ -1991,7 +2010,9 @@ SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1,
 #define PHILOX_READS 256u  /* 128 pairs x 2 mates */
 #define PHILOX_MAP_ITEMS 4096u
 #define PHILOX_CBASE 64u /* contig bases kept in LDS by the CACHED kernels */
+#ifndef FQ_GROUP
 #define FQ_GROUP 64u /* TEXT: headers formatted at a time (LDS slots) */
+#endif
 
 // bytes a + b with per-byte wrap-around (u8 add of util.rs:46-50)
 SIMMR_DEV uint32_t add_bytes(uint32_t a, uint32_t b) {
