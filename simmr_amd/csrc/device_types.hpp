@@ -96,6 +96,7 @@ struct ProfileDev {
   const uint32_t* philox_t1;
   const uint32_t* philox_t2;
   uint32_t philox_qmax;          // largest Phred either table can return
+  uint32_t philox_qmax1;         // largest Phred a level-1 column can answer (the template ESCQ of k_emit_philox)
 };
 
 struct Key8 {

@@ -493,6 +493,7 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
       if (T[k] > 0) see(prim[k]);
       if (T[k] < UNIT) see(prim[alias[k]]);
     }
+    d.philox_qmax1 = d.philox_qmax;  // (so far only level-1 answers have been seen)
     // level 2: Vose's method on the residual law, LIFO worklists filled in increasing index order
     if (E > 0) {
       for (int o = 0; o < N; o++) odds[o] = (w[o] * (double)CELLS - (double)cells[o]) / (double)E * (double)N;
@@ -1424,7 +1425,10 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
         const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * e->philox_wgs_per_cu);
         // an escaped base is noticed through its quality byte when no real one has bit 7 set (kernels.hip: esc_q)
-        const bool escq = (out->qual_offset & 0xffu) + e->prof.philox_qmax <= 127u;
+        bool escq = (out->qual_offset & 0xffu) + e->prof.philox_qmax1 <= 127u;
+#if defined(SIMMR_NO_ESCQ)
+        escq = false;  // measurement build: the flag-bit form on every input
+#endif
         auto kern = escq ? (cached ? (exc ? k_emit_philox<true, false, true, false, true> : k_emit_philox<false, false, true, false, true>)
                                    : (exc ? k_emit_philox<true, false, false, false, true> : k_emit_philox<false, false, false, false, true>))
                          : (cached ? (exc ? k_emit_philox<true, false, true> : k_emit_philox<false, false, true>)
@@ -1999,7 +2003,10 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
     else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
     const bool cached = paired && !e->plan_multi && e->plan_genome < e->genomes.size() &&
                         e->genomes[e->plan_genome].contigs.size() <= PHILOX_CBASE;
-    const bool escq = 33u + e->prof.philox_qmax <= 127u;
+    bool escq = 33u + e->prof.philox_qmax1 <= 127u;
+#if defined(SIMMR_NO_ESCQ)
+    escq = false;
+#endif
     auto kern = escq ? (cached ? (exc ? k_emit_philox<true, false, true, true, true> : k_emit_philox<false, false, true, true, true>)
                                : (exc ? k_emit_philox<true, false, false, true, true> : k_emit_philox<false, false, false, true, true>))
                      : (cached ? (exc ? k_emit_philox<true, false, true, true> : k_emit_philox<false, false, true, true>)

@@ -2125,7 +2125,8 @@ SIMMR_DEV void philox_repair(const uint32_t k0, const uint32_t k1, const uint32_
 // slots out in 16-byte windows — the run of a read is the '\n' that ends the record before it, its header and the
 // header's '\n' (fq_tp != null; with fq_tp == null the headers are left to k_fastq_headers: the two-kernel form, kept
 // for measurement: 10 ms per 100 M reads against the ~2 ms this costs here).
-// ESCQ: see `esc_q` below (the host checks the condition: qual_offset + philox_qmax <= 127)
+// ESCQ: see `esc_q` below (the host checks the condition: qual_offset + philox_qmax1 <= 127, level-1 answers only:
+// an escaped item is drawn again in full by philox_repair, whatever its level-2 answers are)
 template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false, bool ESCQ = false>
 __global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
@@ -2159,8 +2160,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ uint32_t nmask2[17]; // the low 2n bits
   __shared__ uint32_t lds4[4];
   const uint32_t qoff = qual_offset & 0xffu;
-  // Where an escaped base (one item in 9 000) is noticed.  When every encoded quality the tables can answer is below
-  // 128 (the usual case: Phred + 33), an escape cell answers the byte 0xff and one test of the item's four quality
+  // Where an escaped base (one item in 9 000) is noticed.  When every encoded quality the level-1 table can answer is
+  // below 128 (the usual case: Phred + 33), an escape cell answers the byte 0xff and one test of the item's four quality
   // words finds it; otherwise the answers carry a flag bit that is or-ed together base by base (sixteen more
   // instructions per item).
   constexpr bool esc_q = ESCQ;
