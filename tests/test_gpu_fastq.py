@@ -198,3 +198,25 @@ def test_fastq_direct_longest_headers_and_refusals(engine, genome_multi):
     with pytest.raises(SimmrError) as ei:
         engine.emit_fastq(torch.empty(16, dtype=torch.uint8, device=engine.device))
     assert ei.value.code in (_abi.ESTATE, _abi.ERANGE)
+
+
+def test_fastq_direct_exception_bases(engine):
+    """N / '-' runs in the genome (the HAS_EXC instantiations of the text-writing emit kernel), short and long reads."""
+    from tests import _oracle
+    rng = np.random.default_rng(44)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 60000)].copy()
+    seq[rng.integers(0, 60000, 5000)] = ord("N")
+    seq[rng.integers(0, 60000, 900)] = ord("-")
+    seq[7000:7600] = ord("N")
+    engine.stage_genome(12, [seq, seq[:21000].copy()])
+    names = [(12, "exc-genome", ["first", "second one"])]
+    prof = MinimalShortErrorProfile(mean_phred_score=9, rng_mode=_abi.RNG_PHILOX).pod()
+    reads = engine.simulate_pe_reads_from_genome(12, prof, 4001, 5, first=1, count=1990, read_id_base=3, qual_offset=33)
+    want = _two_step(engine, reads, names, FMT, True)
+    engine.pe_plan(12, prof, 4001, 5, 1, 1990)
+    _same_text(engine.fastq_direct(FMT, names, 3).cpu().numpy().tobytes(), want, "pairs ")
+    lp = MinimalLongErrorProfile(gamma_mean=2500.0, gamma_std=2000.0, length_mode=_abi.LEN_PER_READ, rng_mode=_abi.RNG_PHILOX).pod()
+    reads = engine.simulate_long_reads([12], [60], lp, 8, qual_offset=33)
+    want = _two_step(engine, reads, names, FMT, False)
+    engine.long_plan([12], [60], lp, 8)
+    _same_text(engine.fastq_direct(FMT, names, 0).cpu().numpy().tobytes(), want, "long ")
