@@ -2300,7 +2300,11 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           uint8_t* h = fq_slots + (threadIdx.x & (FQ_GROUP - 1u)) * fq_hpitch;
           const uint32_t lead = h_rd > 0 ? 1u : 0u;
           h[0] = '\n';  // ends the record before this one
+#if defined(FQH_ABLATE_FORMAT)
+          uint32_t at = lead + fq_header_len_lds(fq_segs, fq_n_segs, fq_tb, hf);  // timing only: the slot keeps whatever it held
+#else
           uint32_t at = fq_format_header(h, lead, fq_segs, fq_n_segs, fq_tb, fq_lit, hf, (paired && (threadIdx.x & 1u)) ? '2' : '1');
+#endif
           h[at++] = '\n';
           fq_run_at[threadIdx.x & (FQ_GROUP - 1u)] = h_rec - lead;
           fq_run_len[threadIdx.x & (FQ_GROUP - 1u)] = at;
