@@ -318,8 +318,8 @@ def main():
                          "see DESIGN.md section 4 (kernel table)" if (custom is not None or args.profile == "custom-short"
                                                                      or args.rng == "reference") else
                          "see DESIGN.md section 4 (profiles/r2, profiles/r3): the instruction stream and the store path add up "
-                         "instead of overlapping; neither fewer VALU instructions, nor prefetching the plan rows or the plane "
-                         "word, nor an LDS-tiled form with whole-line stores moved the 13 ms in round 3"),
+                         "instead of overlapping; in round 3 neither prefetching the plan rows or the plane word nor an LDS-tiled "
+                         "form with whole-line stores moved the 13 ms, 5 % fewer VALU instructions bought 2-3 %"),
             },
         }
         valu = measured_valu(args, 2 * pairs_per_gpu, emit_avg_ms)

@@ -2038,6 +2038,26 @@ SIMMR_DEV void store_tail(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi, uin
   if (n & 1u) d[p] = (uint8_t)v;
 }
 
+// the low n (< 16) bytes of two 128-bit values to two places: one branch per bit of n for both (half the exec-mask
+// bookkeeping of two store_tail calls; the same stores)
+SIMMR_DEV void store_tail2(uint8_t* __restrict__ d0, uint64_t lo0, uint64_t hi0, uint8_t* __restrict__ d1, uint64_t lo1, uint64_t hi1,
+                            uint32_t n) {
+  uint64_t v0 = lo0, v1 = lo1;
+  uint32_t p = 0;
+  if (n & 8u) { *reinterpret_cast<u64_unaligned*>(d0) = lo0; *reinterpret_cast<u64_unaligned*>(d1) = lo1; v0 = hi0; v1 = hi1; p = 8; }
+  if (n & 4u) {
+    *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(d0 + p) = (uint32_t)v0;
+    *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(d1 + p) = (uint32_t)v1;
+    v0 >>= 32; v1 >>= 32; p += 4;
+  }
+  if (n & 2u) {
+    *reinterpret_cast<uint16_t __attribute__((aligned(1)))*>(d0 + p) = (uint16_t)v0;
+    *reinterpret_cast<uint16_t __attribute__((aligned(1)))*>(d1 + p) = (uint16_t)v1;
+    v0 >>= 16; v1 >>= 16; p += 2;
+  }
+  if (n & 1u) { d0[p] = (uint8_t)v0; d1[p] = (uint8_t)v1; }
+}
+
 // Per-read record of a block: 32 bytes, read with two ds_read_b128.
 struct alignas(16) PhRec {
   uint32_t k0, k1;  // Philox key = the read's Phred seed
@@ -2180,7 +2200,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     }
     if (t <= 16u) {
       auto bytes = [](int k) { return k >= 4 ? 0xffffffffu : (k <= 0 ? 0u : ((1u << (8 * k)) - 1u)); };
-      nmask[t] = make_uint4(bytes((int)t), bytes((int)t - 4), bytes((int)t - 8), bytes((int)t - 12));
+      // (bytes of 0x01, not 0xff: v_dot4_u32_u8 with them sums the live quality bytes in one instruction per word)
+      nmask[t] = make_uint4(bytes((int)t) & 0x01010101u, bytes((int)t - 4) & 0x01010101u, bytes((int)t - 8) & 0x01010101u,
+                            bytes((int)t - 12) & 0x01010101u);
       nmask2[t] = t >= 16u ? 0xffffffffu : ((1u << (2u * t)) - 1u);
     }
     const uint32_t acgt = 0x54474341u;  // "ACGT"
@@ -2440,10 +2462,10 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       if (HAS_EXC) n_acgt += __builtin_popcount(~spread16(exc) & live2 & 0x55555555u);
       else if (COPY_ONLY) n_acgt += n;
       if (!COPY_ONLY) {
-        uint32_t qs = __builtin_amdgcn_sad_u8(qr[0] & bm.x, 0u, 0u);
-        qs = __builtin_amdgcn_sad_u8(qr[1] & bm.y, 0u, qs);
-        qs = __builtin_amdgcn_sad_u8(qr[2] & bm.z, 0u, qs);
-        qs = __builtin_amdgcn_sad_u8(qr[3] & bm.w, 0u, qs);
+        uint32_t qs = __builtin_amdgcn_udot4(qr[0], bm.x, 0u, false);
+        qs = __builtin_amdgcn_udot4(qr[1], bm.y, qs, false);
+        qs = __builtin_amdgcn_udot4(qr[2], bm.z, qs, false);
+        qs = __builtin_amdgcn_udot4(qr[3], bm.w, qs, false);
         qsum += qs;
       }
       if (!COPY_ONLY && !q_nowrap) {
@@ -2517,8 +2539,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #endif
         if (!COPY_ONLY) store16(qd, q_lo, q_hi);
         store16(sd, s_lo, s_hi);
+      } else if (!COPY_ONLY) {
+        store_tail2(qd, q_lo, q_hi, sd, s_lo, s_hi, n);
       } else {
-        if (!COPY_ONLY) store_tail(qd, q_lo, q_hi, n);
         store_tail(sd, s_lo, s_hi, n);
       }
 #endif
