@@ -903,8 +903,15 @@ SIMMR_DEV uint32_t fetch_mask16(const uint32_t* __restrict__ mask, int64_t p) {
 }
 // reverse the order of the sixteen 2-bit groups
 SIMMR_DEV uint32_t reverse_groups16(uint32_t x) {
-  uint32_t y = __builtin_bitreverse32(x);
-  return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+  const uint32_t y = __builtin_bitreverse32(x);
+  // each bit pair swapped back: odd result bits from y << 1, even ones from y >> 1 — one three-input select (v_bitop3_b32,
+  // truth table of c ? a : b with a = y >> 1, b = y << 1, c = 0x55555555)
+  return __builtin_amdgcn_bitop3_b32(y >> 1, y << 1, 0x55555555u, 0xe4);
+}
+// ~reverse_groups16(x): the complement folded into the select's truth table
+SIMMR_DEV uint32_t reverse_complement_groups16(uint32_t x) {
+  const uint32_t y = __builtin_bitreverse32(x);
+  return __builtin_amdgcn_bitop3_b32(y >> 1, y << 1, 0x55555555u, 0x1b);
 }
 // low bit of each of the sixteen 2-bit codes -> 16 bits
 SIMMR_DEV uint32_t c16_odd(uint32_t c) {
@@ -2472,8 +2479,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         for (uint32_t j = 0; j < n; j++) n_wrap += ((qr[j >> 2] >> (8 * (j & 3u))) & 0xffu) < qoff ? 1u : 0u;
       }
       // substitutions in the 2-bit code domain: code' = (code + s) mod 4, 16 bases at once
-      codes = (((codes & 0x33333333u) + (ss & 0x33333333u)) & 0x33333333u) |
-              (((codes & 0xccccccccu) + (ss & 0xccccccccu)) & 0xccccccccu);
+      // (two-bit addition without the field masks: the low bits add as xor, their carry = and goes into the high bit;
+      // v_bitop3_b32 takes three inputs, so this is and-and, shift, xor-xor: three instructions for nine)
+      codes = xor3(codes, ss, __builtin_amdgcn_bitop3_b32(codes, ss, 0x55555555u, 0x80) << 1);
       // qualities are already offset-encoded, forward order
       const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
       uint32_t o_s = ra.z + b0;
@@ -2481,7 +2489,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       if (rev) {
         // mate 2 is reverse-complemented after mutation (simulate.rs:283), still in the code domain:
         // base b0+j -> byte L-1-(b0+j); the 16-n dead groups fall off the low end
-        codes = ~reverse_groups16(codes);
+        codes = reverse_complement_groups16(codes);
         if (HAS_EXC) { exc = __builtin_bitreverse32(exc) >> 16; codes ^= spread16(exc); }
         const uint32_t dead = 16u - n;
         if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
