@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--through-fastq", action="store_true",
                     help="one step = plan + FASTQ sizing + emit straight into FASTQ text resident in HBM (simmr_fastq_plan_direct / "
                          "simmr_emit_fastq: what the reference's run produces, main.rs:180-206), instead of the SoA columns")
+    ap.add_argument("--layout", default="compact", choices=["compact", "slot16"],
+                    help="slot16: every read in a 16-byte-aligned slot of seq / qual (SIMMR_SLOT16, include/simmr_hip.h): the "
+                         "counter-mode emit kernel then writes whole aligned 16-byte groups only; counter mode, minimal profiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -108,6 +111,11 @@ def main():
     if args.rng == "philox" and args.profile != "perfect-short":
         prof.rng_mode = _abi.RNG_PHILOX
 
+    slot16 = args.layout == "slot16"
+    if slot16 and (prof.rng_mode != _abi.RNG_PHILOX or custom is not None):
+        raise SystemExit("--layout slot16 is the counter mode's layout (minimal-short / minimal-long with --rng philox)")
+    eng.set_read_slots(16 if slot16 else 0)
+
     pairs_per_gpu = args.reads // 2
     total_reads = 2 * pairs_per_gpu * world  # the whole job
     first = rank * (2 * pairs_per_gpu if long_mode else pairs_per_gpu)
@@ -132,7 +140,17 @@ def main():
 
     # sizes are a deterministic function of (seed, shard): plan once to allocate
     info = plan()
-    out = Reads.allocate(info.n_reads, info.total_bases, eng.device, qual_offset=33)
+    # (one pair of buffers serves both layouts of the side measurements: sized for the larger, the slots)
+    slot_capable = prof.rng_mode == _abi.RNG_PHILOX and custom is None and args.profile != "perfect-short"
+    cap_bases = info.total_bases
+    if slot_capable and not slot16:
+        eng.set_read_slots(16)
+        cap_bases = max(cap_bases, plan().total_bases)
+        eng.set_read_slots(0)
+        info = plan()
+    out = Reads.allocate(info.n_reads, cap_bases, eng.device, qual_offset=33, slot_bytes=info.slot_bytes)
+    out.total_bases = int(info.total_bases)
+    out_main = out
     # the reference's default read header (cli.rs:193-200) and ids for the synthetic genome
     FQ_FMT = ("@{:read_id:}|{:genome_id:}/{:pair:} metadata:sid={:sequence_id:}|sp={:start_position:}"
               "|ep={:end_position:}|rc={:reverse_complement:}")
@@ -164,7 +182,7 @@ def main():
 
     def step(record):
         eng.counters_reset()
-        plan()
+        out.total_bases = int(plan().total_bases)
         if long_mode:
             eng.long_emit(0, out)
         else:
@@ -208,6 +226,9 @@ def main():
     if world == 1 and not args.no_other_mode and args.profile != "perfect-short":
         keep_mode, keep_c = prof.rng_mode, counters_dev.clone()
         prof.rng_mode = _abi.RNG_REFERENCE if args.rng == "philox" else _abi.RNG_PHILOX
+        if slot16:  # (the reference's streams are walked by kernels that write the compact layout)
+            eng.set_read_slots(0)
+            out.slot_bytes = 0
         step(False)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -223,6 +244,30 @@ def main():
             "steps": 1, "note": "one step after one warm-up step, same shard, outside the timed region",
         }
         prof.rng_mode = keep_mode
+        counters_dev.copy_(keep_c)
+        if slot16:
+            eng.set_read_slots(16)
+            out.slot_bytes = 16
+
+    # untimed side measurement of the other output layout (N = 1, counter mode only)
+    other_layout = None
+    if world == 1 and not args.no_other_mode and slot_capable and not args.through_fastq:
+        keep_c = counters_dev.clone()
+        eng.set_read_slots(0 if slot16 else 16)
+        out.slot_bytes = 0 if slot16 else 16
+        step(False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        other_layout = {"layout": "compact" if slot16 else "slot16", "value": info.n_reads / dt, "unit": "reads/s",
+                        "ms_per_step": dt * 1e3, "kernel": "k_emit_philox", "kernel_ms": eng.last_emit_kernel_ms(),
+                        "stream_bytes": 2 * out.total_bases,
+                        "steps": 1, "note": "one step after one warm-up step, same shard, outside the timed region"}
+        eng.set_read_slots(16 if slot16 else 0)
+        out.slot_bytes = 16 if slot16 else 0
+        step(False)  # (the columns of the timed layout again: the read lengths below come from them)
         counters_dev.copy_(keep_c)
 
     # untimed side measurement: the same step through FASTQ text (N = 1, the default command only)
@@ -249,8 +294,13 @@ def main():
 
     # algorithmic bytes of ONE emit launch on this rank:
     # per read ceil(L/4) packed-reference bytes + L bases + L qualities + 16 metadata
-    lens = out.seq_off[1:info.n_reads + 1] - out.seq_off[:info.n_reads]
-    alg_bytes = int(((lens + 3) // 4).sum().item()) + 2 * int(info.total_bases) + 16 * int(info.n_reads)
+    # (the padding of the slot layout is traffic, not credit: bases and qualities count L bytes each in either layout)
+    lens = ((out.end[:info.n_reads] - out.start[:info.n_reads]).abs() if slot16 else
+            out.seq_off[1:info.n_reads + 1] - out.seq_off[:info.n_reads])
+    alg_bytes = int(((lens + 3) // 4).sum().item()) + 2 * int(lens.sum().item()) + 16 * int(info.n_reads)
+    if other_layout is not None and other_layout["kernel_ms"] > 0:
+        other_layout["achieved_GBps"] = alg_bytes / (other_layout["kernel_ms"] * 1e-3) / 1e9
+        other_layout["roofline_frac"] = other_layout["achieved_GBps"] / HBM_PEAK_GBPS
     if other is not None and other["kernel_ms"] > 0:
         other["achieved_GBps"] = alg_bytes / (other["kernel_ms"] * 1e-3) / 1e9
         other["roofline_frac"] = other["achieved_GBps"] / HBM_PEAK_GBPS
@@ -284,6 +334,9 @@ def main():
                             f"{2 * pairs_per_gpu} reads per GPU per step, seed {args.seed}",
                 "rng": ("reference StdRng streams (ChaCha12), bit-exact mode" if args.rng == "reference" else
                         "Philox4x32-10 counter mode for per-base draws (tolerance parity)"),
+                "layout": ("slot16: every read in a 16-byte-aligned slot of seq / qual (SIMMR_SLOT16, include/simmr_hip.h), "
+                           f"{2 * int(info.total_bases)} stream bytes per step" if slot16 else
+                           f"compact: seq / qual byte streams without gaps, {2 * int(info.total_bases)} stream bytes per step"),
                 "reads_per_gpu": 2 * pairs_per_gpu,
                 "sharding": "pair-index range per GPU",
             },
@@ -327,6 +380,8 @@ def main():
             result["roofline"]["valu"] = valu
         if other is not None:
             result["other_rng_mode"] = other
+        if other_layout is not None:
+            result["other_layout"] = other_layout
         if through is not None:
             result["through_fastq"] = through
         if args.through_fastq:
@@ -373,7 +428,8 @@ def _profile_record(args, reads_per_gpu):
     if reads_per_gpu != 100_000_000 or args.genome_bases != 100_000_000:
         return None, "collected at 100 M reads on 100 Mbp only"
     if args.profile == "minimal-short" and args.rng == "philox":
-        return t.get("k_emit_philox"), None
+        key = "k_emit_philox_slot16" if args.layout == "slot16" else "k_emit_philox"
+        return (t.get(key), None) if t.get(key) else (None, f"not collected for {key}")
     if args.profile == "perfect-short":
         return t.get("k_emit_perfect_pe"), None
     return None, "not collected for this profile"

@@ -124,7 +124,7 @@ typedef struct simmr_plan_info {
   uint64_t seed_used;    /* the seed (given, or drawn from OS entropy)        */
   uint64_t outer_slots;  /* u64 draws consumed from the outer StdRng stream   */
   uint32_t const_read_length; /* long/REFERENCE: the run-wide length, else 0  */
-  uint32_t reserved;
+  uint32_t slot_bytes;   /* 0: compact streams; 16: SIMMR_SLOT16 (simmr_engine_set_read_slots) */
 } simmr_plan_info;
 
 /* flags[] bits */
@@ -153,8 +153,28 @@ typedef struct simmr_reads_out {
   uint64_t seq_capacity;   /* bytes available in seq and in qual              */
   uint64_t reads_capacity; /* entries available in the per-read columns       */
   uint32_t qual_offset;    /* 0: raw Phred as SingleRead.quality; 33: FASTQ   */
-  uint32_t reserved;
+  uint32_t slot_bytes;     /* the layout the caller expects: 0 (or 1) compact, 16 SIMMR_SLOT16; an emit call whose
+                              plan was made for the other layout answers SIMMR_EINVAL                        */
 } simmr_reads_out;
+
+/* Layout of seq[] / qual[] (the reference's SingleRead is a heap Vec per read, simulate.rs:27-40: neither layout
+ * below is "the" reference layout).
+ * compact (default): read r's bases are seq[seq_off[r] .. seq_off[r+1]) and its qualities the same bytes of qual[]:
+ *   two byte streams without gaps.
+ * SIMMR_SLOT16 (opt-in, simmr_engine_set_read_slots(e, 16) before the plan call): every read owns a slot of
+ *   ceil(L / 16) * 16 bytes that starts on a 16-byte boundary of both streams (total_bases counts the slots), so that the
+ *   counter-mode emit kernel writes nothing but whole aligned 16-byte groups (no byte-granular stores at the reads'
+ *   ends: 12.0 instead of 12.9 ms per 100 M reads).  Qualities are left-aligned in the slot.
+ *   Bases are left-aligned too, except for a reverse-complemented mate (SIMMR_FLAG_REVCOMP), whose bases are written
+ *   back to front and therefore RIGHT-aligned: its 16-base draw groups then land on aligned 16 bytes as well.
+ *     seq_off[r]         = first base of read r in seq[]   (for a reverse-complemented mate not a multiple of 16)
+ *     seq_off[r] & ~15   = first quality of read r in qual[]
+ *     L(r)               = |end[r] - start[r]|   (seq_off[r+1] - seq_off[r] is NOT the length in this layout)
+ *     seq_off[n_reads]   = total_bases
+ *   Padding bytes are written as 0 in both streams.  Offered by the kernels that gain from it — SIMMR_RNG_PHILOX with
+ *   minimal-short, minimal-long and perfect-long profiles; a plan call for any other profile answers SIMMR_ENOTSUP
+ *   while the engine is set to slots.  simmr_fastq_plan / simmr_fastq_emit read either layout. */
+#define SIMMR_SLOT16 16u
 
 /* Device-side counters a run accumulates (reduced across GPUs by the caller
  * with one all-reduce).  Indices into the uint64 array. */
@@ -182,6 +202,9 @@ void simmr_engine_destroy(simmr_engine* e);
 const char* simmr_last_error(const simmr_engine* e);
 /* All work is enqueued on this hipStream_t (default: the null stream). */
 int simmr_engine_set_stream(simmr_engine* e, void* hip_stream);
+/* Layout of the reads that plans made FROM NOW ON will emit: 0 (or 1) = compact, SIMMR_SLOT16 = 16-byte read slots
+ * (see simmr_reads_out).  Anything else: SIMMR_EINVAL.  The plan in force keeps the layout it was made with. */
+int simmr_engine_set_read_slots(simmr_engine* e, uint32_t slot_bytes);
 
 /* ---- reference staging -------------------------------------------------- */
 /* Replaces the in-RAM `Genome { sequence: Vec<Seq> }` (genome.rs:17-41): the

@@ -69,7 +69,7 @@ class PlanInfo(C.Structure):
         ("seed_used", C.c_uint64),
         ("outer_slots", C.c_uint64),
         ("const_read_length", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("slot_bytes", C.c_uint32),
     ]
 
 
@@ -89,7 +89,7 @@ class ReadsOut(C.Structure):
         ("seq_capacity", C.c_uint64),
         ("reads_capacity", C.c_uint64),
         ("qual_offset", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("slot_bytes", C.c_uint32),
     ]
 
 
@@ -117,6 +117,7 @@ SYMBOLS = {
     "simmr_engine_destroy": (None, [C.c_void_p]),
     "simmr_last_error": (C.c_char_p, [C.c_void_p]),
     "simmr_engine_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "simmr_engine_set_read_slots": (C.c_int, [C.c_void_p, C.c_uint32]),
     "simmr_stage_genome": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_void_p),
                                      _P(C.c_uint64), _P(C.c_uint64)]),
     "simmr_stage_fasta": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_void_p), _P(C.c_uint64), C.c_int,

@@ -80,6 +80,8 @@ struct simmr_engine {
   ProfileDev prof{};
   uint32_t plan_genome = 0;
   uint64_t plan_first = 0, plan_units = 0, plan_total_bases = 0;
+  uint32_t read_slots = 0;  // simmr_engine_set_read_slots: the layout of the plans to come (0 compact, 16 SIMMR_SLOT16)
+  uint32_t plan_slot = 0;   // ... and of the plan in force
   bool plan_paired = false;
   bool plan_multi = false;    // paired-end plan over several genomes (u_genome per pair)
   bool plan_any_exc = false;  // some genome of the plan has an exception plane
@@ -626,7 +628,7 @@ int sort_by_length(simmr_engine* e, uint64_t count, uint32_t shift) {
 
 // exclusive scan of scale * in[i] (n entries of type T) -> `out` (n + 1 u64 entries); returns the total
 template <typename T>
-int scan_scaled(simmr_engine* e, DevBuf& in, uint64_t n, uint32_t scale, DevBuf& out, uint64_t* total) {
+int scan_scaled(simmr_engine* e, DevBuf& in, uint64_t n, uint32_t scale, DevBuf& out, uint64_t* total, uint32_t round = 0) {
   if (!out.ensure((n + 1) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
   if (n == 0) {
     HIP_TRY(e, hipMemsetAsync(out.p, 0, 8, e->stream));
@@ -639,10 +641,10 @@ int scan_scaled(simmr_engine* e, DevBuf& in, uint64_t n, uint32_t scale, DevBuf&
   uint64_t* wg_tot = e->scan_tmp.as<uint64_t>();
   uint64_t* grand = wg_tot + n_wg;
   hipLaunchKernelGGL(k_scan_reduce<T>, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
-                     (const T*)in.as<T>(), n, scale, wg_tot);
+                     (const T*)in.as<T>(), n, scale, round, wg_tot);
   hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_THREADS), 0, e->stream, wg_tot, n_wg, grand);
   hipLaunchKernelGGL(k_scan_apply<T>, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
-                     (const T*)in.as<T>(), n, scale, (const uint64_t*)wg_tot, out.as<uint64_t>());
+                     (const T*)in.as<T>(), n, scale, round, (const uint64_t*)wg_tot, out.as<uint64_t>());
   HIP_TRY(e, hipMemcpyAsync(total, grand, 8, hipMemcpyDeviceToHost, e->stream));
   return sync_check(e, "offset scan");
 }
@@ -658,7 +660,7 @@ unsigned long long* tile_sums_begin(simmr_engine* e, uint64_t n) {
   return e->scan_tmp.as<unsigned long long>();
 }
 template <typename T>
-int scan_presummed(simmr_engine* e, DevBuf& in, uint64_t n, uint32_t scale, DevBuf& out, uint64_t* total) {
+int scan_presummed(simmr_engine* e, DevBuf& in, uint64_t n, uint32_t scale, DevBuf& out, uint64_t* total, uint32_t round = 0) {
   if (!out.ensure((n + 1) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
   if (n == 0) {
     HIP_TRY(e, hipMemsetAsync(out.p, 0, 8, e->stream));
@@ -671,13 +673,13 @@ int scan_presummed(simmr_engine* e, DevBuf& in, uint64_t n, uint32_t scale, DevB
   uint64_t* grand = wg_tot + n_wg;
   hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_THREADS), 0, e->stream, wg_tot, n_wg, grand);
   hipLaunchKernelGGL(k_scan_apply<T>, dim3((uint32_t)n_wg), dim3(SCAN_THREADS), 0, e->stream,
-                     (const T*)in.as<T>(), n, scale, (const uint64_t*)wg_tot, out.as<uint64_t>());
+                     (const T*)in.as<T>(), n, scale, round, (const uint64_t*)wg_tot, out.as<uint64_t>());
   HIP_TRY(e, hipMemcpyAsync(total, grand, 8, hipMemcpyDeviceToHost, e->stream));
   return sync_check(e, "offset scan");
 }
 // exclusive scan of the bytes each unit writes (reads_per_unit * u_len) -> u_off
-int scan_offsets(simmr_engine* e, uint64_t n, uint32_t reads_per_unit, uint64_t* total) {
-  return scan_scaled<uint32_t>(e, e->u_len, n, reads_per_unit, e->u_off, total);
+int scan_offsets(simmr_engine* e, uint64_t n, uint32_t reads_per_unit, uint64_t* total, uint32_t round = 0) {
+  return scan_scaled<uint32_t>(e, e->u_len, n, reads_per_unit, e->u_off, total, round);
 }
 
 int ensure_plan_arrays(simmr_engine* e, uint64_t n, bool need_seeds2, bool need_genome) {
@@ -707,6 +709,18 @@ int read_err_word(simmr_engine* e, uint32_t* w) {
   return sync_check(e, "error word readback");
 }
 
+// The layout a plan for `prof` gets (simmr_engine_set_read_slots): *round = 15 for 16-byte read slots, else 0.  Slots
+// are written by the counter-mode item kernel (k_emit_philox) only.
+int plan_slot_round(simmr_engine* e, const ProfileDev& prof, uint32_t* round) {
+  *round = 0;
+  if (e->read_slots != SIMMR_SLOT16) return SIMMR_OK;
+  if (prof.kind == SIMMR_K_CUSTOM || prof.kind == SIMMR_K_PERFECT_SHORT || prof.rng_mode != SIMMR_RNG_PHILOX)
+    return e->fail(SIMMR_ENOTSUP, "16-byte read slots are written in SIMMR_RNG_PHILOX mode by the minimal and perfect-long profiles only "
+                                  "(simmr_engine_set_read_slots(e, 0) for the compact layout)");
+  *round = 15;
+  return SIMMR_OK;
+}
+
 int check_out(simmr_engine* e, const simmr_reads_out* out, uint64_t n_reads, uint64_t total) {
   if (!out) return e->fail(SIMMR_EINVAL, "out is NULL");
   if (!out->seq_off) return e->fail(SIMMR_EINVAL, "out->seq_off is NULL");
@@ -718,6 +732,9 @@ int check_out(simmr_engine* e, const simmr_reads_out* out, uint64_t n_reads, uin
     return e->fail(SIMMR_ERANGE, "reads_capacity %llu < %llu reads planned",
                    (unsigned long long)out->reads_capacity, (unsigned long long)n_reads);
   if (out->qual_offset > 255u) return e->fail(SIMMR_EINVAL, "qual_offset too large");
+  if ((out->slot_bytes <= 1u ? 0u : out->slot_bytes) != e->plan_slot)
+    return e->fail(SIMMR_EINVAL, "out->slot_bytes = %u, but the plan was made for %s (simmr_engine_set_read_slots, simmr_plan_info.slot_bytes)",
+                   out->slot_bytes, e->plan_slot ? "16-byte read slots" : "the compact layout");
   return SIMMR_OK;
 }
 
@@ -922,6 +939,13 @@ void simmr_engine_destroy(simmr_engine* e) {
   if (e->ev_c) (void)hipEventDestroy(e->ev_c);
   if (e->ev_d) (void)hipEventDestroy(e->ev_d);
   delete e;
+}
+
+int simmr_engine_set_read_slots(simmr_engine* e, uint32_t slot_bytes) {
+  if (!e) return SIMMR_EINVAL;
+  if (slot_bytes > 1u && slot_bytes != SIMMR_SLOT16) return e->fail(SIMMR_EINVAL, "read slots are 0 (compact) or 16 bytes");
+  e->read_slots = slot_bytes == SIMMR_SLOT16 ? SIMMR_SLOT16 : 0u;
+  return SIMMR_OK;
 }
 
 int simmr_engine_set_stream(simmr_engine* e, void* hip_stream) {
@@ -1166,6 +1190,8 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   if (rc) return rc;
   ProfileDev prof;
   if ((rc = make_profile(e, profile, false, &prof))) return rc;
+  uint32_t slot_round = 0;
+  if ((rc = plan_slot_round(e, prof, &slot_round))) return rc;
   GenomeHost& g = e->genomes[genome_idx];
   // simulate.rs:220-225: a sequence not larger than minimum_genome_size() is an
   // Err that the caller unwrap()s (simulate.rs:186) — any such sequence can be drawn.
@@ -1202,7 +1228,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                        e->d_genomes.as<GenomeDev>(), genome_idx, count, e->u_contig.as<uint32_t>(),
                        e->u_seed.as<uint64_t>(), (const uint32_t*)nullptr, pw,
-                       e->d_tables.as<Tables>(), e->d_err.as<uint32_t>(), tiles);
+                       e->d_tables.as<Tables>(), e->d_err.as<uint32_t>(), tiles, slot_round);
   }
   e->plan_sorted = false;
   if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0 &&
@@ -1210,7 +1236,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     return rc;
   if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
     total = count * 2ull * prof.read_length;  // constant lengths (perfect_short.rs:22-40): read r starts at r * L
-  } else if ((rc = presummed ? scan_presummed<uint32_t>(e, e->u_len, count, 2u, e->u_off, &total) : scan_offsets(e, count, 2u, &total))) {
+  } else if ((rc = presummed ? scan_presummed<uint32_t>(e, e->u_len, count, 2u, e->u_off, &total, slot_round) : scan_offsets(e, count, 2u, &total, slot_round))) {
     return rc;
   }
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
@@ -1226,6 +1252,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   e->plan_kind = PLAN_PE;
   e->prof = prof;
   e->plan_genome = genome_idx;
+  e->plan_slot = slot_round ? SIMMR_SLOT16 : 0u;
   e->plan_first = first;
   e->plan_units = count;
   e->plan_total_bases = total;
@@ -1239,6 +1266,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     info->total_bases = total;
     info->seed_used = seed;
     info->outer_slots = end_slot;
+    info->slot_bytes = e->plan_slot;
   }
   return SIMMR_OK;
 }
@@ -1256,6 +1284,8 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
   int rc;
   ProfileDev prof;
   if ((rc = make_profile(e, profile, false, &prof))) return rc;
+  uint32_t slot_round = 0;
+  if ((rc = plan_slot_round(e, prof, &slot_round))) return rc;
   if (prof.kind == SIMMR_K_CUSTOM || (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant != 0))
     return e->fail(SIMMR_ENOTSUP, "this profile / emit variant is planned one genome at a time (simmr_pe_plan)");
   // global pair ranges of the genomes (simulate.rs:179: num_reads / 2 pairs each)
@@ -1320,14 +1350,14 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
     hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                        e->d_genomes.as<GenomeDev>(), 0u, count, e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(),
                        e->u_genome.as<uint32_t>(), pw, e->d_tables.as<Tables>(),
-                       e->d_err.as<uint32_t>(), tiles);
+                       e->d_err.as<uint32_t>(), tiles, slot_round);
   }
   e->plan_sorted = false;
   if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && (rc = sort_by_length(e, count, 0)))
     return rc;
   if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
     total = count * 2ull * prof.read_length;
-  } else if ((rc = presummed ? scan_presummed<uint32_t>(e, e->u_len, count, 2u, e->u_off, &total) : scan_offsets(e, count, 2u, &total))) {
+  } else if ((rc = presummed ? scan_presummed<uint32_t>(e, e->u_len, count, 2u, e->u_off, &total, slot_round) : scan_offsets(e, count, 2u, &total, slot_round))) {
     return rc;
   }
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
@@ -1341,6 +1371,7 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
   e->plan_kind = PLAN_PE;
   e->prof = prof;
   e->plan_genome = genome_idx[0];
+  e->plan_slot = slot_round ? SIMMR_SLOT16 : 0u;
   e->plan_first = first;
   e->plan_units = count;
   e->plan_total_bases = total;
@@ -1354,6 +1385,7 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
     info->total_bases = total;
     info->seed_used = seed;
     info->outer_slots = end_slot;
+    info->slot_bytes = e->plan_slot;
   }
   return SIMMR_OK;
 }
@@ -1392,7 +1424,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       // pairs of one genome with few contigs: the contig bases live in LDS (no dependent load per record)
       const bool cached = paired && !e->plan_multi && e->plan_genome < e->genomes.size() &&
                           e->genomes[e->plan_genome].contigs.size() <= PHILOX_CBASE;
-      if (paired && e->plan_tile_ok && e->philox_form == 2) {
+      if (paired && e->plan_tile_ok && e->philox_form == 2 && !e->plan_slot) {
         // tile form (emit_tile.hip): the block's piece of both streams is built in LDS and flushed in whole lines
         const uint32_t upb = e->tile_upb;  // (1..32: one lane of the prologue wave per read)
         // tile capacity: the block's expected bytes plus slack (a block that does not fit stores directly)
@@ -1433,6 +1465,11 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                                    : (exc ? k_emit_philox<true, false, false, false, true> : k_emit_philox<false, false, false, false, true>))
                          : (cached ? (exc ? k_emit_philox<true, false, true> : k_emit_philox<false, false, true>)
                                    : (exc ? k_emit_philox<true, false, false> : k_emit_philox<false, false, false>));
+        if (e->plan_slot)  // 16-byte read slots (SIMMR_SLOT16): whole aligned 16-byte stores only
+          kern = escq ? (cached ? (exc ? k_emit_philox<true, false, true, false, true, true> : k_emit_philox<false, false, true, false, true, true>)
+                                : (exc ? k_emit_philox<true, false, false, false, true, true> : k_emit_philox<false, false, false, false, true, true>))
+                      : (cached ? (exc ? k_emit_philox<true, false, true, false, false, true> : k_emit_philox<false, false, true, false, false, true>)
+                                : (exc ? k_emit_philox<true, false, false, false, false, true> : k_emit_philox<false, false, false, false, false, true>));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
                            e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                            e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
@@ -1557,6 +1594,8 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   int rc;
   ProfileDev prof;
   if ((rc = make_profile(e, profile, true, &prof))) return rc;
+  uint32_t slot_round = 0;
+  if ((rc = plan_slot_round(e, prof, &slot_round))) return rc;
   uint64_t total_reads = 0;
   for (uint32_t g = 0; g < n_genomes; g++) {
     if ((rc = check_genome(e, genome_idx[g]))) return rc;
@@ -1653,7 +1692,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   }
   e->plan_sorted = false;
   if (e->emit_variant == 0 && prof.rng_mode == SIMMR_RNG_REFERENCE && (rc = sort_by_length(e, count, 6))) return rc;
-  if ((rc = scan_offsets(e, count, 1u, &total))) return rc;
+  if ((rc = scan_offsets(e, count, 1u, &total, slot_round))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;
   if ((rc = read_err_word(e, &errw))) return rc;
@@ -1664,6 +1703,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   e->plan_kind = PLAN_LONG;
   e->prof = prof;
   e->plan_genome = 0;
+  e->plan_slot = slot_round ? SIMMR_SLOT16 : 0u;
   e->plan_first = first;
   e->plan_units = count;
   e->plan_total_bases = total;
@@ -1676,6 +1716,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
     info->seed_used = seed;
     info->outer_slots = end_slot;
     info->const_read_length = per_read ? 0 : L0;
+    info->slot_bytes = e->plan_slot;
   }
   return SIMMR_OK;
 }
@@ -1840,7 +1881,7 @@ int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fas
   HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
   const FqTables tb = fq_tables(e, n_slots);
   const FqReads rd{reads->seq, reads->qual, reads->seq_off, reads->start, reads->end, reads->contig, reads->genome,
-                   reads->read_id, reads->flags};
+                   reads->read_id, reads->flags, reads->slot_bytes == SIMMR_SLOT16 ? 1u : 0u};
   if (n_reads > 0)
     hipLaunchKernelGGL(k_fastq_size, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, rd, n_reads,
                        e->fq_len.as<uint64_t>(), e->d_err.as<uint32_t>());
@@ -1874,7 +1915,7 @@ int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst
   HIP_TRY(e, hipSetDevice(e->device));
   const FqTables tb = fq_tables(e, e->fq_slots);
   const FqReads rd{reads->seq, reads->qual, reads->seq_off, reads->start, reads->end, reads->contig, reads->genome,
-                   reads->read_id, reads->flags};
+                   reads->read_id, reads->flags, reads->slot_bytes == SIMMR_SLOT16 ? 1u : 0u};
   const uint64_t n_batches = (e->fq_reads + FQ_BATCH - 1) / FQ_BATCH;
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 8);
   const uint32_t hdr_lds = 4 * FQ_BATCH * e->fq_hpitch;  // up to 68 KB with 255-byte headers: above the default limit
@@ -1978,7 +2019,7 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
     cols.seq_capacity = tb_bytes; cols.reads_capacity = nr; cols.qual_offset = 33;
     int rc = emit_common(e, e->fq_read_id_base, &cols);
     if (rc) return rc;
-    const FqReads rd{cols.seq, cols.qual, cols.seq_off, cols.start, cols.end, cols.contig, cols.genome, cols.read_id, cols.flags};
+    const FqReads rd{cols.seq, cols.qual, cols.seq_off, cols.start, cols.end, cols.contig, cols.genome, cols.read_id, cols.flags, 0u};
     const uint64_t n_batches = (n_reads + FQ_BATCH - 1) / FQ_BATCH;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 8);
     const uint32_t hdr_lds = 4 * FQ_BATCH * e->fq_hpitch;

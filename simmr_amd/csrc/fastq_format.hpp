@@ -39,6 +39,7 @@ struct FqReads {  // the SoA columns simmr_*_emit filled (device pointers)
   const uint32_t* genome;
   const uint32_t* read_id;
   const uint8_t* flags;
+  uint32_t slot16;  // SIMMR_SLOT16 columns: a read's length is |end - start|, its qualities start at seq_off & ~15
 };
 
 // What a header can show of a read (fastq.rs:34-56), from the emitted columns or straight from the plan.
@@ -48,8 +49,9 @@ struct FqFields {
   uint32_t L;           // bases
 };
 SIMMR_DEV FqFields fq_fields(const FqReads& rd, uint64_t r) {
-  return FqFields{rd.start[r], rd.end[r], rd.genome[r], rd.contig[r], rd.read_id[r], rd.flags[r],
-                  (uint32_t)(rd.seq_off[r + 1] - rd.seq_off[r])};
+  const uint64_t a = rd.start[r], b = rd.end[r];
+  return FqFields{a, b, rd.genome[r], rd.contig[r], rd.read_id[r], rd.flags[r],
+                  rd.slot16 ? (uint32_t)(a < b ? b - a : a - b) : (uint32_t)(rd.seq_off[r + 1] - rd.seq_off[r])};
 }
 // The plan of the shard about to be emitted (simmr_fastq_plan_direct): the same values simmr_*_emit would write into
 // the columns (k_write_meta / the emit kernels' prologues; simulate.rs:274,289-296,515-516).

@@ -168,7 +168,7 @@ k_fastq_write(const FqTemplate* __restrict__ tp, FqTables tb, FqReads rd, uint64
         const uint32_t t = shifted ? w + 16u - n_src : 0u;
         const uint32_t ld = shifted ? n_src - 16u : w;
         // both loads are always issued (no branch): the one that is not needed reads a harmless address
-        const uint8_t* gsrc = (isB ? rd.seq : rd.qual) + R.so + ((fast && !isA) ? ld : 0u);
+        const uint8_t* gsrc = (isB ? rd.seq + R.so : rd.qual + (rd.slot16 ? (R.so & ~15ull) : R.so)) + ((fast && !isA) ? ld : 0u);
         const u32x4 vg = *(global_u128_unaligned_ptr)(fast && !isA ? gsrc : rd.seq);
         const u32x4 vl = *reinterpret_cast<const u32x4_unaligned*>(hdr + i * hpitch + ((fast && isA) ? w : 0u));
         v[u] = isA ? vl : fq_shift_in(vg, t, fill);
@@ -192,7 +192,7 @@ k_fastq_write(const FqTemplate* __restrict__ tp, FqTables tb, FqReads rd, uint64
           recB[R.L] = '\n'; recB[R.L + 1] = '+'; recB[R.L + 2] = '\n';
         } else {
           uint8_t* recC = rec + R.H + R.L + 3u;
-          for (uint32_t j = 0; j < R.L; j++) recC[j] = rd.qual[R.so + j];
+          for (uint32_t j = 0; j < R.L; j++) recC[j] = rd.qual[(rd.slot16 ? (R.so & ~15ull) : R.so) + j];
           recC[R.L] = '\n';
         }
       }

@@ -568,14 +568,14 @@ extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
 k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
           const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
           const uint32_t* __restrict__ u_genome, PlanArrays pl, const Tables* __restrict__ T,
-          uint32_t* __restrict__ err, unsigned long long* __restrict__ tile_bytes) {
+          uint32_t* __restrict__ err, unsigned long long* __restrict__ tile_bytes, uint32_t slot_round) {
   __shared__ uint32_t rows[PLAN_THREADS * 17];
   uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
   const uint32_t planned = k < n_units ? k_plan_pe_unit(prof, genomes, genome, k, u_contig, u_seed, u_genome, pl, T, err, rows) : 0u;
   // The bytes this workgroup's pairs will write, added to the sum of their tile of the offset scan (SCAN_THREADS *
   // SCAN_ITEMS units: a multiple of this workgroup's 256), so that the scan needs no pass of its own to reduce them.
   if (tile_bytes) {
-    unsigned long long s = 2ull * planned;
+    unsigned long long s = 2ull * ((planned + slot_round) & ~slot_round);  // (slot_round = 15 for 16-byte read slots, else 0)
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
     if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&tile_bytes[((uint64_t)blockIdx.x * PLAN_THREADS) / (SCAN_THREADS * SCAN_ITEMS)], s);
   }
@@ -779,15 +779,16 @@ SIMMR_DEV uint64_t wg_exclusive_scan_u64(uint64_t v, uint64_t* lds4, uint64_t* t
   return pre + inc - v;
 }
 
-// T = uint64_t (byte counts) or uint32_t (read lengths, `scale` reads per unit: the bytes a unit writes)
+// T = uint64_t (byte counts) or uint32_t (read lengths, `scale` reads per unit: the bytes a unit writes; every length is
+// first rounded up to a multiple of round + 1: 16-byte read slots, SIMMR_SLOT16)
 template <typename T>
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_scan_reduce(const T* __restrict__ in, uint64_t n, uint32_t scale, uint64_t* __restrict__ wg_tot) {
+k_scan_reduce(const T* __restrict__ in, uint64_t n, uint32_t scale, uint32_t round, uint64_t* __restrict__ wg_tot) {
   __shared__ uint64_t lds4[4];
   uint64_t base = ((uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
   uint64_t s = 0;
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) s += (uint64_t)in[base + i] * scale;
+  for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) s += (((uint64_t)in[base + i] + round) & ~(uint64_t)round) * scale;
   uint64_t tot;
   (void)wg_exclusive_scan_u64(s, lds4, &tot);
   if (threadIdx.x == 0) wg_tot[blockIdx.x] = tot;
@@ -816,13 +817,13 @@ k_scan_tops(uint64_t* __restrict__ wg_tot, uint64_t n_wg, uint64_t* __restrict__
 
 template <typename T>
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_scan_apply(const T* __restrict__ in, uint64_t n, uint32_t scale, const uint64_t* __restrict__ wg_tot,
+k_scan_apply(const T* __restrict__ in, uint64_t n, uint32_t scale, uint32_t round, const uint64_t* __restrict__ wg_tot,
              uint64_t* __restrict__ out /* n + 1 */) {
   __shared__ uint64_t lds4[4];
   uint64_t base = ((uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
   uint64_t v[SCAN_ITEMS], s = 0;
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? (uint64_t)in[base + i] * scale : 0; s += v[i]; }
+  for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? (((uint64_t)in[base + i] + round) & ~(uint64_t)round) * scale : 0; s += v[i]; }
   uint64_t tot;
   uint64_t ex = wg_exclusive_scan_u64(s, lds4, &tot) + wg_tot[blockIdx.x];
 #pragma unroll
@@ -2154,7 +2155,11 @@ SIMMR_DEV void philox_repair(const uint32_t k0, const uint32_t k1, const uint32_
 // for measurement: 10 ms per 100 M reads against the ~2 ms this costs here).
 // ESCQ: see `esc_q` below (the host checks the condition: qual_offset + philox_qmax1 <= 127, level-1 answers only:
 // an escaped item is drawn again in full by philox_repair, whatever its level-2 answers are)
-template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false, bool ESCQ = false>
+// SLOT: 16-byte read slots (SIMMR_SLOT16, include/simmr_hip.h): every read's place in both streams is ceil(L / 16) * 16
+// bytes on a 16-byte boundary (u_off is the scan of the padded lengths), qualities and forward bases left-aligned, the
+// bases of a reverse-complemented mate right-aligned — so EVERY item, the partial group at a read's end included, is one
+// whole aligned 16-byte store per stream (padding written as 0) and the byte ladder of store_tail2 is gone.
+template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false, bool ESCQ = false, bool SLOT = false>
 __global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
@@ -2256,7 +2261,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint32_t contig = u_contig[u];
       const uint32_t genome = (!CACHED && u_genome) ? u_genome[u] : genome_const;
       const uint64_t rd = paired ? 2 * u + rev : u;
-      const uint64_t dst = TEXT ? rec_off[rd] + hlen[rd] + 1u : u_off[u] + (rev ? L : 0u);
+      const uint32_t Lp = SLOT ? ((L + 15u) & ~15u) : L;  // the read's place in the streams
+      const uint64_t dst = TEXT ? rec_off[rd] + hlen[rd] + 1u : u_off[u] + (rev ? Lp : 0u);
       const uint64_t pos = rev ? pl.b[u] : pl.a[u];  // first source base of this read on the contig
       const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
       uint64_t cb;
@@ -2298,7 +2304,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           h_rec = rec_off[rd]; h_rd = rd;
         }
         if (!TEXT) {
-          o.seq_off[rd] = dst;
+          o.seq_off[rd] = (SLOT && rev) ? dst + (Lp - L) : dst;  // first base (SLOT: a reverse mate's bases are right-aligned)
           if (rd + 1 == n_reads) o.seq_off[n_reads] = u_off[n_units];  // closing CSR offset
           if (paired) {
             if (o.start) o.start[rd] = rev ? pos + L : pos;  // simulate.rs:289,295
@@ -2482,8 +2488,6 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       // (two-bit addition without the field masks: the low bits add as xor, their carry = and goes into the high bit;
       // v_bitop3_b32 takes three inputs, so this is and-and, shift, xor-xor: three instructions for nine)
       codes = xor3(codes, ss, __builtin_amdgcn_bitop3_b32(codes, ss, 0x55555555u, 0x80) << 1);
-      // qualities are already offset-encoded, forward order
-      const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
       uint32_t o_s = ra.z + b0;
       const uint32_t o_q = TEXT ? o_s + L + 3u : o_s;  // (TEXT: the qualities' line follows the bases' line and "+\n")
       if (rev) {
@@ -2492,8 +2496,13 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         codes = reverse_complement_groups16(codes);
         if (HAS_EXC) { exc = __builtin_bitreverse32(exc) >> 16; codes ^= spread16(exc); }
         const uint32_t dead = 16u - n;
-        if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
-        o_s = ra.z + (L - b0 - n);
+        if (SLOT) {
+          // right-aligned: the group's 16 bytes end at slot byte Lp - b0, the dead groups stay at the low end (zeroed below)
+          o_s = ra.z + (((L + 15u) & ~15u) - b0 - 16u);
+        } else {
+          if (dead) { codes >>= 2 * dead; if (HAS_EXC) exc >>= dead; }
+          o_s = ra.z + (L - b0 - n);
+        }
       }
       uint32_t s0, s1, s2, s3;
       if (HAS_EXC) {
@@ -2502,6 +2511,17 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       } else {
         s0 = asc[codes & 0xffu]; s1 = asc[(codes >> 8) & 0xffu]; s2 = asc[(codes >> 16) & 0xffu]; s3 = asc[codes >> 24];
       }
+      if (SLOT && n < 16u) {
+        // padding bytes are 0: the qualities' and a forward read's bases' high 16 - n bytes, a reverse mate's low ones
+        const uint4 m1 = nmask[n];                      // 0x01 in the low n bytes
+        qr[0] &= m1.x * 255u; qr[1] &= m1.y * 255u; qr[2] &= m1.z * 255u; qr[3] &= m1.w * 255u;
+        const uint4 d1 = nmask[16u - n];                // 0x01 in the low 16 - n bytes
+        const uint32_t k0m = rev ? ~(d1.x * 255u) : m1.x * 255u, k1m = rev ? ~(d1.y * 255u) : m1.y * 255u;
+        const uint32_t k2m = rev ? ~(d1.z * 255u) : m1.z * 255u, k3m = rev ? ~(d1.w * 255u) : m1.w * 255u;
+        s0 &= k0m; s1 &= k1m; s2 &= k2m; s3 &= k3m;
+      }
+      // qualities are already offset-encoded, forward order
+      const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
       const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
 #if defined(SIMMR_PREFETCH_CODES)
       if (item + 256u < i_end) { r_next = locate(item + 256u); raw_next = plane_word(item + 256u, r_next); }
@@ -2543,7 +2563,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       // 16 bytes would leave the streams: the last groups of the shard keep their exact stores
       if (n == 16u || (uint64_t)(o_q > o_s ? o_q : o_s) + out0 + 16u <= u_off[n_units]) {
 #else
-      if (n == 16u) {
+      if (SLOT || n == 16u) {
 #endif
         if (!COPY_ONLY) store16(qd, q_lo, q_hi);
         store16(sd, s_lo, s_hi);

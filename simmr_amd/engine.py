@@ -38,9 +38,10 @@ class Reads:
     n_reads: int
     total_bases: int
     qual_offset: int = 0
+    slot_bytes: int = 0  # 0: compact streams; 16: SIMMR_SLOT16 (include/simmr_hip.h, simmr_reads_out)
 
     @classmethod
-    def allocate(cls, n_reads: int, total_bases: int, device, qual_offset: int = 0) -> "Reads":
+    def allocate(cls, n_reads: int, total_bases: int, device, qual_offset: int = 0, slot_bytes: int = 0) -> "Reads":
         torch = _torch()
         n = max(int(n_reads), 1)
         # the library needs exactly total_bases bytes (include/simmr_hip.h); the slack only keeps torch views of
@@ -56,7 +57,8 @@ class Reads:
             genome=torch.empty(n, dtype=torch.int32, device=device),
             read_id=torch.empty(n, dtype=torch.int32, device=device),
             flags=torch.empty(n, dtype=torch.uint8, device=device),
-            n_reads=int(n_reads), total_bases=int(total_bases), qual_offset=int(qual_offset))
+            n_reads=int(n_reads), total_bases=int(total_bases), qual_offset=int(qual_offset),
+            slot_bytes=int(slot_bytes))
 
     def pod(self) -> ReadsOut:
         o = ReadsOut()
@@ -72,10 +74,29 @@ class Reads:
         o.seq_capacity = self.seq.numel()
         o.reads_capacity = self.start.numel()
         o.qual_offset = self.qual_offset
+        o.slot_bytes = self.slot_bytes
         return o
 
     def to_host(self) -> dict:
-        """numpy copies, trimmed to the planned sizes."""
+        """numpy copies, trimmed to the planned sizes.  Reads emitted into 16-byte slots (SIMMR_SLOT16) come back in
+        the compact form — seq / qual without the padding, CSR seq_off — so that a consumer sees one layout; the
+        columns as they lie in HBM are `raw_to_host()`."""
+        h = self.raw_to_host()
+        if self.slot_bytes != 16:
+            return h
+        n = self.n_reads
+        a, b = h["start"].astype(np.int64), h["end"].astype(np.int64)
+        L = np.abs(b - a)                                   # a read's length in this layout
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(L, out=off[1:])
+        first = h["seq_off"][:n].astype(np.int64)           # first base; the qualities start at first & ~15
+        within = np.arange(int(off[n]), dtype=np.int64) - np.repeat(off[:n], L)
+        h["seq"] = h["seq"][np.repeat(first, L) + within]
+        h["qual"] = h["qual"][np.repeat(first & ~np.int64(15), L) + within]
+        h["seq_off"] = off.astype(np.uint64)
+        return h
+
+    def raw_to_host(self) -> dict:
         n, tb = self.n_reads, self.total_bases
         return {
             "seq": self.seq[:tb].cpu().numpy(),
@@ -126,6 +147,10 @@ class Engine:
     def use_current_torch_stream(self):
         s = _torch().cuda.current_stream(self.device)
         self._check(self.lib.simmr_engine_set_stream(self._h, C.c_void_p(s.cuda_stream)))
+
+    def set_read_slots(self, slot_bytes: int):
+        """Layout of the reads that plans made from now on emit: 0 compact, 16 = SIMMR_SLOT16 (simmr_engine_set_read_slots)."""
+        self._check(self.lib.simmr_engine_set_read_slots(self._h, int(slot_bytes)))
 
     # -- staging ------------------------------------------------------------
     def stage_genome(self, genome_idx: int, contigs: Sequence, sizes: Optional[Sequence[int]] = None):
@@ -210,7 +235,7 @@ class Engine:
     def simulate_pe_reads_multi(self, genome_idx, genome_reads, profile, seed, first=0, count=U64_MAX,
                                 qual_offset=0) -> Reads:
         info = self.pe_plan_multi(genome_idx, genome_reads, profile, seed, first, count)
-        out = Reads.allocate(info.n_reads, info.total_bases, self.device, qual_offset)
+        out = Reads.allocate(info.n_reads, info.total_bases, self.device, qual_offset, info.slot_bytes)
         self.pe_emit(0, out)
         return out
 
@@ -223,7 +248,7 @@ class Engine:
                                       read_id_base: int = 0, qual_offset: int = 0,
                                       start: Tuple[int, int] = (0, 0)) -> Reads:
         info = self.pe_plan(genome_idx, profile, genome_reads, seed, first, count, start)
-        out = Reads.allocate(info.n_reads, info.total_bases, self.device, qual_offset)
+        out = Reads.allocate(info.n_reads, info.total_bases, self.device, qual_offset, info.slot_bytes)
         self.pe_emit(read_id_base, out)
         return out
 
@@ -246,7 +271,7 @@ class Engine:
     def simulate_long_reads(self, genome_idx, genome_reads, profile, seed, first=0, count=U64_MAX,
                             read_id_base=0, qual_offset=0) -> Reads:
         info = self.long_plan(genome_idx, genome_reads, profile, seed, first, count)
-        out = Reads.allocate(info.n_reads, info.total_bases, self.device, qual_offset)
+        out = Reads.allocate(info.n_reads, info.total_bases, self.device, qual_offset, info.slot_bytes)
         self.long_emit(read_id_base, out)
         return out
 
