@@ -82,6 +82,9 @@ struct simmr_engine {
   uint64_t plan_first = 0, plan_units = 0, plan_total_bases = 0;
   uint32_t read_slots = 0;  // simmr_engine_set_read_slots: the layout of the plans to come (0 compact, 16 SIMMR_SLOT16)
   uint32_t plan_slot = 0;   // ... and of the plan in force
+  bool plan_coarse = false; // pairs for the counter-mode kernel: u_off64 (first byte of every 64th pair) instead of u_off
+  DevBuf w_bytes, u_off64;
+  bool fine_offsets = false;  // SIMMR_FINE_OFFSETS=1: per-pair offsets for the counter-mode kernel too (A/B timing)
   bool plan_paired = false;
   bool plan_multi = false;    // paired-end plan over several genomes (u_genome per pair)
   bool plan_any_exc = false;  // some genome of the plan has an exception plane
@@ -721,6 +724,14 @@ int plan_slot_round(simmr_engine* e, const ProfileDev& prof, uint32_t* round) {
   return SIMMR_OK;
 }
 
+// Pair plans whose emit kernel is the counter-mode item kernel get no per-pair offsets: the plan kernel leaves the bytes
+// of every 64 pairs, their scan (u_off64) places the emit kernel's blocks, and a block places its own reads
+// (k_emit_philox: `coarse`).  The tile form (SIMMR_PHILOX_FORM=2) reads per-pair offsets.
+bool plan_is_coarse(simmr_engine* e, const ProfileDev& prof) {
+  return prof.rng_mode == SIMMR_RNG_PHILOX && prof.kind != SIMMR_K_CUSTOM && prof.kind != SIMMR_K_PERFECT_SHORT && e->philox_form != 2 &&
+         !e->fine_offsets;
+}
+
 int check_out(simmr_engine* e, const simmr_reads_out* out, uint64_t n_reads, uint64_t total) {
   if (!out) return e->fail(SIMMR_EINVAL, "out is NULL");
   if (!out->seq_off) return e->fail(SIMMR_EINVAL, "out->seq_off is NULL");
@@ -743,6 +754,21 @@ OutCols out_cols(const simmr_reads_out* out) {
   o.seq_off = out->seq_off; o.start = out->start; o.end = out->end; o.contig = out->contig;
   o.genome = out->genome; o.read_id = out->read_id; o.flags = out->flags;
   return o;
+}
+
+// the instantiation of the counter-mode item kernel for (exception plane, contig bases in LDS, escapes noticed through
+// the quality byte, 16-byte read slots, block offsets from the coarse scan)
+using PhiloxKernel = decltype(&k_emit_philox<false, false, false, false, false, false, false>);
+template <bool EXC, bool CACHED, bool ESCQ>
+static PhiloxKernel philox_kernel3(bool slot, bool coarse) {
+  return slot ? (coarse ? k_emit_philox<EXC, false, CACHED, false, ESCQ, true, true> : k_emit_philox<EXC, false, CACHED, false, ESCQ, true, false>)
+              : (coarse ? k_emit_philox<EXC, false, CACHED, false, ESCQ, false, true> : k_emit_philox<EXC, false, CACHED, false, ESCQ, false, false>);
+}
+static PhiloxKernel philox_kernel(bool exc, bool cached, bool escq, bool slot, bool coarse) {
+  if (exc) return cached ? (escq ? philox_kernel3<true, true, true>(slot, coarse) : philox_kernel3<true, true, false>(slot, coarse))
+                         : (escq ? philox_kernel3<true, false, true>(slot, coarse) : philox_kernel3<true, false, false>(slot, coarse));
+  return cached ? (escq ? philox_kernel3<false, true, true>(slot, coarse) : philox_kernel3<false, true, false>(slot, coarse))
+                : (escq ? philox_kernel3<false, false, true>(slot, coarse) : philox_kernel3<false, false, false>(slot, coarse));
 }
 
 int stream_grid(simmr_engine* e, uint64_t n_units) {
@@ -805,6 +831,7 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
   if (const char* v = getenv("SIMMR_TILE_WGS_PER_CU")) e->tile_wgs_per_cu = (uint32_t)std::min<unsigned long long>(16, strtoull(v, nullptr, 10));
   if (const char* v = getenv("SIMMR_SPLICE_VARIANT")) e->splice_variant = atoi(v);
   if (const char* v = getenv("SIMMR_FASTQ_HEADERS")) e->fastq_headers_form = atoi(v);
+  if (const char* v = getenv("SIMMR_FINE_OFFSETS")) e->fine_offsets = atoi(v) != 0;
   bool ok = e->d_tables.ensure(sizeof(Tables)) && e->d_counters.ensure(8 * SIMMR_N_COUNTERS) &&
             e->d_err.ensure(64) && e->d_scalars.ensure(256);
   ok = ok && hipEventCreate(&e->ev_a) == hipSuccess && hipEventCreate(&e->ev_b) == hipSuccess &&
@@ -932,7 +959,7 @@ void simmr_engine_destroy(simmr_engine* e) {
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
                     &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->c_kslots, &e->c_krecs, &e->c_kdirect, &e->c_kcnt8, &e->c_kcols, &e->ph_table,
                     &e->fq_blob, &e->fq_gid_off, &e->fq_gid_len, &e->fq_cbase, &e->fq_ncontig, &e->fq_coff, &e->fq_clen,
-                    &e->fq_len, &e->fq_off, &e->m_genomes, &e->m_contig, &e->m_seed};
+                    &e->fq_len, &e->fq_off, &e->m_genomes, &e->m_contig, &e->m_seed, &e->w_bytes, &e->u_off64};
   for (DevBuf* b : bufs) b->release();
   if (e->ev_a) (void)hipEventDestroy(e->ev_a);
   if (e->ev_b) (void)hipEventDestroy(e->ev_b);
@@ -1212,6 +1239,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
   uint64_t end_slot = 0, total = 0;
   bool presummed = false;
+  const bool coarse = plan_is_coarse(e, prof);
   if (count > 0) {
     // the stream is entered at pair start_unit (slot start_slot): units are counted from there
     rc = run_outer(e, seed, g.contigs.size(), start_slot, first - start_unit + count, first - start_unit, count,
@@ -1221,14 +1249,16 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     // the mutation seed of mate 2 is only read by the kernels that walk the reference's mutation stream
     if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode == SIMMR_RNG_PHILOX) pw.ms2 = nullptr;
     // the plan kernel adds each pair's bytes to its tile of the offset scan (sort_by_length uses the same scratch first)
-    presummed = prof.kind != SIMMR_K_PERFECT_SHORT &&
+    presummed = prof.kind != SIMMR_K_PERFECT_SHORT && !coarse &&
                 !(prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0);
     unsigned long long* tiles = presummed ? tile_sums_begin(e, count) : nullptr;
     if (presummed && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
+    if (coarse && !e->w_bytes.ensure(((count + 63) / 64) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
     hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                        e->d_genomes.as<GenomeDev>(), genome_idx, count, e->u_contig.as<uint32_t>(),
                        e->u_seed.as<uint64_t>(), (const uint32_t*)nullptr, pw,
-                       e->d_tables.as<Tables>(), e->d_err.as<uint32_t>(), tiles, slot_round);
+                       e->d_tables.as<Tables>(), e->d_err.as<uint32_t>(), tiles, slot_round,
+                       coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr);
   }
   e->plan_sorted = false;
   if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0 &&
@@ -1236,6 +1266,8 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     return rc;
   if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
     total = count * 2ull * prof.read_length;  // constant lengths (perfect_short.rs:22-40): read r starts at r * L
+  } else if (coarse) {  // the first output byte of every 64th pair is all the counter-mode emit kernel asks for
+    if ((rc = scan_u64(e, e->w_bytes, (count + 63) / 64, e->u_off64, &total))) return rc;
   } else if ((rc = presummed ? scan_presummed<uint32_t>(e, e->u_len, count, 2u, e->u_off, &total, slot_round) : scan_offsets(e, count, 2u, &total, slot_round))) {
     return rc;
   }
@@ -1253,6 +1285,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   e->prof = prof;
   e->plan_genome = genome_idx;
   e->plan_slot = slot_round ? SIMMR_SLOT16 : 0u;
+  e->plan_coarse = coarse;
   e->plan_first = first;
   e->plan_units = count;
   e->plan_total_bases = total;
@@ -1333,6 +1366,7 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
   HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
   uint64_t end_slot = 0, total = 0;
   bool presummed = false;
+  const bool coarse = plan_is_coarse(e, prof);
   for (const Cls& c : classes) {  // run_outer synchronises, so `mg` has been uploaded when it returns
     if ((rc = run_outer(e, seed, c.range, 0, c.need, 0, c.need, e->m_contig.as<uint32_t>() + c.off,
                         e->m_seed.as<uint64_t>() + c.off, &end_slot)))
@@ -1344,19 +1378,23 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
                        e->u_genome.as<uint32_t>(), e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>());
     PlanArrays pw = plan_arrays(e, seeds2);
     if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode == SIMMR_RNG_PHILOX) pw.ms2 = nullptr;
-    presummed = prof.kind != SIMMR_K_PERFECT_SHORT && !(prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE);
+    presummed = prof.kind != SIMMR_K_PERFECT_SHORT && !coarse && !(prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE);
     unsigned long long* tiles = presummed ? tile_sums_begin(e, count) : nullptr;
     if (presummed && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
+    if (coarse && !e->w_bytes.ensure(((count + 63) / 64) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
     hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                        e->d_genomes.as<GenomeDev>(), 0u, count, e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(),
                        e->u_genome.as<uint32_t>(), pw, e->d_tables.as<Tables>(),
-                       e->d_err.as<uint32_t>(), tiles, slot_round);
+                       e->d_err.as<uint32_t>(), tiles, slot_round,
+                       coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr);
   }
   e->plan_sorted = false;
   if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && (rc = sort_by_length(e, count, 0)))
     return rc;
   if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
     total = count * 2ull * prof.read_length;
+  } else if (coarse) {
+    if ((rc = scan_u64(e, e->w_bytes, (count + 63) / 64, e->u_off64, &total))) return rc;
   } else if ((rc = presummed ? scan_presummed<uint32_t>(e, e->u_len, count, 2u, e->u_off, &total, slot_round) : scan_offsets(e, count, 2u, &total, slot_round))) {
     return rc;
   }
@@ -1372,6 +1410,7 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
   e->prof = prof;
   e->plan_genome = genome_idx[0];
   e->plan_slot = slot_round ? SIMMR_SLOT16 : 0u;
+  e->plan_coarse = coarse;
   e->plan_first = first;
   e->plan_units = count;
   e->plan_total_bases = total;
@@ -1461,20 +1500,14 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
 #if defined(SIMMR_NO_ESCQ)
         escq = false;  // measurement build: the flag-bit form on every input
 #endif
-        auto kern = escq ? (cached ? (exc ? k_emit_philox<true, false, true, false, true> : k_emit_philox<false, false, true, false, true>)
-                                   : (exc ? k_emit_philox<true, false, false, false, true> : k_emit_philox<false, false, false, false, true>))
-                         : (cached ? (exc ? k_emit_philox<true, false, true> : k_emit_philox<false, false, true>)
-                                   : (exc ? k_emit_philox<true, false, false> : k_emit_philox<false, false, false>));
-        if (e->plan_slot)  // 16-byte read slots (SIMMR_SLOT16): whole aligned 16-byte stores only
-          kern = escq ? (cached ? (exc ? k_emit_philox<true, false, true, false, true, true> : k_emit_philox<false, false, true, false, true, true>)
-                                : (exc ? k_emit_philox<true, false, false, false, true, true> : k_emit_philox<false, false, false, false, true, true>))
-                      : (cached ? (exc ? k_emit_philox<true, false, true, false, false, true> : k_emit_philox<false, false, true, false, false, true>)
-                                : (exc ? k_emit_philox<true, false, false, false, false, true> : k_emit_philox<false, false, false, false, false, true>));
+        const bool coarse = paired && e->plan_coarse;
+        auto kern = philox_kernel(exc, cached, escq, e->plan_slot != 0, coarse);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->prof, paired ? 1u : 0u,
                            e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                            e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
                            out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters,
-                           (const uint64_t*)nullptr, (const uint8_t*)nullptr, (const FqTemplate*)nullptr, FqTables{}, 0u, 0u, 0u);
+                           (const uint64_t*)nullptr, (const uint8_t*)nullptr, (const FqTemplate*)nullptr, FqTables{}, 0u, 0u, 0u,
+                           coarse ? (const uint64_t*)e->u_off64.as<uint64_t>() : (const uint64_t*)nullptr);
       }
     } else if (e->prof.kind == SIMMR_K_CUSTOM && !paired) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
@@ -1523,7 +1556,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
                          (const uint32_t*)nullptr, e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset,
                          e->plan_first, read_id_base, out_cols(out), counters, (const uint64_t*)nullptr, (const uint8_t*)nullptr,
-                         (const FqTemplate*)nullptr, FqTables{}, 0u, 0u, 0u);
+                         (const FqTemplate*)nullptr, FqTables{}, 0u, 0u, 0u, (const uint64_t*)nullptr);
     } else if (e->emit_variant == 0) {
       // lane-per-read kernel: template on (exception plane present, paired, perfect-long Phred)
       bool exc = false;
@@ -1704,6 +1737,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   e->prof = prof;
   e->plan_genome = 0;
   e->plan_slot = slot_round ? SIMMR_SLOT16 : 0u;
+  e->plan_coarse = false;
   e->plan_first = first;
   e->plan_units = count;
   e->plan_total_bases = total;
@@ -2061,7 +2095,8 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
                        e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome,
                        e->u_seed.as<uint64_t>(), dst, dst, 33u, e->plan_first, e->fq_read_id_base, OutCols{}, counters,
                        e->fq_off.as<uint64_t>(), e->fq_hlen.as<uint8_t>(),
-                       own_headers ? e->fq_tpl_dev.as<FqTemplate>() : (const FqTemplate*)nullptr, tb, e->fq_lit_bytes, e->fq_hpitch, wshift);
+                       own_headers ? e->fq_tpl_dev.as<FqTemplate>() : (const FqTemplate*)nullptr, tb, e->fq_lit_bytes, e->fq_hpitch, wshift,
+                       (const uint64_t*)nullptr);
   }
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
   if (e->fastq_headers_form != 0) {  // SIMMR_FASTQ_HEADERS=1: headers by a kernel of their own (measurement)

@@ -88,6 +88,23 @@ SIMMR_DEV uint32_t wg_exclusive_scan_u32(uint32_t v, uint32_t* lds4, uint32_t* t
 SIMMR_DEV uint32_t wg_exclusive_scan_u32(uint32_t v, uint32_t* lds4, uint32_t* total) {
   return wg_exclusive_scan_u32(v, lds4, total, threadIdx.x);
 }
+// two 32-bit values scanned together (one barrier): v = lo | hi << 32, no carry from lo into hi as long as the
+// workgroup's sum of lo stays below 2^32; lds4: four u64
+SIMMR_DEV uint64_t wg_exclusive_scan_2x32(uint64_t v, uint64_t* lds4, uint64_t* total, uint32_t tid) {
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  uint64_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc += o;
+  }
+  if (lane == 63) lds4[wave] = inc;
+  lds_barrier();
+  const uint64_t t0 = lds4[0], t1 = lds4[1], t2 = lds4[2], t3 = lds4[3];
+  const uint64_t pre = (wave > 0 ? t0 : 0ull) + (wave > 1 ? t1 : 0ull) + (wave > 2 ? t2 : 0ull);
+  *total = t0 + t1 + t2 + t3;
+  return pre + inc - v;
+}
 
 // ---------------------------------------------------------------------------
 // FASTA bodies -> planes on the device (simmr_stage_fasta): needletail 0.4.1
@@ -568,16 +585,23 @@ extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
 k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
           const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
           const uint32_t* __restrict__ u_genome, PlanArrays pl, const Tables* __restrict__ T,
-          uint32_t* __restrict__ err, unsigned long long* __restrict__ tile_bytes, uint32_t slot_round) {
+          uint32_t* __restrict__ err, unsigned long long* __restrict__ tile_bytes, uint32_t slot_round,
+          unsigned long long* __restrict__ wave_bytes) {
   __shared__ uint32_t rows[PLAN_THREADS * 17];
   uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
   const uint32_t planned = k < n_units ? k_plan_pe_unit(prof, genomes, genome, k, u_contig, u_seed, u_genome, pl, T, err, rows) : 0u;
   // The bytes this workgroup's pairs will write, added to the sum of their tile of the offset scan (SCAN_THREADS *
   // SCAN_ITEMS units: a multiple of this workgroup's 256), so that the scan needs no pass of its own to reduce them.
-  if (tile_bytes) {
+  // Or (wave_bytes: the plans the counter-mode emit kernel serves) the bytes of every 64 pairs by themselves: that kernel
+  // takes a block's first output byte from the scan of THESE and places the block's reads with a scan of its own, so the
+  // per-pair offsets (50 M entries, 0.4 ms) are never made.
+  if (tile_bytes || wave_bytes) {
     unsigned long long s = 2ull * ((planned + slot_round) & ~slot_round);  // (slot_round = 15 for 16-byte read slots, else 0)
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-    if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&tile_bytes[((uint64_t)blockIdx.x * PLAN_THREADS) / (SCAN_THREADS * SCAN_ITEMS)], s);
+    if ((threadIdx.x & 63u) == 0) {
+      if (wave_bytes) wave_bytes[((uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x) >> 6] = s;
+      else if (s) atomicAdd(&tile_bytes[((uint64_t)blockIdx.x * PLAN_THREADS) / (SCAN_THREADS * SCAN_ITEMS)], s);
+    }
   }
 }
 
@@ -2159,7 +2183,7 @@ SIMMR_DEV void philox_repair(const uint32_t k0, const uint32_t k1, const uint32_
 // bytes on a 16-byte boundary (u_off is the scan of the padded lengths), qualities and forward bases left-aligned, the
 // bases of a reverse-complemented mate right-aligned — so EVERY item, the partial group at a read's end included, is one
 // whole aligned 16-byte store per stream (padding written as 0) and the byte ladder of store_tail2 is gone.
-template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false, bool ESCQ = false, bool SLOT = false>
+template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false, bool ESCQ = false, bool SLOT = false, bool COARSE = false>
 __global__ void __launch_bounds__(256)
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
@@ -2168,7 +2192,11 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
               uint32_t qual_offset, uint64_t first_unit, uint32_t read_id_base, OutCols o,
               unsigned long long* __restrict__ counters, const uint64_t* __restrict__ rec_off = nullptr,
               const uint8_t* __restrict__ hlen = nullptr, const FqTemplate* __restrict__ fq_tp = nullptr, FqTables fq_tb = FqTables{},
-              uint32_t fq_lit_bytes = 0, uint32_t fq_hpitch = 0, uint32_t fq_wshift = 0) {
+              uint32_t fq_lit_bytes = 0, uint32_t fq_hpitch = 0, uint32_t fq_wshift = 0,
+              const uint64_t* __restrict__ off64 = nullptr) {
+  // off64 != null ("coarse" plans, engine.hip): u_off does not exist; off64[w] = first output byte of pair 64 w (the scan
+  // of the plan kernel's per-wave byte sums), and a block places its reads with a scan of their (padded) lengths
+  constexpr bool coarse = COARSE && !TEXT;
   // TEXT: header slots of FQ_GROUP reads at a time (dynamic LDS, FQ_GROUP * fq_hpitch bytes), the template and its literals
   extern __shared__ __attribute__((aligned(16))) uint8_t fq_slots[];
   __shared__ __attribute__((aligned(16))) uint8_t fq_lit[TEXT ? FQ_LIT_MAX + 8 : 1];
@@ -2191,6 +2219,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ uint4 nmask[17];    // byte masks of the first n bytes of 16
   __shared__ uint32_t nmask2[17]; // the low 2n bits
   __shared__ uint32_t lds4[4];
+  __shared__ uint64_t lds4w[COARSE ? 4 : 1];
   const uint32_t qoff = qual_offset & 0xffu;
   // Where an escaped base (one item in 9 000) is noticed.  When every encoded quality the level-1 table can answer is
   // below 128 (the usual case: Phred + 33), an escape cell answers the byte 0xff and one test of the item's four quality
@@ -2245,11 +2274,13 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     const uint32_t nu = (n_units - u0) < PHILOX_UNITS ? (uint32_t)(n_units - u0) : PHILOX_UNITS;
     const uint32_t nr = nu * rpu;
     // the block's first output byte (same for every lane: a scalar load)
-    const uint64_t out0 = TEXT ? rec_off[paired ? 2 * u0 : u0] : u_off[u0];
+    const uint64_t out0 = TEXT ? rec_off[paired ? 2 * u0 : u0] : (coarse ? off64[u0 >> 6] : u_off[u0]);
     uint8_t* const seq_blk = seq + out0;
     uint8_t* const qual_blk = (TEXT ? seq : qual) + out0;
     lds_barrier();  // the previous block's items are done with the records
     uint32_t g = 0;
+    uint32_t my_Lp = 0, my_pad = 0;  // this thread's read: its place in the streams, and (SLOT, reverse mate) the padding in front
+    uint64_t my_rd = 0, my_dst = 0;
     FqFields hf{};           // TEXT: what this thread's read shows in its header
     uint64_t h_rec = 0, h_rd = 0;
     if (threadIdx.x < nr) {
@@ -2262,7 +2293,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint32_t genome = (!CACHED && u_genome) ? u_genome[u] : genome_const;
       const uint64_t rd = paired ? 2 * u + rev : u;
       const uint32_t Lp = SLOT ? ((L + 15u) & ~15u) : L;  // the read's place in the streams
-      const uint64_t dst = TEXT ? rec_off[rd] + hlen[rd] + 1u : u_off[u] + (rev ? Lp : 0u);
+      const uint64_t dst = TEXT ? rec_off[rd] + hlen[rd] + 1u : (coarse ? out0 : u_off[u] + (rev ? Lp : 0u));  // (coarse: after the scan below)
+      my_Lp = Lp; my_pad = (SLOT && rev) ? Lp - L : 0u; my_rd = rd; my_dst = dst;
       const uint64_t pos = rev ? pl.b[u] : pl.a[u];  // first source base of this read on the contig
       const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
       uint64_t cb;
@@ -2304,8 +2336,6 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           h_rec = rec_off[rd]; h_rd = rd;
         }
         if (!TEXT) {
-          o.seq_off[rd] = (SLOT && rev) ? dst + (Lp - L) : dst;  // first base (SLOT: a reverse mate's bases are right-aligned)
-          if (rd + 1 == n_reads) o.seq_off[n_reads] = u_off[n_units];  // closing CSR offset
           if (paired) {
             if (o.start) o.start[rd] = rev ? pos + L : pos;  // simulate.rs:289,295
             if (o.end) o.end[rd] = rev ? pos : pos + L;      // simulate.rs:290,296
@@ -2364,8 +2394,21 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         }
       }
     }
-    uint32_t n_items;
-    const uint32_t ex = wg_exclusive_scan_u32<true>(g, lds4, &n_items, threadIdx.x);
+    uint32_t n_items, ex;
+    if (coarse) {  // the reads' places too: the scan of their (padded) lengths rides in the upper half
+      uint64_t tot2;
+      const uint64_t ex2 = wg_exclusive_scan_2x32((uint64_t)g | ((uint64_t)my_Lp << 32), lds4w, &tot2, threadIdx.x);
+      ex = (uint32_t)ex2; n_items = (uint32_t)tot2;
+      if (threadIdx.x < nr) { recs[threadIdx.x].dst = (uint32_t)(ex2 >> 32); my_dst = out0 + (ex2 >> 32); }
+    } else {
+      ex = wg_exclusive_scan_u32<true>(g, lds4, &n_items, threadIdx.x);
+    }
+#if !defined(SIMMR_ABLATE_META)
+    if (!TEXT && !COPY_ONLY && threadIdx.x < nr) {
+      o.seq_off[my_rd] = my_dst + my_pad;  // first base (SLOT: a reverse mate's bases are right-aligned)
+      if (my_rd + 1 == n_reads) o.seq_off[n_reads] = coarse ? off64[(n_units + 63u) >> 6] : u_off[n_units];  // closing CSR offset
+    }
+#endif
     if (threadIdx.x < nr) recs[threadIdx.x].gs = ex;
     r_gs[threadIdx.x] = threadIdx.x < nr ? ex : 0xffffffffu;
     if (threadIdx.x == 0) r_gs[PHILOX_READS] = 0xffffffffu;
@@ -2533,7 +2576,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       // timing only: every 16-byte store instruction of a wave writes sixteen WHOLE 64-byte lines (the wave's first
       // lane's place rounded down to 1 KB, then lane by lane); wrong places, and clamped so that the 1 KB stays
       // inside the total_bases bytes of the streams (a shard of less than 1 KB writes nothing at all)
-      const uint64_t abl_total = u_off[n_units];
+      const uint64_t abl_total = coarse ? off64[(n_units + 63u) >> 6] : u_off[n_units];
       const uint64_t abl_last = abl_total >= 1024u ? ((abl_total - 1024u) & ~1023ull) : 0u;
       uint64_t abl_q = ((uint64_t)__builtin_amdgcn_readfirstlane(o_q) + out0) & ~1023ull;
       uint64_t abl_s = ((uint64_t)__builtin_amdgcn_readfirstlane(o_s) + out0) & ~1023ull;
@@ -2561,7 +2604,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #elif defined(SIMMR_ABLATE_ALL16)
       // timing only: partial groups store 16 bytes too (they overwrite the head of the next read) — except where those
       // 16 bytes would leave the streams: the last groups of the shard keep their exact stores
-      if (n == 16u || (uint64_t)(o_q > o_s ? o_q : o_s) + out0 + 16u <= u_off[n_units]) {
+      if (n == 16u || (uint64_t)(o_q > o_s ? o_q : o_s) + out0 + 16u <= (coarse ? off64[(n_units + 63u) >> 6] : u_off[n_units])) {
 #else
       if (SLOT || n == 16u) {
 #endif

@@ -7,6 +7,6 @@ for r in $(seq 1 "$rounds"); do
   for nv in "$@"; do
     name="${nv%%=*}"; lib="${nv#*=}"
     out=$(SIMMR_HIP_LIB="$lib" timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-mode $args 2>/dev/null | tail -1)
-    echo "$name round $r: $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print("kernel_ms=%.3f ms_per_step=%.3f value=%.4g subst=%.6f phred=%.4f" % (d["roofline"]["kernel_ms"], d["ms_per_step"], d["value"], d.get("substitution_rate", 0), d.get("mean_phred", 0)))' 2>&1)"
+    echo "$name round $r: $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print("kernel_ms=%.3f ms_per_step=%.3f plan_ms=%.3f value=%.4g subst=%.6f phred=%.4f" % (d["roofline"]["kernel_ms"], d["ms_per_step"], d["plan_ms_per_step"], d["value"], d.get("substitution_rate", 0), d.get("mean_phred", 0)))' 2>&1)"
   done
 done
