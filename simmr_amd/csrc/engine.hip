@@ -727,6 +727,19 @@ int plan_slot_round(simmr_engine* e, const ProfileDev& prof, uint32_t* round) {
 // Pair plans whose emit kernel is the counter-mode item kernel get no per-pair offsets: the plan kernel leaves the bytes
 // of every 64 pairs, their scan (u_off64) places the emit kernel's blocks, and a block places its own reads
 // (k_emit_philox: `coarse`).  The tile form (SIMMR_PHILOX_FORM=2) reads per-pair offsets.
+// k_plan_pe for `count` pairs.  (Round 3 built a register form of it — the pair's ChaCha12 block in registers, every
+// usual draw a fixed word, the 1-2 % of the pairs whose draws take another way left to a second kernel: bit-exact in
+// the whole suite and no faster, 1.22 + 1.31 ms against 1.39: the kernel's thousand instructions per pair are PCG32 and
+// ChaCha12 either way, and the left-over pairs cost 5000 apiece once no neighbour shares their path.
+// profiles/r3/plan_register_form_kernels.txt)
+int launch_plan_pe(simmr_engine* e, const ProfileDev& prof, uint32_t genome, uint64_t count, const uint32_t* u_genome,
+                   const PlanArrays& pw, unsigned long long* tiles, uint32_t slot_round, unsigned long long* wave_bytes) {
+  hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
+                     e->d_genomes.as<GenomeDev>(), genome, count, e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(), u_genome, pw,
+                     e->d_tables.as<Tables>(), e->d_err.as<uint32_t>(), tiles, slot_round, wave_bytes);
+  return SIMMR_OK;
+}
+
 bool plan_is_coarse(simmr_engine* e, const ProfileDev& prof) {
   return prof.rng_mode == SIMMR_RNG_PHILOX && prof.kind != SIMMR_K_CUSTOM && prof.kind != SIMMR_K_PERFECT_SHORT && e->philox_form != 2 &&
          !e->fine_offsets;
@@ -1254,11 +1267,9 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     unsigned long long* tiles = presummed ? tile_sums_begin(e, count) : nullptr;
     if (presummed && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
     if (coarse && !e->w_bytes.ensure(((count + 63) / 64) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
-    hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
-                       e->d_genomes.as<GenomeDev>(), genome_idx, count, e->u_contig.as<uint32_t>(),
-                       e->u_seed.as<uint64_t>(), (const uint32_t*)nullptr, pw,
-                       e->d_tables.as<Tables>(), e->d_err.as<uint32_t>(), tiles, slot_round,
-                       coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr);
+    if ((rc = launch_plan_pe(e, prof, genome_idx, count, (const uint32_t*)nullptr, pw, tiles, slot_round,
+                             coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr)))
+      return rc;
   }
   e->plan_sorted = false;
   if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0 &&
@@ -1382,11 +1393,9 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
     unsigned long long* tiles = presummed ? tile_sums_begin(e, count) : nullptr;
     if (presummed && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
     if (coarse && !e->w_bytes.ensure(((count + 63) / 64) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
-    hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
-                       e->d_genomes.as<GenomeDev>(), 0u, count, e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(),
-                       e->u_genome.as<uint32_t>(), pw, e->d_tables.as<Tables>(),
-                       e->d_err.as<uint32_t>(), tiles, slot_round,
-                       coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr);
+    if ((rc = launch_plan_pe(e, prof, 0u, count, (const uint32_t*)e->u_genome.as<uint32_t>(), pw, tiles, slot_round,
+                             coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr)))
+      return rc;
   }
   e->plan_sorted = false;
   if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && (rc = sort_by_length(e, count, 0)))
