@@ -51,9 +51,10 @@ def main():
     ap.add_argument("--through-fastq", action="store_true",
                     help="one step = plan + FASTQ sizing + emit straight into FASTQ text resident in HBM (simmr_fastq_plan_direct / "
                          "simmr_emit_fastq: what the reference's run produces, main.rs:180-206), instead of the SoA columns")
-    ap.add_argument("--layout", default="compact", choices=["compact", "slot16"],
-                    help="slot16: every read in a 16-byte-aligned slot of seq / qual (SIMMR_SLOT16, include/simmr_hip.h): the "
-                         "counter-mode emit kernel then writes whole aligned 16-byte groups only; counter mode, minimal profiles")
+    ap.add_argument("--layout", default=None, choices=["compact", "slot16"],
+                    help="slot16 (the default where it is offered: counter mode, minimal profiles): every read in a 16-byte-aligned "
+                         "slot of seq / qual (SIMMR_SLOT16, include/simmr_hip.h), the emit kernel then writes whole aligned 16-byte "
+                         "groups only; compact: byte streams without gaps (the other one is timed once as `other_layout`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -111,6 +112,9 @@ def main():
     if args.rng == "philox" and args.profile != "perfect-short":
         prof.rng_mode = _abi.RNG_PHILOX
 
+    # default layout: the 16-byte read slots where the emit kernel offers them (counter mode, minimal profiles), else compact
+    if args.layout is None:
+        args.layout = "slot16" if (prof.rng_mode == _abi.RNG_PHILOX and custom is None and args.profile != "perfect-short") else "compact"
     slot16 = args.layout == "slot16"
     if slot16 and (prof.rng_mode != _abi.RNG_PHILOX or custom is not None):
         raise SystemExit("--layout slot16 is the counter mode's layout (minimal-short / minimal-long with --rng philox)")

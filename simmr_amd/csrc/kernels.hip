@@ -916,6 +916,17 @@ k_write_meta(uint32_t paired, uint64_t n_units, uint64_t first_unit, uint32_t re
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 typedef v4u32 __attribute__((aligned(1))) v4u32_unaligned;
+// A store into the output streams and columns.  They are written once and read by nobody on the device, so where a wave
+// writes WHOLE lines the stores are nontemporal (`nt`): the lines are not kept in L2 / MALL behind the write.  Same-box
+// A/B (profiles/r3/ab_nt_stores_*): k_emit_perfect_pe 6.3 against 7.4 ms per 100 M reads, k_emit_philox in the slot
+// layout 11.4 against 11.9 — and in the compact layout, whose 16-byte stores straddle lines and whose read ends are
+// written bytewise, 15.3 against 12.7: there the stores stay plain.  -DSIMMR_PLAIN_STORES: the A side.
+// (a macro, not a function template: the pointee types carry `aligned(1)`, which template deduction would drop)
+#if defined(SIMMR_PLAIN_STORES)
+#define stream_store(p, v) (*(p) = (v))
+#else
+#define stream_store(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 typedef const __attribute__((address_space(1))) u64_unaligned* global_u64_unaligned_ptr;
 SIMMR_DEV uint64_t load_plane_u64(const uint32_t* __restrict__ plane, int64_t word) {
   return *(global_u64_unaligned_ptr)(plane + word);  // words `word` and `word + 1`, 4-byte aligned
@@ -1048,14 +1059,14 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, const 
       if (MULTI) { r_packed[threadIdx.x] = Gr.packed; r_mask[threadIdx.x] = Gr.has_exc ? Gr.mask : nullptr; }
       r_pos[threadIdx.x] = (int64_t)(Gr.contigs[contig].base + (rev ? pos + L - 1 : pos));  // mate 2: byte k comes from pos - k
       // metadata columns of this read (k_write_meta is not launched for this kernel)
-      o.seq_off[r] = r * L;
+      stream_store(&o.seq_off[r], (uint64_t)(r * L));
       if (r + 1 == n_reads) o.seq_off[n_reads] = n_reads * L;  // closing CSR offset
-      if (o.start) o.start[r] = rev ? pos + L : pos;  // simulate.rs:289,295
-      if (o.end) o.end[r] = rev ? pos : pos + L;      // simulate.rs:290,296
-      if (o.contig) o.contig[r] = contig;
-      if (o.genome) o.genome[r] = gslot;
-      if (o.read_id) o.read_id[r] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
-      if (o.flags) o.flags[r] = rev ? (uint8_t)pl.flags[u] : 0;
+      if (o.start) stream_store(&o.start[r], (uint64_t)(rev ? pos + L : pos));  // simulate.rs:289,295
+      if (o.end) stream_store(&o.end[r], (uint64_t)(rev ? pos : pos + L));      // simulate.rs:290,296
+      if (o.contig) stream_store(&o.contig[r], contig);
+      if (o.genome) stream_store(&o.genome[r], gslot);
+      if (o.read_id) stream_store(&o.read_id[r], read_id_base + (uint32_t)(first_unit + u));  // simulate.rs:85-89,274
+      if (o.flags) stream_store(&o.flags[r], rev ? (uint8_t)pl.flags[u] : (uint8_t)0);
     }
     __syncthreads();
     uint32_t rl = rl0, k0 = k00;
@@ -1126,8 +1137,8 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, const 
           const uint32_t lb = cl << 4;
           const uint64_t byte0 = gbyte0 + lb;
           if (lb + 16u <= gbytes) {
-            *reinterpret_cast<uint4*>(seq + byte0) = out;
-            *reinterpret_cast<uint4*>(qual + byte0) = qv;
+            stream_store(reinterpret_cast<v4u32*>(seq + byte0), (v4u32{out.x, out.y, out.z, out.w}));
+            stream_store(reinterpret_cast<v4u32*>(qual + byte0), (v4u32{qv.x, qv.y, qv.z, qv.w}));
           } else {  // last partial chunk of the shard
             const uint32_t words[4] = {out.x, out.y, out.z, out.w};
             for (uint32_t i = 0; lb + i < gbytes; i++) {
@@ -1166,8 +1177,8 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, const 
       out.w = expand4(codes >> 24, (exc >> 12) & 0xfu);
       const uint64_t byte0 = gbyte0 + lb;
       if (lb + 16u <= gbytes) {
-        *reinterpret_cast<uint4*>(seq + byte0) = out;
-        *reinterpret_cast<uint4*>(qual + byte0) = qv;
+        stream_store(reinterpret_cast<v4u32*>(seq + byte0), (v4u32{out.x, out.y, out.z, out.w}));
+        stream_store(reinterpret_cast<v4u32*>(qual + byte0), (v4u32{qv.x, qv.y, qv.z, qv.w}));
       } else {  // last partial chunk of the shard
         const uint32_t words[4] = {out.x, out.y, out.z, out.w};
         for (uint32_t i = 0; lb + i < gbytes; i++) {
@@ -2055,18 +2066,22 @@ SIMMR_DEV uint32_t low_bytes(uint32_t x, int nb) {
   return nb >= 4 ? x : (nb <= 0 ? 0u : (x & ((1u << (8 * nb)) - 1u)));
 }
 // one 16-byte store at any byte address (global_store_dwordx4; one address-unit access per lane instead of two)
+template <bool NT = false>
 SIMMR_DEV void store16(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi) {
   v4u32 v;
   v.x = (uint32_t)lo; v.y = (uint32_t)(lo >> 32); v.z = (uint32_t)hi; v.w = (uint32_t)(hi >> 32);
-  *reinterpret_cast<v4u32_unaligned*>(d) = v;
+  if (NT) stream_store(reinterpret_cast<v4u32_unaligned*>(d), (v4u32_unaligned)v);
+  else *reinterpret_cast<v4u32_unaligned*>(d) = v;
 }
 // store the low n (< 16) bytes of the 128-bit value (lo, hi)
 SIMMR_DEV void store_tail(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi, uint32_t n) {
   uint64_t v = lo;
   uint32_t p = 0;
-  if (n & 8u) { *reinterpret_cast<u64_unaligned*>(d) = lo; v = hi; p = 8; }
-  if (n & 4u) { *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(d + p) = (uint32_t)v; v >>= 32; p += 4; }
-  if (n & 2u) { *reinterpret_cast<uint16_t __attribute__((aligned(1)))*>(d + p) = (uint16_t)v; v >>= 16; p += 2; }
+  typedef uint32_t __attribute__((aligned(1))) u32_un;
+  typedef uint16_t __attribute__((aligned(1))) u16_un;
+  if (n & 8u) { *reinterpret_cast<u64_unaligned*>(d) = (u64_unaligned)lo; v = hi; p = 8; }
+  if (n & 4u) { *reinterpret_cast<u32_un*>(d + p) = (u32_un)(uint32_t)v; v >>= 32; p += 4; }
+  if (n & 2u) { *reinterpret_cast<u16_un*>(d + p) = (u16_un)(uint16_t)v; v >>= 16; p += 2; }
   if (n & 1u) d[p] = (uint8_t)v;
 }
 
@@ -2076,15 +2091,17 @@ SIMMR_DEV void store_tail2(uint8_t* __restrict__ d0, uint64_t lo0, uint64_t hi0,
                             uint32_t n) {
   uint64_t v0 = lo0, v1 = lo1;
   uint32_t p = 0;
-  if (n & 8u) { *reinterpret_cast<u64_unaligned*>(d0) = lo0; *reinterpret_cast<u64_unaligned*>(d1) = lo1; v0 = hi0; v1 = hi1; p = 8; }
+  typedef uint32_t __attribute__((aligned(1))) u32_un;
+  typedef uint16_t __attribute__((aligned(1))) u16_un;
+  if (n & 8u) { *reinterpret_cast<u64_unaligned*>(d0) = (u64_unaligned)lo0; *reinterpret_cast<u64_unaligned*>(d1) = (u64_unaligned)lo1; v0 = hi0; v1 = hi1; p = 8; }
   if (n & 4u) {
-    *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(d0 + p) = (uint32_t)v0;
-    *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(d1 + p) = (uint32_t)v1;
+    *reinterpret_cast<u32_un*>(d0 + p) = (u32_un)(uint32_t)v0;
+    *reinterpret_cast<u32_un*>(d1 + p) = (u32_un)(uint32_t)v1;
     v0 >>= 32; v1 >>= 32; p += 4;
   }
   if (n & 2u) {
-    *reinterpret_cast<uint16_t __attribute__((aligned(1)))*>(d0 + p) = (uint16_t)v0;
-    *reinterpret_cast<uint16_t __attribute__((aligned(1)))*>(d1 + p) = (uint16_t)v1;
+    *reinterpret_cast<u16_un*>(d0 + p) = (u16_un)(uint16_t)v0;
+    *reinterpret_cast<u16_un*>(d1 + p) = (u16_un)(uint16_t)v1;
     v0 >>= 16; v1 >>= 16; p += 2;
   }
   if (n & 1u) { d0[p] = (uint8_t)v0; d1[p] = (uint8_t)v1; }
@@ -2197,6 +2214,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   // off64 != null ("coarse" plans, engine.hip): u_off does not exist; off64[w] = first output byte of pair 64 w (the scan
   // of the plan kernel's per-wave byte sums), and a block places its reads with a scan of their (padded) lengths
   constexpr bool coarse = COARSE && !TEXT;
+#define COL_STORE(p, v) do { if (SLOT) stream_store((p), (v)); else *(p) = (v); } while (0)  /* the metadata columns, as the streams */
   // TEXT: header slots of FQ_GROUP reads at a time (dynamic LDS, FQ_GROUP * fq_hpitch bytes), the template and its literals
   extern __shared__ __attribute__((aligned(16))) uint8_t fq_slots[];
   __shared__ __attribute__((aligned(16))) uint8_t fq_lit[TEXT ? FQ_LIT_MAX + 8 : 1];
@@ -2337,16 +2355,16 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         }
         if (!TEXT) {
           if (paired) {
-            if (o.start) o.start[rd] = rev ? pos + L : pos;  // simulate.rs:289,295
-            if (o.end) o.end[rd] = rev ? pos : pos + L;      // simulate.rs:290,296
+            if (o.start) COL_STORE(&o.start[rd], (uint64_t)(rev ? pos + L : pos));  // simulate.rs:289,295
+            if (o.end) COL_STORE(&o.end[rd], (uint64_t)(rev ? pos : pos + L));      // simulate.rs:290,296
           } else {
-            if (o.start) o.start[rd] = pos;                  // simulate.rs:515
-            if (o.end) o.end[rd] = pl.b[u];                  // simulate.rs:516
+            if (o.start) COL_STORE(&o.start[rd], (uint64_t)pos);                  // simulate.rs:515
+            if (o.end) COL_STORE(&o.end[rd], (uint64_t)pl.b[u]);                  // simulate.rs:516
           }
-          if (o.contig) o.contig[rd] = contig;
-          if (o.genome) o.genome[rd] = genome;
-          if (o.read_id) o.read_id[rd] = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
-          if (o.flags) o.flags[rd] = (paired && !rev) ? 0 : (uint8_t)fl;
+          if (o.contig) COL_STORE(&o.contig[rd], contig);
+          if (o.genome) COL_STORE(&o.genome[rd], genome);
+          if (o.read_id) COL_STORE(&o.read_id[rd], read_id_base + (uint32_t)(first_unit + u));  // simulate.rs:85-89,274
+          if (o.flags) COL_STORE(&o.flags[rd], (paired && !rev) ? (uint8_t)0 : (uint8_t)fl);
         }
         if (!rev) {
           p_bases += paired ? 2ull * L : (uint64_t)L;
@@ -2405,7 +2423,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     }
 #if !defined(SIMMR_ABLATE_META)
     if (!TEXT && !COPY_ONLY && threadIdx.x < nr) {
-      o.seq_off[my_rd] = my_dst + my_pad;  // first base (SLOT: a reverse mate's bases are right-aligned)
+      COL_STORE(&o.seq_off[my_rd], (uint64_t)(my_dst + my_pad));  // first base (SLOT: a reverse mate's bases are right-aligned)
       if (my_rd + 1 == n_reads) o.seq_off[n_reads] = coarse ? off64[(n_units + 63u) >> 6] : u_off[n_units];  // closing CSR offset
     }
 #endif
@@ -2608,8 +2626,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #else
       if (SLOT || n == 16u) {
 #endif
-        if (!COPY_ONLY) store16(qd, q_lo, q_hi);
-        store16(sd, s_lo, s_hi);
+        if (!COPY_ONLY) store16<SLOT>(qd, q_lo, q_hi);  // (whole aligned lines per wave in the slot layout: nontemporal)
+        store16<SLOT>(sd, s_lo, s_hi);
       } else if (!COPY_ONLY) {
         store_tail2(qd, q_lo, q_hi, sd, s_lo, s_hi, n);
       } else {
