@@ -83,7 +83,8 @@ struct simmr_engine {
   uint32_t read_slots = 0;  // simmr_engine_set_read_slots: the layout of the plans to come (0 compact, 16 SIMMR_SLOT16)
   uint32_t plan_slot = 0;   // ... and of the plan in force
   bool plan_coarse = false; // pairs for the counter-mode kernel: u_off64 (first byte of every 64th pair) instead of u_off
-  DevBuf w_bytes, u_off64;
+  DevBuf w_bytes, u_off64, fq_off64;
+  bool fq_coarse = false;  // the direct FASTQ plan in force has fq_off64 (first byte of every 64th record) instead of fq_off
   bool fine_offsets = false;  // SIMMR_FINE_OFFSETS=1: per-pair offsets for the counter-mode kernel too (A/B timing)
   bool plan_paired = false;
   bool plan_multi = false;    // paired-end plan over several genomes (u_genome per pair)
@@ -972,7 +973,7 @@ void simmr_engine_destroy(simmr_engine* e) {
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
                     &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->c_kslots, &e->c_krecs, &e->c_kdirect, &e->c_kcnt8, &e->c_kcols, &e->ph_table,
                     &e->fq_blob, &e->fq_gid_off, &e->fq_gid_len, &e->fq_cbase, &e->fq_ncontig, &e->fq_coff, &e->fq_clen,
-                    &e->fq_len, &e->fq_off, &e->m_genomes, &e->m_contig, &e->m_seed, &e->w_bytes, &e->u_off64};
+                    &e->fq_len, &e->fq_off, &e->m_genomes, &e->m_contig, &e->m_seed, &e->w_bytes, &e->u_off64, &e->fq_off64};
   for (DevBuf* b : bufs) b->release();
   if (e->ev_a) (void)hipEventDestroy(e->ev_a);
   if (e->ev_b) (void)hipEventDestroy(e->ev_b);
@@ -1988,6 +1989,11 @@ static FqPlan fq_plan_view(simmr_engine* e) {
   return pn;
 }
 
+// does the current plan's emit kernel write into FASTQ text (the counter-mode item kernel)?
+static bool fq_direct_kernel(const simmr_engine* e) {
+  return e->prof.kind != SIMMR_K_CUSTOM && e->prof.kind != SIMMR_K_PERFECT_SHORT && e->prof.rng_mode == SIMMR_RNG_PHILOX;
+}
+
 int simmr_fastq_plan_direct(simmr_engine* e, const char* header_format, const simmr_fastq_names* names,
                             uint32_t read_id_base, uint64_t* total_bytes) {
   if (!e) return SIMMR_EINVAL;
@@ -2006,13 +2012,21 @@ int simmr_fastq_plan_direct(simmr_engine* e, const char* header_format, const si
   HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
   e->fq_read_id_base = read_id_base;
   const FqTables tb = fq_tables(e, n_slots);
-  unsigned long long* tiles = tile_sums_begin(e, n_reads);
-  if (!tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
+  // When the emit kernel writes into the text and formats the headers itself it also places its own records: it asks for
+  // the first byte of every 64th record only (fq_off64, the scan of the size kernel's per-wave sums), not for fq_off.
+  const bool coarse = fq_direct_kernel(e) && e->fastq_headers_form == 0 && !e->fine_offsets;
+  const uint64_t n_w = (n_reads + 63) / 64;
+  unsigned long long* tiles = coarse ? nullptr : tile_sums_begin(e, n_reads);
+  if (!coarse && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
+  if (coarse && !e->w_bytes.ensure(std::max<uint64_t>(n_w, 1) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
   if (n_reads > 0)
     hipLaunchKernelGGL(k_fastq_size_plan, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, fq_plan_view(e),
-                       n_reads, e->fq_len.as<uint64_t>(), e->fq_hlen.as<uint8_t>(), e->d_err.as<uint32_t>(), tiles);
+                       n_reads, coarse ? (uint64_t*)nullptr : e->fq_len.as<uint64_t>(), e->fq_hlen.as<uint8_t>(), e->d_err.as<uint32_t>(), tiles,
+                       coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr);
   uint64_t total = 0;
-  if ((rc = scan_presummed<uint64_t>(e, e->fq_len, n_reads, 1u, e->fq_off, &total))) return rc;
+  if (coarse) { if ((rc = scan_u64(e, e->w_bytes, n_w, e->fq_off64, &total))) return rc; }
+  else if ((rc = scan_presummed<uint64_t>(e, e->fq_len, n_reads, 1u, e->fq_off, &total))) return rc;
+  e->fq_coarse = coarse;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw2[2] = {0, 0};  // error bits, longest header
   HIP_TRY(e, hipMemcpyAsync(errw2, e->d_err.p, 8, hipMemcpyDeviceToHost, e->stream));
@@ -2045,7 +2059,7 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
   if (!dst) return e->fail(SIMMR_EINVAL, "dst is NULL");
   HIP_TRY(e, hipSetDevice(e->device));
   const bool paired = e->plan_paired;
-  const bool direct_kernel = e->prof.kind != SIMMR_K_CUSTOM && e->prof.kind != SIMMR_K_PERFECT_SHORT && e->prof.rng_mode == SIMMR_RNG_PHILOX;
+  const bool direct_kernel = fq_direct_kernel(e);
   const FqTables tb = fq_tables(e, e->fq_slots);
   if (!direct_kernel) {
     // No emit kernel of this profile writes into text: the columns are built in buffers of the engine and framed from
@@ -2095,6 +2109,11 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
                                : (exc ? k_emit_philox<true, false, false, true, true> : k_emit_philox<false, false, false, true, true>))
                      : (cached ? (exc ? k_emit_philox<true, false, true, true> : k_emit_philox<false, false, true, true>)
                                : (exc ? k_emit_philox<true, false, false, true> : k_emit_philox<false, false, false, true>));
+    if (e->fq_coarse)  // the kernel places its own records (fq_off64)
+      kern = escq ? (cached ? (exc ? k_emit_philox<true, false, true, true, true, false, true> : k_emit_philox<false, false, true, true, true, false, true>)
+                            : (exc ? k_emit_philox<true, false, false, true, true, false, true> : k_emit_philox<false, false, false, true, true, false, true>))
+                  : (cached ? (exc ? k_emit_philox<true, false, true, true, false, false, true> : k_emit_philox<false, false, true, true, false, false, true>)
+                            : (exc ? k_emit_philox<true, false, false, true, false, false, true> : k_emit_philox<false, false, false, true, false, false, true>));
     // windows per run: the power of two that covers the longest run ('\n' + header + '\n'), at most 32 (512 bytes)
     uint32_t wshift = 0;
     while ((16u << wshift) < e->fq_maxhdr + 2u) wshift++;
@@ -2105,7 +2124,7 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
                        e->u_seed.as<uint64_t>(), dst, dst, 33u, e->plan_first, e->fq_read_id_base, OutCols{}, counters,
                        e->fq_off.as<uint64_t>(), e->fq_hlen.as<uint8_t>(),
                        own_headers ? e->fq_tpl_dev.as<FqTemplate>() : (const FqTemplate*)nullptr, tb, e->fq_lit_bytes, e->fq_hpitch, wshift,
-                       (const uint64_t*)nullptr);
+                       e->fq_coarse ? (const uint64_t*)e->fq_off64.as<uint64_t>() : (const uint64_t*)nullptr);
   }
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
   if (e->fastq_headers_form != 0) {  // SIMMR_FASTQ_HEADERS=1: headers by a kernel of their own (measurement)

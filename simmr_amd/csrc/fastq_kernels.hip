@@ -43,7 +43,8 @@ k_fastq_size(const FqTemplate* __restrict__ tp, FqTables tb, FqReads rd, uint64_
 // The same from the plan (simmr_fastq_plan_direct); hlen[r] = the header's bytes, for the emit kernel that writes into the text.
 extern "C" __global__ void __launch_bounds__(256)
 k_fastq_size_plan(const FqTemplate* __restrict__ tp, FqTables tb, FqPlan pn, uint64_t n_reads, uint64_t* __restrict__ rec_len,
-                  uint8_t* __restrict__ hlen, uint32_t* __restrict__ err, unsigned long long* __restrict__ tile_bytes) {
+                  uint8_t* __restrict__ hlen, uint32_t* __restrict__ err, unsigned long long* __restrict__ tile_bytes,
+                  unsigned long long* __restrict__ wave_bytes) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const bool on = r < n_reads;
   uint32_t h = 0;
@@ -56,14 +57,19 @@ k_fastq_size_plan(const FqTemplate* __restrict__ tp, FqTables tb, FqPlan pn, uin
   if ((threadIdx.x & 63u) == 0 && wmax > *(volatile uint32_t*)(err + 1)) atomicMax(err + 1, wmax);  // (rarely: see k_fastq_size)
   const uint64_t len = (on && !bad) ? (uint64_t)h + 1u + (uint64_t)f.L + 3u + (uint64_t)f.L + 1u : 0u;
   {  // the record lengths of this wave, added to the sum of their tile of the scan that follows (engine.hip: scan_presummed)
+     // — or, for the emit kernel that places its own records (wave_bytes: k_emit_philox<TEXT, COARSE>), left as the bytes
+     // of these 64 records: their scan is all that kernel asks for, and no record offset is made per read
     unsigned long long s = len;
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-    if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&tile_bytes[((uint64_t)blockIdx.x * 256u) / (SCAN_THREADS * SCAN_ITEMS)], s);
+    if ((threadIdx.x & 63u) == 0) {
+      if (wave_bytes) wave_bytes[((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6] = s;
+      else if (s) atomicAdd(&tile_bytes[((uint64_t)blockIdx.x * 256u) / (SCAN_THREADS * SCAN_ITEMS)], s);
+    }
   }
   if (!on) return;
   if (bad) atomicOr(err, SIMMR_ERRBIT_FASTQ);
   hlen[r] = bad ? 0 : (uint8_t)h;
-  rec_len[r] = len;
+  if (rec_len) rec_len[r] = len;
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -2214,6 +2214,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   // off64 != null ("coarse" plans, engine.hip): u_off does not exist; off64[w] = first output byte of pair 64 w (the scan
   // of the plan kernel's per-wave byte sums), and a block places its reads with a scan of their (padded) lengths
   constexpr bool coarse = COARSE && !TEXT;
+  // TEXT with COARSE: rec_off does not exist either; off64[w] = first byte of record 64 w, and a block places its records
+  // with a scan of their lengths (header + 1 + L + 3 + L + 1, fastq.rs:58-66) before anything else
+  constexpr bool tcoarse = COARSE && TEXT;
 #define COL_STORE(p, v) do { if (SLOT) stream_store((p), (v)); else *(p) = (v); } while (0)  /* the metadata columns, as the streams */
   // TEXT: header slots of FQ_GROUP reads at a time (dynamic LDS, FQ_GROUP * fq_hpitch bytes), the template and its literals
   extern __shared__ __attribute__((aligned(16))) uint8_t fq_slots[];
@@ -2237,7 +2240,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ uint4 nmask[17];    // byte masks of the first n bytes of 16
   __shared__ uint32_t nmask2[17]; // the low 2n bits
   __shared__ uint32_t lds4[4];
-  __shared__ uint64_t lds4w[COARSE ? 4 : 1];
+  __shared__ uint64_t lds4w[COARSE ? 4 : 1];  // (TEXT too)
   const uint32_t qoff = qual_offset & 0xffu;
   // Where an escaped base (one item in 9 000) is noticed.  When every encoded quality the level-1 table can answer is
   // below 128 (the usual case: Phred + 33), an escape cell answers the byte 0xff and one test of the item's four quality
@@ -2292,11 +2295,25 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     const uint32_t nu = (n_units - u0) < PHILOX_UNITS ? (uint32_t)(n_units - u0) : PHILOX_UNITS;
     const uint32_t nr = nu * rpu;
     // the block's first output byte (same for every lane: a scalar load)
-    const uint64_t out0 = TEXT ? rec_off[paired ? 2 * u0 : u0] : (coarse ? off64[u0 >> 6] : u_off[u0]);
+    const uint64_t out0 = TEXT ? (tcoarse ? off64[(paired ? 2 * u0 : u0) >> 6] : rec_off[paired ? 2 * u0 : u0]) : (coarse ? off64[u0 >> 6] : u_off[u0]);
     uint8_t* const seq_blk = seq + out0;
     uint8_t* const qual_blk = (TEXT ? seq : qual) + out0;
     lds_barrier();  // the previous block's items are done with the records
     uint32_t g = 0;
+    uint32_t n_items = 0, ex = 0;
+    uint64_t rec_place = 0;  // tcoarse: this thread's record, relative to the block's first
+    if (tcoarse) {
+      uint32_t L0 = 0, h0 = 0;
+      const bool on = threadIdx.x < nr;
+      if (on) {
+        const uint64_t u = u0 + (paired ? (threadIdx.x >> 1) : threadIdx.x);
+        L0 = pl.len[u];
+        h0 = hlen[paired ? 2 * u + (threadIdx.x & 1u) : u];
+      }
+      uint64_t tot2;
+      const uint64_t ex2 = wg_exclusive_scan_2x32((uint64_t)((L0 + 15u) >> 4) | ((uint64_t)(on ? h0 + 2u * L0 + 5u : 0u) << 32), lds4w, &tot2, threadIdx.x);
+      ex = (uint32_t)ex2; n_items = (uint32_t)tot2; rec_place = ex2 >> 32;
+    }
     uint32_t my_Lp = 0, my_pad = 0;  // this thread's read: its place in the streams, and (SLOT, reverse mate) the padding in front
     uint64_t my_rd = 0, my_dst = 0;
     FqFields hf{};           // TEXT: what this thread's read shows in its header
@@ -2311,7 +2328,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint32_t genome = (!CACHED && u_genome) ? u_genome[u] : genome_const;
       const uint64_t rd = paired ? 2 * u + rev : u;
       const uint32_t Lp = SLOT ? ((L + 15u) & ~15u) : L;  // the read's place in the streams
-      const uint64_t dst = TEXT ? rec_off[rd] + hlen[rd] + 1u : (coarse ? out0 : u_off[u] + (rev ? Lp : 0u));  // (coarse: after the scan below)
+      const uint64_t my_rec = TEXT ? (tcoarse ? out0 + rec_place : rec_off[rd]) : 0u;
+      const uint64_t dst = TEXT ? my_rec + hlen[rd] + 1u : (coarse ? out0 : u_off[u] + (rev ? Lp : 0u));  // (coarse: after the scan below)
       my_Lp = Lp; my_pad = (SLOT && rev) ? Lp - L : 0u; my_rd = rd; my_dst = dst;
       const uint64_t pos = rev ? pl.b[u] : pl.a[u];  // first source base of this read on the contig
       const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
@@ -2351,7 +2369,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           hf.read_id = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
           hf.flags = (paired && !rev) ? 0u : fl;
           hf.L = L;
-          h_rec = rec_off[rd]; h_rd = rd;
+          h_rec = my_rec; h_rd = rd;
         }
         if (!TEXT) {
           if (paired) {
@@ -2392,7 +2410,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           fq_run_at[threadIdx.x & (FQ_GROUP - 1u)] = h_rec - lead;
           fq_run_len[threadIdx.x & (FQ_GROUP - 1u)] = at;
           if (hf.L == 0) { uint8_t* p = seq + h_rec + (at - lead); p[0] = '\n'; p[1] = '+'; p[2] = '\n'; }  // (no item writes it)
-          if (h_rd + 1 == n_reads) seq[rec_off[n_reads] - 1] = '\n';
+          if (h_rd + 1 == n_reads) seq[(tcoarse ? off64[(n_reads + 63u) >> 6] : rec_off[n_reads]) - 1] = '\n';
         }
         lds_barrier();
         const uint32_t n_runs = nr - FQ_GROUP * half < FQ_GROUP ? nr - FQ_GROUP * half : FQ_GROUP;
@@ -2412,8 +2430,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         }
       }
     }
-    uint32_t n_items, ex;
-    if (coarse) {  // the reads' places too: the scan of their (padded) lengths rides in the upper half
+    if (tcoarse) {
+      // (scanned above)
+    } else if (coarse) {  // the reads' places too: the scan of their (padded) lengths rides in the upper half
       uint64_t tot2;
       const uint64_t ex2 = wg_exclusive_scan_2x32((uint64_t)g | ((uint64_t)my_Lp << 32), lds4w, &tot2, threadIdx.x);
       ex = (uint32_t)ex2; n_items = (uint32_t)tot2;
