@@ -2237,7 +2237,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ uint32_t r_gs[PHILOX_READS + 1];  // first item of each read, ~0 past the last read
   __shared__ uint8_t owner[PHILOX_MAP_ITEMS];   // item -> read, when the block has few enough items
   __shared__ uint64_t cbase[CACHED ? PHILOX_CBASE : 1];
-  __shared__ uint4 nmask[17];    // byte masks of the first n bytes of 16
+  // byte masks (0xff) of the first n bytes of 16; SLOT: a second row at +32 with the LAST n bytes (a reverse mate's live bytes)
+  __shared__ uint4 nmask[SLOT ? 64 : 17];
   __shared__ uint32_t nmask2[17]; // the low 2n bits
   __shared__ uint32_t lds4[4];
   __shared__ uint64_t lds4w[COARSE ? 4 : 1];  // (TEXT too)
@@ -2262,9 +2263,13 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     }
     if (t <= 16u) {
       auto bytes = [](int k) { return k >= 4 ? 0xffffffffu : (k <= 0 ? 0u : ((1u << (8 * k)) - 1u)); };
-      // (bytes of 0x01, not 0xff: v_dot4_u32_u8 with them sums the live quality bytes in one instruction per word)
-      nmask[t] = make_uint4(bytes((int)t) & 0x01010101u, bytes((int)t - 4) & 0x01010101u, bytes((int)t - 8) & 0x01010101u,
-                            bytes((int)t - 12) & 0x01010101u);
+      // (v_dot4_u32_u8 against them sums the live quality bytes 255-fold in one instruction per word: qsum is divided once,
+      // at the end; and the same masks zero the padding of the slot layout with a plain `and`, no multiply)
+      nmask[t] = make_uint4(bytes((int)t), bytes((int)t - 4), bytes((int)t - 8), bytes((int)t - 12));
+      if (SLOT) {
+        const int d = 16 - (int)t;  // the low d bytes are padding
+        nmask[32u + t] = make_uint4(~bytes(d), ~bytes(d - 4), ~bytes(d - 8), ~bytes(d - 12));
+      }
       nmask2[t] = t >= 16u ? 0xffffffffu : ((1u << (2u * t)) - 1u);
     }
     const uint32_t acgt = 0x54474341u;  // "ACGT"
@@ -2559,7 +2564,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         qs = __builtin_amdgcn_udot4(qr[1], bm.y, qs, false);
         qs = __builtin_amdgcn_udot4(qr[2], bm.z, qs, false);
         qs = __builtin_amdgcn_udot4(qr[3], bm.w, qs, false);
-        qsum += qs;
+        qsum += qs;  // 255 x the sum of the live bytes (<= 16 * 255 * 255 per item)
       }
       if (!COPY_ONLY && !q_nowrap) {
         for (uint32_t j = 0; j < n; j++) n_wrap += ((qr[j >> 2] >> (8 * (j & 3u))) & 0xffu) < qoff ? 1u : 0u;
@@ -2591,14 +2596,12 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       } else {
         s0 = asc[codes & 0xffu]; s1 = asc[(codes >> 8) & 0xffu]; s2 = asc[(codes >> 16) & 0xffu]; s3 = asc[codes >> 24];
       }
-      if (SLOT && n < 16u) {
+      if (SLOT) {
         // padding bytes are 0: the qualities' and a forward read's bases' high 16 - n bytes, a reverse mate's low ones
-        const uint4 m1 = nmask[n];                      // 0x01 in the low n bytes
-        qr[0] &= m1.x * 255u; qr[1] &= m1.y * 255u; qr[2] &= m1.z * 255u; qr[3] &= m1.w * 255u;
-        const uint4 d1 = nmask[16u - n];                // 0x01 in the low 16 - n bytes
-        const uint32_t k0m = rev ? ~(d1.x * 255u) : m1.x * 255u, k1m = rev ? ~(d1.y * 255u) : m1.y * 255u;
-        const uint32_t k2m = rev ? ~(d1.z * 255u) : m1.z * 255u, k3m = rev ? ~(d1.w * 255u) : m1.w * 255u;
-        s0 &= k0m; s1 &= k1m; s2 &= k2m; s3 &= k3m;
+        // (every item, without a branch: the masks of n = 16 are all ones)
+        qr[0] &= bm.x; qr[1] &= bm.y; qr[2] &= bm.z; qr[3] &= bm.w;
+        const uint4 sm = nmask[(rev << 5) + n];
+        s0 &= sm.x; s1 &= sm.y; s2 &= sm.z; s3 &= sm.w;
       }
       // qualities are already offset-encoded, forward order
       const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
@@ -2657,7 +2660,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   }
   // sum of the raw Phred values (per lane modulo 2^64: a lane that wrote records but drew few bases goes "negative";
   // the sum over the lanes is exact)
-  qsum = qsum + 256ull * n_wrap - (uint64_t)qoff * p_bases;
+  // (the masks of the dot products are 0xff bytes: qsum is a multiple of 255, divided exactly by the inverse of 255 modulo 2^64)
+  qsum = qsum * 0xFEFEFEFEFEFEFEFFull + 256ull * n_wrap - (uint64_t)qoff * p_bases;
   uint64_t acgt = (HAS_EXC || COPY_ONLY) ? (uint64_t)n_acgt : p_bases;
   for (int d = 32; d > 0; d >>= 1) {
     n_subst += __shfl_down(n_subst, d, 64);
