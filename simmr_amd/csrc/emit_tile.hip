@@ -453,13 +453,13 @@ k_emit_philox_tile(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint3
     p_seedsubst += __shfl_down(p_seedsubst, d, 64);
   }
   if (lane == 0 && counters) {
-    atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
-    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)acgt);
-    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
-    if (p_bases) atomicAdd(&counters[SIMMR_CNT_BASES], (unsigned long long)p_bases);
-    if (p_redrawn) atomicAdd(&counters[SIMMR_CNT_REDRAWN], (unsigned long long)p_redrawn);
-    if (p_seedsubst) atomicAdd(&counters[SIMMR_CNT_SEED_SUBST], (unsigned long long)p_seedsubst);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[SIMMR_CNT_READS], (unsigned long long)n_reads);
+    shard_add(counters, SIMMR_CNT_SUBSTITUTIONS, (unsigned long long)n_subst);
+    shard_add(counters, SIMMR_CNT_ACGT_BASES, (unsigned long long)acgt);
+    shard_add(counters, SIMMR_CNT_QUAL_SUM, (unsigned long long)qsum);
+    if (p_bases) shard_add(counters, SIMMR_CNT_BASES, (unsigned long long)p_bases);
+    if (p_redrawn) shard_add(counters, SIMMR_CNT_REDRAWN, (unsigned long long)p_redrawn);
+    if (p_seedsubst) shard_add(counters, SIMMR_CNT_SEED_SUBST, (unsigned long long)p_seedsubst);
+    if (blockIdx.x == 0 && threadIdx.x == 0) shard_add(counters, SIMMR_CNT_READS, (unsigned long long)n_reads);
   }
 }
 

@@ -96,7 +96,14 @@ struct simmr_engine {
   int emit_variant = 0;  // 0 = lane-per-read kernel for short reads, 1 = wave-per-unit kernel
   // measurement knobs, read ONCE when the engine is made (a stray variable cannot change a running engine's launches)
   int philox_form = 1;          // SIMMR_PHILOX_FORM: 1 = the item kernel (default), 2 = the tile kernel where it applies (emit_tile.hip; measured slower: profiles/r3/tile_form_*)
-  uint32_t philox_wgs_per_cu = 8;  // SIMMR_PHILOX_WGS_PER_CU (item kernel), clamped to 1..64
+  uint32_t philox_wgs_per_cu = 128;  // SIMMR_PHILOX_WGS_PER_CU (item kernel), clamped to 1..4096.  More workgroups than the 4 per CU that
+                                    // are resident: 11.25 ms at 8, 10.6 at 32, 10.4 at 64-256, 11.1 at one block per workgroup
+                                    // (profiles/r3/ab_wgs_per_cu_*: the workgroups of a CU stop running their phases in step)
+  // The other grid-stride emit kernels: workgroups per CU as a multiple of what is resident.  Every one of them ran its
+  // best with far more workgroups than fit at a time (profiles/r3/ab_grid_sweep.log: k_emit_lanes 107.6 ms at 1 x, 98.5 at
+  // 4 x, 94.7 at 64 x; k_emit_perfect_pe 6.65 / 5.99 / 5.78; k_emit_custom_pe 10.99 / 10.58 / 10.44 at 16 x; the splice
+  // kernel does not care).  SIMMR_GRID_MULT overrides all of them (measurement knob, 1..512).
+  uint32_t lanes_mult = 64, perfect_mult = 64, custom_pe_mult = 16, custom_long_mult = 1, fastq_mult = 1;
   uint32_t tile_upb = 32;       // SIMMR_TILE_UPB: pairs per block of the tile kernel (1..32)
   uint32_t tile_cap = 0;        // SIMMR_TILE_CAP: bytes per LDS tile (0 = from the profile's read length)
   uint32_t tile_wgs_per_cu = 0; // SIMMR_TILE_WGS_PER_CU: 0 = what fits
@@ -839,14 +846,17 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
   e->n_cu = prop.multiProcessorCount;
   if (const char* v = getenv("SIMMR_EMIT_VARIANT")) e->emit_variant = atoi(v);
   if (const char* v = getenv("SIMMR_PHILOX_FORM")) e->philox_form = atoi(v);
-  if (const char* v = getenv("SIMMR_PHILOX_WGS_PER_CU")) e->philox_wgs_per_cu = (uint32_t)std::min<unsigned long long>(64, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
+  if (const char* v = getenv("SIMMR_GRID_MULT"))
+    e->lanes_mult = e->perfect_mult = e->custom_pe_mult = e->custom_long_mult = e->fastq_mult =
+        (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
+  if (const char* v = getenv("SIMMR_PHILOX_WGS_PER_CU")) e->philox_wgs_per_cu = (uint32_t)std::min<unsigned long long>(4096, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_TILE_UPB")) e->tile_upb = (uint32_t)std::min<unsigned long long>(32, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_TILE_CAP")) e->tile_cap = (uint32_t)std::min<unsigned long long>(16384, strtoull(v, nullptr, 10)) & ~15u;
   if (const char* v = getenv("SIMMR_TILE_WGS_PER_CU")) e->tile_wgs_per_cu = (uint32_t)std::min<unsigned long long>(16, strtoull(v, nullptr, 10));
   if (const char* v = getenv("SIMMR_SPLICE_VARIANT")) e->splice_variant = atoi(v);
   if (const char* v = getenv("SIMMR_FASTQ_HEADERS")) e->fastq_headers_form = atoi(v);
   if (const char* v = getenv("SIMMR_FINE_OFFSETS")) e->fine_offsets = atoi(v) != 0;
-  bool ok = e->d_tables.ensure(sizeof(Tables)) && e->d_counters.ensure(8 * SIMMR_N_COUNTERS) &&
+  bool ok = e->d_tables.ensure(sizeof(Tables)) && e->d_counters.ensure(8 * SIMMR_N_COUNTERS * (1 + SIMMR_CNT_SHARDS)) &&
             e->d_err.ensure(64) && e->d_scalars.ensure(256);
   ok = ok && hipEventCreate(&e->ev_a) == hipSuccess && hipEventCreate(&e->ev_b) == hipSuccess &&
        hipEventCreate(&e->ev_c) == hipSuccess && hipEventCreate(&e->ev_d) == hipSuccess;
@@ -854,7 +864,7 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
     Tables* T = new Tables();
     build_tables(T);
     ok = hipMemcpy(e->d_tables.p, T, sizeof(Tables), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemset(e->d_counters.p, 0, 8 * SIMMR_N_COUNTERS) == hipSuccess &&
+         hipMemset(e->d_counters.p, 0, 8 * SIMMR_N_COUNTERS * (1 + SIMMR_CNT_SHARDS)) == hipSuccess &&
          hipMemset(e->d_err.p, 0, 64) == hipSuccess;
     delete T;
   }
@@ -1460,7 +1470,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
   if (n_units > 0) {
     if (e->prof.kind == SIMMR_K_PERFECT_SHORT) {
       const uint64_t groups = (n_reads + PERFECT_GROUP - 1) / PERFECT_GROUP;
-      const uint32_t grid = (uint32_t)std::min<uint64_t>(groups, (uint64_t)e->n_cu * 8);
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(groups, (uint64_t)e->n_cu * 8 * e->perfect_mult);
       auto kern = e->plan_multi ? k_emit_perfect_pe<true> : k_emit_perfect_pe<false>;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, e->stream, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, u_genome, e->plan_any_exc ? 1u : 0u, n_units, e->prof.read_length, pl,
@@ -1524,7 +1534,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       bool exc = false;
       for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
       const uint64_t blocks = (n_reads + 255) / 256;
-      const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8 * e->custom_long_mult);
       const uint32_t* order = e->plan_sorted ? e->u_order.as<uint32_t>() : (const uint32_t*)nullptr;
       hipLaunchKernelGGL(k_custom_long_qual, dim3(grid), dim3(256), 0, e->stream, e->prof, n_units, order, pl,
                          e->u_off.as<uint64_t>(), e->u_seed.as<uint64_t>(), out->qual, out->qual_offset, counters,
@@ -1540,7 +1550,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
           HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           attr_set[exc ? 1 : 0] = true;
         }
-        const uint32_t fgrid = (uint32_t)std::min<uint64_t>((n_reads + SPLICE_FAST_LANES - 1) / SPLICE_FAST_LANES, (uint64_t)e->n_cu * 8);
+        const uint32_t fgrid = (uint32_t)std::min<uint64_t>((n_reads + SPLICE_FAST_LANES - 1) / SPLICE_FAST_LANES, (uint64_t)e->n_cu * 8 * e->custom_long_mult);
         hipLaunchKernelGGL(kern, dim3(fgrid), dim3(SPLICE_FAST_LANES), lds, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
                            n_units, order, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
                            e->u_seed.as<uint64_t>(), out->seq, counters, e->d_err.as<uint32_t>());
@@ -1553,14 +1563,14 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
     } else if (e->prof.kind == SIMMR_K_CUSTOM) {
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
       const uint64_t blocks = (n_units + 255) / 256;  // one lane per pair
-      const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8);
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * 8 * e->custom_pe_mult);
       // qualities: one lane per pair (k_emit_custom_pe); bases: the item kernel without draws (coalesced stores)
       hipLaunchKernelGGL(k_emit_custom_pe, dim3(grid), dim3(256), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
                          e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset, counters,
                          e->d_err.as<uint32_t>());
       const uint64_t cblocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
-      const uint32_t cgrid = (uint32_t)std::min<uint64_t>(cblocks, (uint64_t)e->n_cu * 8);
+      const uint32_t cgrid = (uint32_t)std::min<uint64_t>(cblocks, (uint64_t)e->n_cu * e->philox_wgs_per_cu);
       auto copy = e->plan_any_exc ? k_emit_philox<true, true, false> : k_emit_philox<false, true, false>;
       hipLaunchKernelGGL(copy, dim3(cgrid), dim3(256), 0, e->stream, e->prof, 1u, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
@@ -1584,7 +1594,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, LANES_WG, 0) != hipSuccess || per_cu < 1) per_cu = 1;
       const uint64_t n_tasks = paired ? 2 * n_units : n_units;
       const uint64_t wgs = (n_tasks + LANES_WG - 1) / LANES_WG;
-      const uint32_t grid = (uint32_t)std::min<uint64_t>(wgs, (uint64_t)e->n_cu * (uint64_t)per_cu);
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(wgs, (uint64_t)e->n_cu * (uint64_t)per_cu * e->lanes_mult);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(LANES_WG), 0, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, e->plan_sorted ? e->u_order.as<uint32_t>() : (const uint32_t*)nullptr,
                          pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(),
@@ -1961,7 +1971,7 @@ int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst
   const FqReads rd{reads->seq, reads->qual, reads->seq_off, reads->start, reads->end, reads->contig, reads->genome,
                    reads->read_id, reads->flags, reads->slot_bytes == SIMMR_SLOT16 ? 1u : 0u};
   const uint64_t n_batches = (e->fq_reads + FQ_BATCH - 1) / FQ_BATCH;
-  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 8);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 8 * e->fastq_mult);
   const uint32_t hdr_lds = 4 * FQ_BATCH * e->fq_hpitch;  // up to 68 KB with 255-byte headers: above the default limit
   if (hdr_lds > 48 * 1024)
     HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fastq_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_lds));
@@ -2078,7 +2088,7 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
     if (rc) return rc;
     const FqReads rd{cols.seq, cols.qual, cols.seq_off, cols.start, cols.end, cols.contig, cols.genome, cols.read_id, cols.flags, 0u};
     const uint64_t n_batches = (n_reads + FQ_BATCH - 1) / FQ_BATCH;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 8);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * 8 * e->fastq_mult);
     const uint32_t hdr_lds = 4 * FQ_BATCH * e->fq_hpitch;
     if (hdr_lds > 48 * 1024)
       HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fastq_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_lds));
@@ -2149,6 +2159,8 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
 // ---- counters / timing ---------------------------------------------------------------
 int simmr_counters(simmr_engine* e, uint64_t* dst_device, uint64_t* dst_host) {
   if (!e) return SIMMR_EINVAL;
+  // (the counter-mode emit kernel's workgroups add to SIMMR_CNT_SHARDS partial rows behind the counters: fold them in)
+  hipLaunchKernelGGL(k_counters_fold, dim3(1), dim3(64), 0, e->stream, e->d_counters.as<unsigned long long>());
   if (dst_device)
     HIP_TRY(e, hipMemcpyAsync(dst_device, e->d_counters.p, 8 * SIMMR_N_COUNTERS, hipMemcpyDeviceToDevice, e->stream));
   if (dst_host) {
@@ -2160,7 +2172,7 @@ int simmr_counters(simmr_engine* e, uint64_t* dst_device, uint64_t* dst_host) {
 
 int simmr_counters_reset(simmr_engine* e) {
   if (!e) return SIMMR_EINVAL;
-  HIP_TRY(e, hipMemsetAsync(e->d_counters.p, 0, 8 * SIMMR_N_COUNTERS, e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_counters.p, 0, 8 * SIMMR_N_COUNTERS * (1 + SIMMR_CNT_SHARDS), e->stream));
   return SIMMR_OK;
 }
 

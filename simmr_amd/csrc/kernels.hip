@@ -1194,10 +1194,10 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, const 
   // perfect-short has no per-base draws: every counter follows from the plan
   if (blockIdx.x == 0 && threadIdx.x == 0 && counters) {
     const uint64_t bases = n_reads * L;
-    atomicAdd(&counters[SIMMR_CNT_READS], (unsigned long long)n_reads);
-    atomicAdd(&counters[SIMMR_CNT_BASES], (unsigned long long)bases);
-    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)(bases * 60u));  // perfect_short.rs:42-44
-    if (!G.has_exc) atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)bases);
+    shard_add(counters, SIMMR_CNT_READS, (unsigned long long)n_reads);
+    shard_add(counters, SIMMR_CNT_BASES, (unsigned long long)bases);
+    shard_add(counters, SIMMR_CNT_QUAL_SUM, (unsigned long long)(bases * 60u));  // perfect_short.rs:42-44
+    if (!G.has_exc) shard_add(counters, SIMMR_CNT_ACGT_BASES, (unsigned long long)bases);
   }
 }
 
@@ -1518,9 +1518,9 @@ k_emit_stream(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     qsum += __shfl_down(qsum, d, 64);
   }
   if (lane == 0 && counters) {
-    atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
-    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
-    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
+    shard_add(counters, SIMMR_CNT_SUBSTITUTIONS, (unsigned long long)n_subst);
+    shard_add(counters, SIMMR_CNT_ACGT_BASES, (unsigned long long)n_acgt);
+    shard_add(counters, SIMMR_CNT_QUAL_SUM, (unsigned long long)qsum);
   }
 }
 
@@ -1975,9 +1975,9 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
     qsum_tot += __shfl_down(qsum_tot, d, 64);
   }
   if ((threadIdx.x & 63u) == 0 && counters) {
-    atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)subst_tot);
-    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)acgt_tot);
-    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum_tot);
+    shard_add(counters, SIMMR_CNT_SUBSTITUTIONS, (unsigned long long)subst_tot);
+    shard_add(counters, SIMMR_CNT_ACGT_BASES, (unsigned long long)acgt_tot);
+    shard_add(counters, SIMMR_CNT_QUAL_SUM, (unsigned long long)qsum_tot);
   }
 }
 
@@ -2073,6 +2073,31 @@ SIMMR_DEV void store16(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi) {
   if (NT) stream_store(reinterpret_cast<v4u32_unaligned*>(d), (v4u32_unaligned)v);
   else *reinterpret_cast<v4u32_unaligned*>(d) = v;
 }
+// Measurement builds (-DSIMMR_SLOT_STORE_POLICY=n): the slot layout's 16-byte stores with other cache-policy bits than
+// the `nt` of __builtin_nontemporal_store (MI355X_MICROARCH.md: plain / sc0 / nt keep the line in the XCD's L2 behind the
+// write, sc1 / sc0 sc1 drop it).  `base` is the block's (wave-uniform) first byte, `off` the lane's offset from it.
+#if defined(SIMMR_SLOT_STORE_POLICY)
+#if SIMMR_SLOT_STORE_POLICY == 1
+#define SLOT_STORE_BITS "sc1"
+#elif SIMMR_SLOT_STORE_POLICY == 2
+#define SLOT_STORE_BITS "sc0 sc1"
+#elif SIMMR_SLOT_STORE_POLICY == 3
+#define SLOT_STORE_BITS "sc1 nt"
+#elif SIMMR_SLOT_STORE_POLICY == 4
+#define SLOT_STORE_BITS "sc0 sc1 nt"
+#elif SIMMR_SLOT_STORE_POLICY == 5
+#define SLOT_STORE_BITS "sc0 nt"
+#else
+#define SLOT_STORE_BITS "nt"
+#endif
+SIMMR_DEV void slot_store16(uint8_t* __restrict__ base, uint32_t off, uint64_t lo, uint64_t hi) {
+  v4u32 v;
+  v.x = (uint32_t)lo; v.y = (uint32_t)(lo >> 32); v.z = (uint32_t)hi; v.w = (uint32_t)(hi >> 32);
+  asm volatile("global_store_dwordx4 %0, %1, %2 " SLOT_STORE_BITS :: "v"(off), "v"(v), "s"(base));
+}
+#else
+SIMMR_DEV void slot_store16(uint8_t* __restrict__ base, uint32_t off, uint64_t lo, uint64_t hi) { store16<true>(base + off, lo, hi); }
+#endif
 // store the low n (< 16) bytes of the 128-bit value (lo, hi)
 SIMMR_DEV void store_tail(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi, uint32_t n) {
   uint64_t v = lo;
@@ -2200,8 +2225,13 @@ SIMMR_DEV void philox_repair(const uint32_t k0, const uint32_t k1, const uint32_
 // bytes on a 16-byte boundary (u_off is the scan of the padded lengths), qualities and forward bases left-aligned, the
 // bases of a reverse-complemented mate right-aligned — so EVERY item, the partial group at a read's end included, is one
 // whole aligned 16-byte store per stream (padding written as 0) and the byte ladder of store_tail2 is gone.
+#if defined(PHILOX_WAVES_PER_SIMD)  /* measurement builds: the register budget of that many waves per SIMD (5: 96 VGPRs, four reloads per block; 12.7 vs 12.1 ms, profiles/r3/ab_slot16_five_waves_per_simd.log) */
+#define PHILOX_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PHILOX_WAVES_PER_SIMD, PHILOX_WAVES_PER_SIMD)))
+#else
+#define PHILOX_OCCUPANCY
+#endif
 template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false, bool ESCQ = false, bool SLOT = false, bool COARSE = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) PHILOX_OCCUPANCY
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
               uint64_t n_units, PlanArrays pl, const uint64_t* __restrict__ u_off,
               const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
@@ -2217,6 +2247,11 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   // TEXT with COARSE: rec_off does not exist either; off64[w] = first byte of record 64 w, and a block places its records
   // with a scan of their lengths (header + 1 + L + 3 + L + 1, fastq.rs:58-66) before anything else
   constexpr bool tcoarse = COARSE && TEXT;
+#if defined(SIMMR_NT_PLAN_LOADS)  /* measurement: the plan rows (read once) as nontemporal loads */
+#define PL(x) __builtin_nontemporal_load(&(x))
+#else
+#define PL(x) (x)
+#endif
 #define COL_STORE(p, v) do { if (SLOT) stream_store((p), (v)); else *(p) = (v); } while (0)  /* the metadata columns, as the streams */
   // TEXT: header slots of FQ_GROUP reads at a time (dynamic LDS, FQ_GROUP * fq_hpitch bytes), the template and its literals
   extern __shared__ __attribute__((aligned(16))) uint8_t fq_slots[];
@@ -2312,7 +2347,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const bool on = threadIdx.x < nr;
       if (on) {
         const uint64_t u = u0 + (paired ? (threadIdx.x >> 1) : threadIdx.x);
-        L0 = pl.len[u];
+        L0 = PL(pl.len[u]);
         h0 = hlen[paired ? 2 * u + (threadIdx.x & 1u) : u];
       }
       uint64_t tot2;
@@ -2327,17 +2362,17 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint32_t t = threadIdx.x;
       const uint64_t u = u0 + (paired ? (t >> 1) : t);
       const uint32_t rev = paired ? (t & 1u) : 0u;
-      const uint32_t L = pl.len[u];
+      const uint32_t L = PL(pl.len[u]);
       g = (L + 15u) >> 4;
-      const uint32_t contig = u_contig[u];
+      const uint32_t contig = PL(u_contig[u]);
       const uint32_t genome = (!CACHED && u_genome) ? u_genome[u] : genome_const;
       const uint64_t rd = paired ? 2 * u + rev : u;
       const uint32_t Lp = SLOT ? ((L + 15u) & ~15u) : L;  // the read's place in the streams
       const uint64_t my_rec = TEXT ? (tcoarse ? out0 + rec_place : rec_off[rd]) : 0u;
       const uint64_t dst = TEXT ? my_rec + hlen[rd] + 1u : (coarse ? out0 : u_off[u] + (rev ? Lp : 0u));  // (coarse: after the scan below)
       my_Lp = Lp; my_pad = (SLOT && rev) ? Lp - L : 0u; my_rd = rd; my_dst = dst;
-      const uint64_t pos = rev ? pl.b[u] : pl.a[u];  // first source base of this read on the contig
-      const uint64_t key = rev ? pl.qs2[u] : u_seed[u];
+      const uint64_t pos = rev ? PL(pl.b[u]) : PL(pl.a[u]);  // first source base of this read on the contig
+      const uint64_t key = rev ? PL(pl.qs2[u]) : PL(u_seed[u]);
       uint64_t cb;
       const uint32_t* packed;
       const uint32_t* mk = nullptr;
@@ -2366,7 +2401,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       if (!COPY_ONLY) {
 #endif
         // metadata columns of this read (the other emit kernels leave them to k_write_meta)
-        const uint32_t fl = pl.flags[u];
+        const uint32_t fl = PL(pl.flags[u]);
         if (TEXT) {  // the same values, for the header (fastq.rs:34-56)
           hf.start = paired ? (rev ? pos + L : pos) : pos;   // simulate.rs:289,295 / :515
           hf.end = paired ? (rev ? pos : pos + L) : pl.b[u];  // simulate.rs:290,296 / :516
@@ -2648,8 +2683,16 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #else
       if (SLOT || n == 16u) {
 #endif
-        if (!COPY_ONLY) store16<SLOT>(qd, q_lo, q_hi);  // (whole aligned lines per wave in the slot layout: nontemporal)
-        store16<SLOT>(sd, s_lo, s_hi);
+#if !defined(SIMMR_ABLATE_LINES) && !defined(SIMMR_ABLATE_HOTSTORE) && !defined(SIMMR_ABLATE_ALIGN16)
+        if (SLOT) {  // (whole aligned lines per wave in the slot layout: nontemporal)
+          if (!COPY_ONLY) slot_store16(qual_blk, o_q, q_lo, q_hi);
+          slot_store16(seq_blk, o_s, s_lo, s_hi);
+        } else
+#endif
+        {
+          if (!COPY_ONLY) store16<SLOT>(qd, q_lo, q_hi);
+          store16<SLOT>(sd, s_lo, s_hi);
+        }
       } else if (!COPY_ONLY) {
         store_tail2(qd, q_lo, q_hi, sd, s_lo, s_hi, n);
       } else {
@@ -2671,18 +2714,40 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     p_redrawn += __shfl_down(p_redrawn, d, 64);
     p_seedsubst += __shfl_down(p_seedsubst, d, 64);
   }
-  if (COPY_ONLY) {
-    if ((threadIdx.x & 63u) == 0 && counters) atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)acgt);
-    return;
+  // One add per counter and WORKGROUP, into one of SIMMR_CNT_SHARDS rows behind the run's counters (k_counters_fold sums
+  // the rows when the counters are read): every wave adding to the same eight addresses served the adds one at a time —
+  // with 64 workgroups per CU (16 384 workgroups: what the kernel runs best with) that was 460 000 adds to seven addresses.
+  __shared__ unsigned long long wsum[4][SIMMR_N_COUNTERS];
+  if ((threadIdx.x & 63u) == 0) {
+    unsigned long long* w = wsum[threadIdx.x >> 6];
+    w[SIMMR_CNT_READS] = (!COPY_ONLY && blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)n_reads : 0ull;
+    w[SIMMR_CNT_BASES] = COPY_ONLY ? 0ull : (unsigned long long)p_bases;
+    w[SIMMR_CNT_ACGT_BASES] = (unsigned long long)acgt;
+    w[SIMMR_CNT_SUBSTITUTIONS] = COPY_ONLY ? 0ull : (unsigned long long)n_subst;
+    w[SIMMR_CNT_OUTER_REJECTS] = 0ull;
+    w[SIMMR_CNT_REDRAWN] = COPY_ONLY ? 0ull : (unsigned long long)p_redrawn;
+    w[SIMMR_CNT_SEED_SUBST] = COPY_ONLY ? 0ull : (unsigned long long)p_seedsubst;
+    w[SIMMR_CNT_QUAL_SUM] = COPY_ONLY ? 0ull : (unsigned long long)qsum;
   }
-  if ((threadIdx.x & 63u) == 0 && counters) {
-    atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
-    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)acgt);
-    atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
-    if (p_bases) atomicAdd(&counters[SIMMR_CNT_BASES], (unsigned long long)p_bases);
-    if (p_redrawn) atomicAdd(&counters[SIMMR_CNT_REDRAWN], (unsigned long long)p_redrawn);
-    if (p_seedsubst) atomicAdd(&counters[SIMMR_CNT_SEED_SUBST], (unsigned long long)p_seedsubst);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[SIMMR_CNT_READS], (unsigned long long)n_reads);
+  __syncthreads();
+  if (threadIdx.x < SIMMR_N_COUNTERS && counters) {
+    const unsigned long long v = wsum[0][threadIdx.x] + wsum[1][threadIdx.x] + wsum[2][threadIdx.x] + wsum[3][threadIdx.x];
+    if (v) atomicAdd(&counters[(1u + (blockIdx.x & (SIMMR_CNT_SHARDS - 1u))) * SIMMR_N_COUNTERS + threadIdx.x], v);
+  }
+}
+
+// Rows 1 .. SIMMR_CNT_SHARDS of the counter block (what k_emit_philox's workgroups add to) summed into row 0 — the run's
+// counters, which every other kernel adds to directly — and cleared.  One wave; launched where the counters are read.
+extern "C" __global__ void __launch_bounds__(64)
+k_counters_fold(unsigned long long* __restrict__ counters) {
+  static_assert(SIMMR_CNT_SHARDS == 64, "one lane per shard row");
+  unsigned long long* row = counters + (1u + threadIdx.x) * SIMMR_N_COUNTERS;
+#pragma unroll
+  for (uint32_t k = 0; k < SIMMR_N_COUNTERS; k++) {
+    unsigned long long v = row[k];
+    row[k] = 0ull;
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    if (threadIdx.x == 0 && v) counters[k] += v;
   }
 }
 
@@ -2848,7 +2913,7 @@ k_emit_custom_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_
   }
   if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
   for (int d = 32; d > 0; d >>= 1) qsum += __shfl_down(qsum, d, 64);
-  if ((threadIdx.x & 63u) == 0 && counters) atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
+  if ((threadIdx.x & 63u) == 0 && counters) shard_add(counters, SIMMR_CNT_QUAL_SUM, (unsigned long long)qsum);
 }
 
 // ===========================================================================
@@ -3027,7 +3092,7 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
   }
   if (bad) atomicOr(err, SIMMR_ERRBIT_PDF);
   for (int d = 32; d > 0; d >>= 1) qsum += __shfl_down(qsum, d, 64);
-  if ((threadIdx.x & 63u) == 0 && counters) atomicAdd(&counters[SIMMR_CNT_QUAL_SUM], (unsigned long long)qsum);
+  if ((threadIdx.x & 63u) == 0 && counters) shard_add(counters, SIMMR_CNT_QUAL_SUM, (unsigned long long)qsum);
 }
 
 // bases of the long reads (simulate_errors, custom_short.rs:455-516): one lane per read.
@@ -3328,8 +3393,8 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
     n_subst += __shfl_down(n_subst, d, 64);
   }
   if ((threadIdx.x & 63u) == 0 && counters) {
-    atomicAdd(&counters[SIMMR_CNT_ACGT_BASES], (unsigned long long)n_acgt);
-    atomicAdd(&counters[SIMMR_CNT_SUBSTITUTIONS], (unsigned long long)n_subst);
+    shard_add(counters, SIMMR_CNT_ACGT_BASES, (unsigned long long)n_acgt);
+    shard_add(counters, SIMMR_CNT_SUBSTITUTIONS, (unsigned long long)n_subst);
   }
 }
 
