@@ -2,7 +2,9 @@
 """profiles/r3/pmc_traffic.json from the PMC summaries of tools/profile_round.sh, stamped with the hash of the kernel
 sources it was collected from (bench.py reports its numbers only while that hash still matches).
 
-usage: tools/make_pmc_traffic.py <dir with pmc_default.txt [pmc_perfect.txt pmc_custom_long.txt]> [--mix plain,vop3_sdwa,mad_u64]"""
+usage: tools/make_pmc_traffic.py <dir with pmc_default.txt [pmc_compact.txt pmc_perfect.txt pmc_custom_long.txt]>
+       [--mix plain,vop3_sdwa,mad_u64] [--mix-slot plain,vop3_sdwa,mad_u64]
+(pmc_default.txt = the default command, i.e. the 16-byte read slots; pmc_compact.txt = the same with --layout compact)"""
 import json
 import sys
 from pathlib import Path
@@ -40,19 +42,21 @@ def record(d, workload, note):
 def main():
     src = Path(sys.argv[1])
     out = {"source_sha256": bench.kernel_source_hash(), "sources": list(bench.KERNEL_SOURCES)}
-    mix = None
-    if "--mix" in sys.argv:
-        a, b, c = (float(x) for x in sys.argv[sys.argv.index("--mix") + 1].split(","))
-        mix = {"plain": a, "vop3_sdwa": b, "mad_u64": c}
-    for name, key, workload in (("pmc_default.txt", "k_emit_philox", "bench.py default (minimal-short 150 bp PE, 100 Mbp, 100 M reads, counter mode)"),
+    mixes = {}
+    for flag, key in (("--mix", "k_emit_philox"), ("--mix-slot", "k_emit_philox_slot16")):
+        if flag in sys.argv:
+            a, b, c = (float(x) for x in sys.argv[sys.argv.index(flag) + 1].split(","))
+            mixes[key] = {"plain": a, "vop3_sdwa": b, "mad_u64": c}
+    for name, key, workload in (("pmc_default.txt", "k_emit_philox_slot16", "bench.py default (minimal-short 150 bp PE, 100 Mbp, 100 M reads, counter mode, 16-byte read slots)"),
+                                ("pmc_compact.txt", "k_emit_philox", "bench.py --layout compact (the same run with byte streams without gaps)"),
                                 ("pmc_perfect.txt", "k_emit_perfect_pe", "bench.py --profile perfect-short"),
                                 ("pmc_custom_long.txt", "k_custom_long_splice", "bench.py --profile custom-long --reads 1000000")):
         f = src / name
         if f.exists():
             out[key] = record(read(f), workload, "separate --pmc passes of the bench command with --steps 1 --warmup 0 "
                                                  "(tools/profile_round.sh), per launch")
-            if key == "k_emit_philox" and mix:
-                out[key]["valu_class_mix"] = mix
+            if key in mixes:
+                out[key]["valu_class_mix"] = mixes[key]
     dst = ROOT / "profiles" / "r3" / "pmc_traffic.json"
     dst.parent.mkdir(parents=True, exist_ok=True)
     dst.write_text(json.dumps(out, indent=1) + "\n")

@@ -18,6 +18,7 @@ stats bench_minimal_long --profile minimal-long --reads 10000000
 stats bench_through_fastq --through-fastq --no-other-mode
 S="FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES;SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD;GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"
 tools/pmc_cmd.sh "prof_$tag/pmc_default" k_emit_philox "$S" -- python3 bench.py --no-cpu-baseline --no-other-mode --steps 1 --warmup 0 > "$out/pmc_default.txt"
+tools/pmc_cmd.sh "prof_$tag/pmc_compact" k_emit_philox "FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES;SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY" -- python3 bench.py --no-cpu-baseline --no-other-mode --layout compact --steps 1 --warmup 0 > "$out/pmc_compact.txt"
 tools/pmc_cmd.sh "prof_$tag/pmc_perfect" k_emit_perfect_pe "FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_WAVES" -- python3 bench.py --no-cpu-baseline --profile perfect-short --steps 1 --warmup 0 > "$out/pmc_perfect.txt"
 tools/pmc_cmd.sh "prof_$tag/pmc_custom_long" k_custom_long_splice "FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES;SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" -- python3 bench.py --no-cpu-baseline --profile custom-long --reads 1000000 --steps 1 --warmup 0 > "$out/pmc_custom_long.txt"
 tools/pmc_cmd.sh "prof_$tag/pmc_through_fastq" k_emit_philox "FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES;SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY" -- python3 bench.py --no-cpu-baseline --no-other-mode --through-fastq --steps 1 --warmup 0 > "$out/pmc_through_fastq.txt"
