@@ -103,7 +103,7 @@ struct simmr_engine {
   // best with far more workgroups than fit at a time (profiles/r3/ab_grid_sweep.log: k_emit_lanes 107.6 ms at 1 x, 98.5 at
   // 4 x, 94.7 at 64 x; k_emit_perfect_pe 6.65 / 5.99 / 5.78; k_emit_custom_pe 10.99 / 10.58 / 10.44 at 16 x; the splice
   // kernel does not care).  SIMMR_GRID_MULT overrides all of them (measurement knob, 1..512).
-  uint32_t lanes_mult = 64, perfect_mult = 64, custom_pe_mult = 16, custom_long_mult = 1, fastq_mult = 1;
+  uint32_t lanes_mult = 64, perfect_mult = 64, custom_pe_mult = 16, custom_long_mult = 1, fastq_mult = 4;  // (k_fastq_write: 34.6 / 32.8 / 33.2 / 33.4 / 34.4 ms per step at 1 / 4 / 16 / 64 / 256 x, profiles/r3/fastq_grid_probe.log)
   uint32_t tile_upb = 32;       // SIMMR_TILE_UPB: pairs per block of the tile kernel (1..32)
   uint32_t tile_cap = 0;        // SIMMR_TILE_CAP: bytes per LDS tile (0 = from the profile's read length)
   uint32_t tile_wgs_per_cu = 0; // SIMMR_TILE_WGS_PER_CU: 0 = what fits
@@ -849,6 +849,7 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
   if (const char* v = getenv("SIMMR_GRID_MULT"))
     e->lanes_mult = e->perfect_mult = e->custom_pe_mult = e->custom_long_mult = e->fastq_mult =
         (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
+  if (const char* v = getenv("SIMMR_FASTQ_GRID_MULT")) e->fastq_mult = (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_PHILOX_WGS_PER_CU")) e->philox_wgs_per_cu = (uint32_t)std::min<unsigned long long>(4096, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_TILE_UPB")) e->tile_upb = (uint32_t)std::min<unsigned long long>(32, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_TILE_CAP")) e->tile_cap = (uint32_t)std::min<unsigned long long>(16384, strtoull(v, nullptr, 10)) & ~15u;
@@ -2128,7 +2129,7 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
     uint32_t wshift = 0;
     while ((16u << wshift) < e->fq_maxhdr + 2u) wshift++;
     const bool own_headers = e->fastq_headers_form == 0;  // the emit kernel writes the headers itself
-    const uint32_t slots_lds = own_headers ? FQ_GROUP * e->fq_hpitch : 0u;
+    const uint32_t slots_lds = std::max<uint32_t>(PHILOX_MAP_ITEMS, own_headers ? FQ_GROUP * e->fq_hpitch : 0u);  // (the item map lives there too)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), slots_lds, e->stream, e->prof, paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(),
                        e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome,
                        e->u_seed.as<uint64_t>(), dst, dst, 33u, e->plan_first, e->fq_read_id_base, OutCols{}, counters,

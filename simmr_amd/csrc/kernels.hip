@@ -2054,7 +2054,7 @@ SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1,
 #define PHILOX_MAP_ITEMS 4096u
 #define PHILOX_CBASE 64u /* contig bases kept in LDS by the CACHED kernels */
 #ifndef FQ_GROUP
-#define FQ_GROUP 64u /* TEXT: headers formatted at a time (LDS slots) */
+#define FQ_GROUP 128u /* TEXT: headers formatted at a time (LDS slots; they share their memory with the item map, see `owner`) */
 #endif
 
 // bytes a + b with per-byte wrap-around (u8 add of util.rs:46-50)
@@ -2270,7 +2270,11 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ uint64_t x_src[HAS_EXC ? PHILOX_READS : 1];          // first source base (exception-plane lookups)
   __shared__ const uint32_t* x_mask[HAS_EXC ? PHILOX_READS : 1];  // exception plane of the read's genome or null
   __shared__ uint32_t r_gs[PHILOX_READS + 1];  // first item of each read, ~0 past the last read
-  __shared__ uint8_t owner[PHILOX_MAP_ITEMS];   // item -> read, when the block has few enough items
+  // item -> read, when the block has few enough items.  TEXT: the map lives in the dynamic LDS under the header slots —
+  // the slots are dead once the block's headers are copied out (a barrier closes the header phase), the map is dead
+  // until then — which is what lets 128 slots and four workgroups per CU fit (engine.hip sizes it: max of the two)
+  __shared__ uint8_t owner_static[TEXT ? 1 : PHILOX_MAP_ITEMS];
+  uint8_t* const owner = TEXT ? fq_slots : owner_static;
   __shared__ uint64_t cbase[CACHED ? PHILOX_CBASE : 1];
   // byte masks (0xff) of the first n bytes of 16; SLOT: a second row at +32 with the LAST n bytes (a reverse mate's live bytes)
   __shared__ uint4 nmask[SLOT ? 64 : 17];
@@ -2432,8 +2436,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       }
     }
     if (TEXT && fq_tp) {
-      // headers of the block's reads, FQ_GROUP at a time (one wave's worth: with 128 the slots would cost the fourth
-      // workgroup per CU): the threads that hold them format, everybody copies
+      // headers of the block's reads, FQ_GROUP at a time (128: two waves format while two wait; 64 was the most that fit
+      // beside four workgroups per CU before the slots shared their memory with the item map): the threads that hold them
+      // format, everybody copies
       const uint32_t W = 1u << fq_wshift;  // 16-byte windows per run (covers the longest)
       for (uint32_t half = 0; half * FQ_GROUP < nr; half++) {
         lds_barrier();  // the slots are free (and, the first time, template and literals are staged)
@@ -2470,6 +2475,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         }
       }
     }
+    if (TEXT) lds_barrier();  // the header slots are read out: their memory becomes the item map
     if (tcoarse) {
       // (scanned above)
     } else if (coarse) {  // the reads' places too: the scan of their (padded) lengths rides in the upper half
