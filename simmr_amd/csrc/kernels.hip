@@ -2343,6 +2343,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     uint8_t* const seq_blk = seq + out0;
     uint8_t* const qual_blk = (TEXT ? seq : qual) + out0;
     lds_barrier();  // the previous block's items are done with the records
+#if defined(SIMMR_PROLOGUE_PRIO)  /* measurement: the latency-bound per-block part at a raised wave priority */
+    __builtin_amdgcn_s_setprio(SIMMR_PROLOGUE_PRIO);
+#endif
     uint32_t g = 0;
     uint32_t n_items = 0, ex = 0;
     uint64_t rec_place = 0;  // tcoarse: this thread's record, relative to the block's first
@@ -2507,6 +2510,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #endif
     // long reads (64 items and more each on average): a lane's items ascend 256 apart, so its read moves on by one
     // now and then — one look at the next read's first item instead of the eight dependent ones of the search
+#if defined(SIMMR_PROLOGUE_PRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const bool walk = !use_map && n_items >= nr * 64u;
     uint32_t r_walk = 0;
     // read of an item: last r with r_gs[r] <= item (items are asked for in ascending order per lane)

@@ -254,3 +254,69 @@ def test_c4_many_genomes_one_plan(engine):
     shift = a % 256
     assert torch.equal(torch.roll(colsum256(part.seq[:part.total_bases]), shift), checksum_range(whole.seq, a, b))
     assert torch.equal(torch.roll(colsum256(part.qual[:part.total_bases]), shift), checksum_range(whole.qual, a, b))
+
+
+def test_c2_full_size_slot16_is_the_compact_run(big):
+    """The 16-byte slot layout (SIMMR_SLOT16, the bench's default layout) at BASELINE configs[1]'s full size: the
+    layout rules of include/simmr_hip.h over all 100 M reads, padding 0, the same reads as the compact layout — every
+    metadata column, the run counters, the byte sums of both streams (padding adds nothing) over the whole run, and
+    byte-for-byte equality of three windows of 2 M reads —, all evaluated on the device."""
+    import torch
+    eng = big
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod()
+    eng.counters_reset()
+    comp = eng.simulate_pe_reads_from_genome(5, prof, N_READS, 42, qual_offset=33)
+    c_comp = eng.counters()
+    n = comp.n_reads
+    c_off = comp.seq_off[: n + 1].clone()
+    c_len = c_off[1:] - c_off[:-1]
+    c_sum_s = int(comp.seq[: comp.total_bases].sum(dtype=torch.int64))
+    c_sum_q = int(comp.qual[: comp.total_bases].sum(dtype=torch.int64))
+    cols = {k: getattr(comp, k)[:n].clone() for k in ("start", "end", "contig", "genome", "read_id", "flags")}
+    wins = [(0, 2_000_000), (n // 2 - 1_000_000, n // 2 + 1_000_000), (n - 2_000_000, n)]
+    k = torch.arange(256, device=c_off.device)
+
+    def window_bytes(stream, first, lens, a, b):
+        idx = first[a:b, None] + k[None, :]
+        live = k[None, :] < lens[a:b, None]
+        return torch.where(live, stream[idx.clamp(max=stream.numel() - 1)], torch.zeros((), dtype=torch.uint8, device=stream.device))
+    want = [(window_bytes(comp.seq, c_off[:-1], c_len, a, b), window_bytes(comp.qual, c_off[:-1], c_len, a, b)) for a, b in wins]
+    del comp
+    eng.set_read_slots(16)
+    try:
+        eng.counters_reset()
+        slot = eng.simulate_pe_reads_from_genome(5, prof, N_READS, 42, qual_offset=33)
+        c_slot = eng.counters()
+    finally:
+        eng.set_read_slots(0)
+    assert slot.slot_bytes == 16 and slot.n_reads == n
+    assert list(c_slot) == list(c_comp)
+    for name, col in cols.items():
+        assert bool((getattr(slot, name)[:n] == col).all()), name
+    L = (slot.end[:n] - slot.start[:n]).abs()
+    assert bool((L == c_len).all())
+    Lp = (L + 15) // 16 * 16
+    place = torch.zeros(n + 1, dtype=torch.int64, device=L.device)
+    torch.cumsum(Lp, 0, out=place[1:])
+    tb = slot.total_bases
+    assert int(place[n]) == tb == int(slot.seq_off[n]) and tb % 16 == 0
+    first = slot.seq_off[:n]
+    rev = (slot.flags[:n] & _abi.FLAG_REVCOMP) != 0
+    assert bool(((first & ~15) == place[:n]).all())                               # a read's slot starts on 16 bytes
+    assert bool(((first - place[:n]) == torch.where(rev, Lp - L, torch.zeros_like(L))).all())  # right-aligned iff reverse
+    # padding adds nothing: the sums of all bytes are the compact run's
+    assert int(slot.seq[:tb].sum(dtype=torch.int64)) == c_sum_s
+    assert int(slot.qual[:tb].sum(dtype=torch.int64)) == c_sum_q
+    # ... and it is where the rules put it: the last 16 bytes of every slot hold L - (Lp - 16) live bytes
+    tail = Lp - L                                                                # padding bytes per read (0..15)
+    j = torch.arange(16, device=L.device)
+    sel = torch.arange(0, n, 97, device=L.device)                                # a million reads, both mates
+    q_last = slot.qual[(place[sel] + Lp[sel] - 16)[:, None] + j[None, :]]
+    assert not bool((q_last * (j[None, :] >= (16 - tail[sel])[:, None])).any())
+    s_edge = torch.where(rev[sel], place[sel], place[sel] + Lp[sel] - 16)        # reverse mates pad in FRONT
+    s_pad = torch.where(rev[sel][:, None], j[None, :] < tail[sel][:, None], j[None, :] >= (16 - tail[sel])[:, None])
+    assert not bool((slot.seq[s_edge[:, None] + j[None, :]] * s_pad).any())
+    # the reads themselves, byte for byte, in three windows
+    for (a, b), (ws, wq) in zip(wins, want):
+        assert bool((window_bytes(slot.seq, first, L, a, b) == ws).all())
+        assert bool((window_bytes(slot.qual, place[:n], L, a, b) == wq).all())
