@@ -2000,9 +2000,11 @@ static FqPlan fq_plan_view(simmr_engine* e) {
   return pn;
 }
 
-// does the current plan's emit kernel write into FASTQ text (the counter-mode item kernel)?
+// does the current plan's emit kernel write into FASTQ text?  The counter-mode item kernel does, and so does its copy-only
+// form for perfect-short (no draws at all: the planned bases, a constant quality line; perfect_short.rs:24-44)
 static bool fq_direct_kernel(const simmr_engine* e) {
-  return e->prof.kind != SIMMR_K_CUSTOM && e->prof.kind != SIMMR_K_PERFECT_SHORT && e->prof.rng_mode == SIMMR_RNG_PHILOX;
+  if (e->prof.kind == SIMMR_K_PERFECT_SHORT) return true;
+  return e->prof.kind != SIMMR_K_CUSTOM && e->prof.rng_mode == SIMMR_RNG_PHILOX;
 }
 
 int simmr_fastq_plan_direct(simmr_engine* e, const char* header_format, const simmr_fastq_names* names,
@@ -2125,6 +2127,12 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
                             : (exc ? k_emit_philox<true, false, false, true, true, false, true> : k_emit_philox<false, false, false, true, true, false, true>))
                   : (cached ? (exc ? k_emit_philox<true, false, true, true, false, false, true> : k_emit_philox<false, false, true, true, false, false, true>)
                             : (exc ? k_emit_philox<true, false, false, true, false, false, true> : k_emit_philox<false, false, false, true, false, false, true>));
+    if (e->prof.kind == SIMMR_K_PERFECT_SHORT) {  // the copy-only form: bases of the plan, every quality 60
+      kern = e->fq_coarse ? (cached ? (exc ? k_emit_philox<true, true, true, true, false, false, true> : k_emit_philox<false, true, true, true, false, false, true>)
+                                    : (exc ? k_emit_philox<true, true, false, true, false, false, true> : k_emit_philox<false, true, false, true, false, false, true>))
+                          : (cached ? (exc ? k_emit_philox<true, true, true, true> : k_emit_philox<false, true, true, true>)
+                                    : (exc ? k_emit_philox<true, true, false, true> : k_emit_philox<false, true, false, true>));
+    }
     // windows per run: the power of two that covers the longest run ('\n' + header + '\n'), at most 32 (512 bytes)
     uint32_t wshift = 0;
     while ((16u << wshift) < e->fq_maxhdr + 2u) wshift++;

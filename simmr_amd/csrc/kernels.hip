@@ -2247,6 +2247,10 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   // TEXT with COARSE: rec_off does not exist either; off64[w] = first byte of record 64 w, and a block places its records
   // with a scan of their lengths (header + 1 + L + 3 + L + 1, fastq.rs:58-66) before anything else
   constexpr bool tcoarse = COARSE && TEXT;
+  // COPY_ONLY with TEXT: perfect-short straight into FASTQ text (perfect_short.rs:42-44: every quality is 60): the copied
+  // bases, a constant quality line, headers and counters as in the drawing form
+  constexpr bool FULL = !COPY_ONLY || TEXT;  // this launch writes qualities, headers / metadata and all run counters
+  const uint32_t const_q4 = (((60u + (qual_offset & 0xffu)) & 0xffu) * 0x01010101u);
 #if defined(SIMMR_NT_PLAN_LOADS)  /* measurement: the plan rows (read once) as nontemporal loads */
 #define PL(x) __builtin_nontemporal_load(&(x))
 #else
@@ -2379,7 +2383,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint64_t dst = TEXT ? my_rec + hlen[rd] + 1u : (coarse ? out0 : u_off[u] + (rev ? Lp : 0u));  // (coarse: after the scan below)
       my_Lp = Lp; my_pad = (SLOT && rev) ? Lp - L : 0u; my_rd = rd; my_dst = dst;
       const uint64_t pos = rev ? PL(pl.b[u]) : PL(pl.a[u]);  // first source base of this read on the contig
-      const uint64_t key = rev ? PL(pl.qs2[u]) : PL(u_seed[u]);
+      const uint64_t key = COPY_ONLY ? 0ull : (rev ? PL(pl.qs2[u]) : PL(u_seed[u]));  // (no draws, no key; qs2 may not exist)
       uint64_t cb;
       const uint32_t* packed;
       const uint32_t* mk = nullptr;
@@ -2405,7 +2409,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #if defined(SIMMR_ABLATE_META)
       if (false) {
 #else
-      if (!COPY_ONLY) {
+      if (FULL) {
 #endif
         // metadata columns of this read (the other emit kernels leave them to k_write_meta)
         const uint32_t fl = PL(pl.flags[u]);
@@ -2568,6 +2572,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       if (HAS_EXC) { const uint32_t* mk = x_mask[r]; if (mk) exc = fetch_mask16(mk, (int64_t)(x_src[r] + b0)); }
       // per base: 24 bits -> (Phred, substitution shift s); qualities packed as bytes, s as 2-bit fields
       uint32_t qr[4] = {0, 0, 0, 0}, ss = 0;
+      if (COPY_ONLY && TEXT) { qr[0] = const_q4; qr[1] = const_q4; qr[2] = const_q4; qr[3] = const_q4; }
       if (!COPY_ONLY) {
         uint32_t w[12];
 #pragma unroll
@@ -2605,7 +2610,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       n_subst += __builtin_popcount((ss | (ss >> 1)) & 0x55555555u);
       // (without exception bases and outside the copy-only form, ACGT bases = bases = p_bases: nothing to count per item)
       if (HAS_EXC) n_acgt += __builtin_popcount(~spread16(exc) & live2 & 0x55555555u);
-      else if (COPY_ONLY) n_acgt += n;
+      else if (COPY_ONLY && !TEXT) n_acgt += n;
       if (!COPY_ONLY) {
         uint32_t qs = __builtin_amdgcn_udot4(qr[0], bm.x, 0u, false);
         qs = __builtin_amdgcn_udot4(qr[1], bm.y, qs, false);
@@ -2697,15 +2702,15 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #endif
 #if !defined(SIMMR_ABLATE_LINES) && !defined(SIMMR_ABLATE_HOTSTORE) && !defined(SIMMR_ABLATE_ALIGN16)
         if (SLOT) {  // (whole aligned lines per wave in the slot layout: nontemporal)
-          if (!COPY_ONLY) slot_store16(qual_blk, o_q, q_lo, q_hi);
+          if (FULL) slot_store16(qual_blk, o_q, q_lo, q_hi);
           slot_store16(seq_blk, o_s, s_lo, s_hi);
         } else
 #endif
         {
-          if (!COPY_ONLY) store16<SLOT>(qd, q_lo, q_hi);
+          if (FULL) store16<SLOT>(qd, q_lo, q_hi);
           store16<SLOT>(sd, s_lo, s_hi);
         }
-      } else if (!COPY_ONLY) {
+      } else if (FULL) {
         store_tail2(qd, q_lo, q_hi, sd, s_lo, s_hi, n);
       } else {
         store_tail(sd, s_lo, s_hi, n);
@@ -2717,7 +2722,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   // the sum over the lanes is exact)
   // (the masks of the dot products are 0xff bytes: qsum is a multiple of 255, divided exactly by the inverse of 255 modulo 2^64)
   qsum = qsum * 0xFEFEFEFEFEFEFEFFull + 256ull * n_wrap - (uint64_t)qoff * p_bases;
-  uint64_t acgt = (HAS_EXC || COPY_ONLY) ? (uint64_t)n_acgt : p_bases;
+  if (COPY_ONLY && TEXT) qsum = 60ull * p_bases;  // perfect_short.rs:42-44
+  uint64_t acgt = (HAS_EXC || !FULL) ? (uint64_t)n_acgt : p_bases;
   for (int d = 32; d > 0; d >>= 1) {
     n_subst += __shfl_down(n_subst, d, 64);
     acgt += __shfl_down(acgt, d, 64);
@@ -2732,14 +2738,14 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ unsigned long long wsum[4][SIMMR_N_COUNTERS];
   if ((threadIdx.x & 63u) == 0) {
     unsigned long long* w = wsum[threadIdx.x >> 6];
-    w[SIMMR_CNT_READS] = (!COPY_ONLY && blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)n_reads : 0ull;
-    w[SIMMR_CNT_BASES] = COPY_ONLY ? 0ull : (unsigned long long)p_bases;
+    w[SIMMR_CNT_READS] = (FULL && blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)n_reads : 0ull;
+    w[SIMMR_CNT_BASES] = !FULL ? 0ull : (unsigned long long)p_bases;
     w[SIMMR_CNT_ACGT_BASES] = (unsigned long long)acgt;
     w[SIMMR_CNT_SUBSTITUTIONS] = COPY_ONLY ? 0ull : (unsigned long long)n_subst;
     w[SIMMR_CNT_OUTER_REJECTS] = 0ull;
-    w[SIMMR_CNT_REDRAWN] = COPY_ONLY ? 0ull : (unsigned long long)p_redrawn;
-    w[SIMMR_CNT_SEED_SUBST] = COPY_ONLY ? 0ull : (unsigned long long)p_seedsubst;
-    w[SIMMR_CNT_QUAL_SUM] = COPY_ONLY ? 0ull : (unsigned long long)qsum;
+    w[SIMMR_CNT_REDRAWN] = !FULL ? 0ull : (unsigned long long)p_redrawn;
+    w[SIMMR_CNT_SEED_SUBST] = !FULL ? 0ull : (unsigned long long)p_seedsubst;
+    w[SIMMR_CNT_QUAL_SUM] = !FULL ? 0ull : (unsigned long long)qsum;
   }
   __syncthreads();
   if (threadIdx.x < SIMMR_N_COUNTERS && counters) {

@@ -215,6 +215,20 @@ def test_fastq_direct_exception_bases(engine):
     want = _two_step(engine, reads, names, FMT, True)
     engine.pe_plan(12, prof, 4001, 5, 1, 1990)
     _same_text(engine.fastq_direct(FMT, names, 3).cpu().numpy().tobytes(), want, "pairs ")
+    # perfect-short goes into the text through the copy-only form of the same kernel (no draws, every quality 60)
+    pp = PerfectShortErrorProfile().pod()
+    engine.counters_reset()
+    reads = engine.simulate_pe_reads_from_genome(12, pp, 3001, 6, first=3, count=1400, read_id_base=9, qual_offset=33)
+    c2 = engine.counters()
+    want = _two_step(engine, reads, names, FMT, True)
+    engine.counters_reset()
+    engine.pe_plan(12, pp, 3001, 6, 3, 1400)
+    _same_text(engine.fastq_direct(FMT, names, 9).cpu().numpy().tobytes(), want, "perfect pairs ")
+    c1 = engine.counters()
+    # (k_emit_perfect_pe leaves the ACGT counter alone when the genome has N / '-' runs; the text-writing form counts them)
+    keep = [i for i in range(_abi.N_COUNTERS) if i != _abi.CNT_ACGT_BASES]
+    assert np.array_equal(c1[keep], c2[keep])
+    assert int(c1[_abi.CNT_ACGT_BASES]) == sum(sum(line.count(b) for b in b"ACGT") for line in want.split(b"\n")[1::4])
     lp = MinimalLongErrorProfile(gamma_mean=2500.0, gamma_std=2000.0, length_mode=_abi.LEN_PER_READ, rng_mode=_abi.RNG_PHILOX).pod()
     reads = engine.simulate_long_reads([12], [60], lp, 8, qual_offset=33)
     want = _two_step(engine, reads, names, FMT, False)
