@@ -2137,7 +2137,11 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
     uint32_t wshift = 0;
     while ((16u << wshift) < e->fq_maxhdr + 2u) wshift++;
     const bool own_headers = e->fastq_headers_form == 0;  // the emit kernel writes the headers itself
+#if FQ_OVERLAP
+    const uint32_t slots_lds = own_headers ? FQ_WAVE * e->fq_hpitch : 0u;  // one wave's headers at a time
+#else
     const uint32_t slots_lds = std::max<uint32_t>(PHILOX_MAP_ITEMS, own_headers ? FQ_GROUP * e->fq_hpitch : 0u);  // (the item map lives there too)
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), slots_lds, e->stream, e->prof, paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(),
                        e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome,
                        e->u_seed.as<uint64_t>(), dst, dst, 33u, e->plan_first, e->fq_read_id_base, OutCols{}, counters,

@@ -2054,8 +2054,15 @@ SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1,
 #define PHILOX_MAP_ITEMS 4096u
 #define PHILOX_CBASE 64u /* contig bases kept in LDS by the CACHED kernels */
 #ifndef FQ_GROUP
-#define FQ_GROUP 128u /* TEXT: headers formatted at a time (LDS slots; they share their memory with the item map, see `owner`) */
+#define FQ_GROUP 128u /* TEXT, phase form: headers formatted at a time (LDS slots; they share their memory with the item map, see `owner`) */
 #endif
+#ifndef FQ_OVERLAP
+#define FQ_OVERLAP 0 /* TEXT: 0 = a block's headers are formatted in phases of their own (FQ_GROUP at a time); 1 = wave by wave in the shadow of
+                        the other waves' items, one barrier per step — bit-identical and no faster (19.6-19.9 vs 19.3-19.7 ms,
+                        profiles/r3/ab_fastq_overlap_vs_phases.log): what the headers cost is their bytes and their formatting, not the waves
+                        that wait meanwhile (the kernel without any header work: 13.8 ms, text_header_probe.log) */
+#endif
+#define FQ_WAVE 64u /* TEXT, overlapped form: one wave's reads = the header slots */
 
 // bytes a + b with per-byte wrap-around (u8 add of util.rs:46-50)
 SIMMR_DEV uint32_t add_bytes(uint32_t a, uint32_t b) {
@@ -2277,8 +2284,11 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   // item -> read, when the block has few enough items.  TEXT: the map lives in the dynamic LDS under the header slots —
   // the slots are dead once the block's headers are copied out (a barrier closes the header phase), the map is dead
   // until then — which is what lets 128 slots and four workgroups per CU fit (engine.hip sizes it: max of the two)
-  __shared__ uint8_t owner_static[TEXT ? 1 : PHILOX_MAP_ITEMS];
-  uint8_t* const owner = TEXT ? fq_slots : owner_static;
+  // (the overlapped TEXT form formats headers WHILE items run: its 64 slots and the map are both live, nothing is shared)
+  constexpr bool fq_overlap = TEXT && (FQ_OVERLAP != 0);
+  constexpr bool fq_shared_map = TEXT && !fq_overlap;
+  __shared__ uint8_t owner_static[fq_shared_map ? 1 : PHILOX_MAP_ITEMS];
+  uint8_t* const owner = fq_shared_map ? fq_slots : owner_static;
   __shared__ uint64_t cbase[CACHED ? PHILOX_CBASE : 1];
   // byte masks (0xff) of the first n bytes of 16; SLOT: a second row at +32 with the LAST n bytes (a reverse mate's live bytes)
   __shared__ uint4 nmask[SLOT ? 64 : 17];
@@ -2442,7 +2452,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         }
       }
     }
-    if (TEXT && fq_tp) {
+    if (TEXT && fq_tp && !fq_overlap) {
       // headers of the block's reads, FQ_GROUP at a time (128: two waves format while two wait; 64 was the most that fit
       // beside four workgroups per CU before the slots shared their memory with the item map): the threads that hold them
       // format, everybody copies
@@ -2482,7 +2492,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         }
       }
     }
-    if (TEXT) lds_barrier();  // the header slots are read out: their memory becomes the item map
+    if (fq_shared_map) lds_barrier();  // the header slots are read out: their memory becomes the item map
     if (tcoarse) {
       // (scanned above)
     } else if (coarse) {  // the reads' places too: the scan of their (padded) lengths rides in the upper half
@@ -2544,22 +2554,69 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       return *reinterpret_cast<global_u64_unaligned_ptr>(wa);
 #endif
     };
+    // One item ahead (lever b of the round-2 verdict): the NEXT item's read and plane word are fetched before this item's
+    // stores are issued, so the wait for that load no longer stands behind them in the in-order counter.  Measured with
+    // the drawing forms (-DSIMMR_PREFETCH_CODES): no gain (13.34 vs 13.22 ms, long reads 50.5 vs 49.6; the TEXT form loses
+    // its registers to it: profiles/r3/ab_prefetch_*).  The copy-only forms have nothing but that wait between two items
+    // and registers to spare: there it is on.
 #if defined(SIMMR_PREFETCH_CODES)
-    // One item ahead (lever b of the round-2 verdict, -DSIMMR_PREFETCH_CODES): the NEXT item's read and plane word are
-    // fetched before this item's stores are issued, so the wait for that load no longer stands behind them in the
-    // in-order counter.  Measured: no gain (13.34 vs 13.22 ms, long reads 50.5 vs 49.6: profiles/r3/ab_prefetch_*), off.
+    constexpr bool prefetch = true;
+#else
+    constexpr bool prefetch = COPY_ONLY;
+#endif
+    // TEXT, overlapped form: the block's headers are formatted wave by wave — in step s wave s formats the headers of the
+    // 64 reads its lanes hold into the LDS slots and copies them out itself (a run = the '\n' that closes the record
+    // before, the header, its '\n'; 16-byte windows, the last one ending where the run ends), while the other three waves
+    // walk the s-th part of the block's items; one barrier per step hands the slots on.  Formatting 64 headers and
+    // copying them out costs a wave about what a third of a quarter of the items costs each of the others (~1000
+    // instructions), so nobody waits for long, and no wave sits at a barrier while headers are formatted.
+    const uint32_t n_steps = (fq_overlap && fq_tp) ? (nr + FQ_WAVE - 1u) / FQ_WAVE : 1u;  // (nr >= 1: 1..4)
+    for (uint32_t step = 0; step < n_steps; step++) {
+    const bool formatter = fq_overlap && fq_tp && (threadIdx.x >> 6) == step;
+    if (formatter) {
+      const uint32_t lane = threadIdx.x & 63u;
+      if (threadIdx.x < nr) {
+        uint8_t* h = fq_slots + lane * fq_hpitch;
+        const uint32_t lead = h_rd > 0 ? 1u : 0u;
+        h[0] = '\n';  // ends the record before this one
+        uint32_t at = fq_format_header(h, lead, fq_segs, fq_n_segs, fq_tb, fq_lit, hf, (paired && (threadIdx.x & 1u)) ? '2' : '1');
+        h[at++] = '\n';
+        fq_run_at[lane] = h_rec - lead;
+        fq_run_len[lane] = at;
+        if (hf.L == 0) { uint8_t* p = seq + h_rec + (at - lead); p[0] = '\n'; p[1] = '+'; p[2] = '\n'; }  // (no item writes it)
+        if (h_rd + 1 == n_reads) seq[(tcoarse ? off64[(n_reads + 63u) >> 6] : rec_off[n_reads]) - 1] = '\n';
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's slot writes are done (LDS serves a wave in order)
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t W = 1u << fq_wshift;
+      const uint32_t n_runs = nr - FQ_WAVE * step < FQ_WAVE ? nr - FQ_WAVE * step : FQ_WAVE;
+      for (uint32_t wi = lane; wi < (n_runs << fq_wshift); wi += 64u) {
+        const uint32_t i = wi >> fq_wshift, piece = wi & (W - 1u);
+        const uint32_t n = fq_run_len[i];
+        uint8_t* d = seq + fq_run_at[i];
+        const uint8_t* sl = fq_slots + i * fq_hpitch;
+        if (n >= 16u) {  // the last window ends where the run ends (it overlaps its neighbour with the same bytes)
+          if (piece * 16u < n) {
+            const uint32_t w0 = (piece + 1u) * 16u <= n ? piece * 16u : n - 16u;
+            *reinterpret_cast<v4u32_unaligned*>(d + w0) = *reinterpret_cast<const v4u32_unaligned*>(sl + w0);
+          }
+        } else if (piece == 0u) {
+          for (uint32_t j = 0; j < n; j++) d[j] = sl[j];
+        }
+      }
+    } else {
+    // the items of this step: all of them (one step), or the step-th part dealt to the 192 lanes that are not formatting
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t it_rank = (fq_overlap && fq_tp) ? ((wv - (wv > step ? 1u : 0u)) << 6) + (threadIdx.x & 63u) : threadIdx.x;
+    const uint32_t it_stride = (fq_overlap && fq_tp) ? 192u : 256u;
+    const uint32_t it_lo = (fq_overlap && fq_tp) ? (uint32_t)(((uint64_t)i_end * step) / n_steps) : 0u;
+    const uint32_t it_hi = (fq_overlap && fq_tp) ? (uint32_t)(((uint64_t)i_end * (step + 1u)) / n_steps) : i_end;
     uint32_t r_next = 0;
     uint64_t raw_next = 0;
-    if (threadIdx.x < i_end) { r_next = locate(threadIdx.x); raw_next = plane_word(threadIdx.x, r_next); }
-#endif
-    for (uint32_t item = threadIdx.x; item < i_end; item += 256) {
-#if defined(SIMMR_PREFETCH_CODES)
-      const uint32_t r = r_next;
-      const uint64_t raw = raw_next;
-#else
-      const uint32_t r = locate(item);
-      const uint64_t raw = plane_word(item, r);
-#endif
+    if (prefetch && it_lo + it_rank < it_hi) { r_next = locate(it_lo + it_rank); raw_next = plane_word(it_lo + it_rank, r_next); }
+    for (uint32_t item = it_lo + it_rank; item < it_hi; item += it_stride) {
+      const uint32_t r = prefetch ? r_next : locate(item);
+      const uint64_t raw = prefetch ? raw_next : plane_word(item, r);
       const uint4 ra = rec4[2 * r], rb = rec4[2 * r + 1];
       const uint32_t k0 = ra.x, k1 = ra.y, lw = ra.w;
       const uint32_t L = lw & 0xffffu, rev = lw >> 31;
@@ -2658,9 +2715,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       // qualities are already offset-encoded, forward order
       const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
       const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
-#if defined(SIMMR_PREFETCH_CODES)
-      if (item + 256u < i_end) { r_next = locate(item + 256u); raw_next = plane_word(item + 256u, r_next); }
-#endif
+      if (prefetch && item + it_stride < it_hi) { r_next = locate(item + it_stride); raw_next = plane_word(item + it_stride, r_next); }
 #if defined(SIMMR_ABLATE_STORES)
       asm volatile("" :: "v"(q_lo), "v"(q_hi), "v"(s_lo), "v"(s_hi), "v"(o_q), "v"(o_s));  // alive, not stored
 #else
@@ -2717,6 +2772,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       }
 #endif
     }
+    }  // (not the formatter)
+    if (fq_overlap && fq_tp) lds_barrier();  // the slots pass to the next step's wave (and, at the end, to the next block's)
+    }  // steps
   }
   // sum of the raw Phred values (per lane modulo 2^64: a lane that wrote records but drew few bases goes "negative";
   // the sum over the lanes is exact)
