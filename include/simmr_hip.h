@@ -389,11 +389,15 @@ int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst
  * start and end; the lengths of the ids), so
  *   simmr_fastq_plan_direct sizes every record from the plan and returns the total, and
  *   simmr_emit_fastq writes the shard's records back to back into dst (device memory, >= total bytes): the emit kernel
- *     stores bases and qualities (offset 33, util.rs:46-57) at their places in the text, a second kernel the headers
- *     and line ends.  The run counters advance as simmr_*_emit advances them.
+ *     stores bases and qualities (offset 33, util.rs:46-57) at their places in the text and formats the headers and
+ *     line ends of its block's records itself.  The run counters advance as simmr_*_emit advances them (for a
+ *     perfect-short run on a genome with N / '-' bases SIMMR_CNT_ACGT_BASES is counted here, which simmr_pe_emit
+ *     leaves at 0).
  * The bytes are those of simmr_*_emit (qual_offset 33) + simmr_fastq_plan + simmr_fastq_emit with the same arguments,
- * and the same cases are refused with SIMMR_ENOTSUP.  Profiles whose emit kernel cannot write into text (perfect-short,
- * SIMMR_RNG_REFERENCE, custom models) are served through columns held by the engine: same result, no saving. */
+ * and the same cases are refused with SIMMR_ENOTSUP.  Served by a kernel that writes into the text: the counter mode
+ * (SIMMR_RNG_PHILOX) of the minimal / perfect-long profiles, and perfect-short (no draws: the planned bases and a
+ * constant quality line).  Profiles whose emit kernel cannot write into text (SIMMR_RNG_REFERENCE, custom models) are
+ * served through columns held by the engine: same result, no saving. */
 int simmr_fastq_plan_direct(simmr_engine* e, const char* header_format, const simmr_fastq_names* names,
                             uint32_t read_id_base, uint64_t* total_bytes);
 int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity);
