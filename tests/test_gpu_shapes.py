@@ -330,3 +330,59 @@ print("inside")
     env = dict(os.environ, SIMMR_HIP_LIB=str(lib))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "inside" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("knobs", [{"SIMMR_PHILOX_WGS_PER_CU": "1", "SIMMR_GRID_MULT": "1"},
+                                   {"SIMMR_PHILOX_WGS_PER_CU": "7", "SIMMR_GRID_MULT": "3"},
+                                   {"SIMMR_PHILOX_WGS_PER_CU": "4096", "SIMMR_GRID_MULT": "512"}])
+def test_results_do_not_depend_on_the_grid(engine, monkeypatch, knobs):
+    """The emit kernels are grid-stride loops whose launch size is a tuning knob ("the grid"), and the
+    run counters are summed from per-workgroup rows: reads, metadata and counters must be the same for one workgroup per
+    CU, for an odd number, and for one block per workgroup — both generators, both layouts of the counter mode,
+    perfect-short, long reads, and the FASTQ text straight from the plan."""
+    from simmr_amd import MinimalLongErrorProfile, PerfectShortErrorProfile
+    from simmr_amd.engine import Engine
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)  # (read once, at engine creation)
+    other = Engine(0)
+    try:
+        names = [(21, "g21", ["c%d" % i for i in range(3)])]
+        for eng in (engine, other):
+            eng.stage_synthetic(21, [400_000, 70_001, 150_000], 4)
+        runs = [("philox", MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod(), 0),
+                ("philox slot16", MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod(), 16),
+                ("reference", MinimalShortErrorProfile().pod(), 0),
+                ("perfect", PerfectShortErrorProfile().pod(), 0)]
+        for what, prof, slot in runs:
+            got = []
+            for eng in (engine, other):
+                eng.set_read_slots(slot)
+                try:
+                    eng.counters_reset()
+                    r = eng.simulate_pe_reads_from_genome(21, prof, 60_001, 5, first=7, count=29_000, read_id_base=3, qual_offset=33)
+                    c = eng.counters()
+                    eng.pe_plan(21, prof, 60_001, 5, 7, 29_000)
+                    text = eng.fastq_direct("@{:read_id:}/{:pair:} {:sequence_id:} {:start_position:}", names, 3).cpu().numpy().tobytes() if slot == 0 else b""
+                finally:
+                    eng.set_read_slots(0)
+                got.append((r.raw_to_host() if slot else r.to_host(), c, text))
+            (a, ca, ta), (b, cb, tb) = got
+            assert np.array_equal(ca, cb), what
+            assert ta == tb, what
+            if slot:
+                for k in a:
+                    assert np.array_equal(a[k], b[k]), (what, k)
+            else:
+                from tests.test_gpu_parity import assert_same
+                assert_same(a, b)
+        lp = MinimalLongErrorProfile(gamma_mean=3000.0, gamma_std=2500.0, length_mode=_abi.LEN_PER_READ, rng_mode=_abi.RNG_PHILOX).pod()
+        got = []
+        for eng in (engine, other):
+            eng.counters_reset()
+            r = eng.simulate_long_reads([21], [900], lp, 9, qual_offset=33)
+            got.append((r.to_host(), eng.counters()))
+        from tests.test_gpu_parity import assert_same
+        assert_same(got[0][0], got[1][0])
+        assert np.array_equal(got[0][1], got[1][1])
+    finally:
+        other.close()
