@@ -2514,8 +2514,17 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     if (threadIdx.x == 0) r_gs[PHILOX_READS] = 0xffffffffu;
     // short reads: every read writes its index over its items, so an item finds its read with one LDS load
     const bool use_map = n_items <= PHILOX_MAP_ITEMS;
-    if (use_map && threadIdx.x < nr)
-      for (uint32_t j = 0; j < g; j++) owner[ex + j] = (uint8_t)threadIdx.x;
+    if (use_map && threadIdx.x < nr) {
+      // (8 <= g <= 16, every 150 bp-class read: two 8-byte LDS writes at any byte address, the second ending where the
+      // read's items end, instead of g byte writes in a loop)
+      const uint64_t t8 = (uint64_t)threadIdx.x * 0x0101010101010101ull;
+      if (g >= 8u && g <= 16u) {
+        *reinterpret_cast<u64_unaligned*>(owner + ex) = t8;
+        *reinterpret_cast<u64_unaligned*>(owner + ex + g - 8u) = t8;
+      } else {
+        for (uint32_t j = 0; j < g; j++) owner[ex + j] = (uint8_t)threadIdx.x;
+      }
+    }
     lds_barrier();
 #if defined(SIMMR_ABLATE_ITEMS)
     const uint32_t i_end = n_items < 256u ? n_items : 256u;  // one round instead of all
