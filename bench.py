@@ -2,6 +2,7 @@
 """bench.py — the reference's headline workload on MI355X.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...        (starts its own N ranks as child processes, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one pass of the whole hot path (outer seed stream, per-pair planning,
@@ -31,6 +32,24 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of
+    `python -m torch.distributed.run` (one rank per GPU, rendezvous on 127.0.0.1 at a free port), pass their
+    output through (rank 0 prints the JSON line) and return the launcher's exit code.  Called before this
+    process imports torch, so nothing here has initialised a GPU; nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")             # (the launcher would set it anyway; cpu_baseline sets its own)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,11 +75,18 @@ def main():
                          "slot of seq / qual (SIMMR_SLOT16, include/simmr_hip.h), the emit kernel then writes whole aligned 16-byte "
                          "groups only; compact: byte streams without gaps (the other one is timed once as `other_layout`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=None,
+                    help="cpu_baseline sample of the paired-end profiles (default 20 M reads, 400 000 for custom-short)")
+    ap.add_argument("--cpu-sample-long-reads", type=int, default=None,
+                    help="cpu_baseline sample of the long-read profiles (BASELINE.md B4; default 100 000 reads, 1000 for custom-long)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only for rehearsing N>1 on a single GPU (all ranks then share --rehearse-device)")
     ap.add_argument("--rehearse-device", type=int, default=None)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly with --gpus N: this process has touched no device yet and never will
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -73,7 +99,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` (it launches "
+                         f"its own ranks) or under torch.distributed.run with --nproc-per-node {args.gpus}")
     if args.rehearse_device is not None:
         local_rank = args.rehearse_device
     torch.cuda.set_device(local_rank)
@@ -147,7 +174,7 @@ def main():
     # (one pair of buffers serves both layouts of the side measurements: sized for the larger, the slots)
     slot_capable = prof.rng_mode == _abi.RNG_PHILOX and custom is None and args.profile != "perfect-short"
     cap_bases = info.total_bases
-    if slot_capable and not slot16:
+    if slot_capable and not slot16 and world == 1 and not args.no_other_mode:
         eng.set_read_slots(16)
         cap_bases = max(cap_bases, plan().total_bases)
         eng.set_read_slots(0)
@@ -342,7 +369,14 @@ def main():
                            f"{2 * int(info.total_bases)} stream bytes per step" if slot16 else
                            f"compact: seq / qual byte streams without gaps, {2 * int(info.total_bases)} stream bytes per step"),
                 "reads_per_gpu": 2 * pairs_per_gpu,
-                "sharding": "pair-index range per GPU",
+                "sharding": ("global read-index range per GPU" if long_mode else "pair-index range per GPU"),
+                # what carried the collectives of this run, and how many ranks it saw
+                "backend": ("none (one rank)" if world == 1 else
+                            "nccl (RCCL)" if args.backend == "nccl" else "gloo (CPU rehearsal: every rank on one device)"),
+                "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                "collectives": ("none" if world == 1 else
+                                "per step one all-reduce of %d run counters; once before the timed steps one all-gather of 4 x i64 "
+                                "per rank (outer-stream seek)" % _abi.N_COUNTERS),
             },
             "gbases_per_sec": n_bases_job * args.steps / elapsed / 1e9,
             "substitution_rate": subst_rate,
@@ -393,12 +427,16 @@ def main():
             result["config"]["output"] = "FASTQ text in HBM (header format of cli.rs:193-200), no SoA columns"
             result["fastq"] = {"text_bytes": fq["bytes"], "fastq_plan_ms_per_step": sum(fq["plan_ms"]) / max(len(fq["plan_ms"]), 1),
                                "text_GBps": fq["bytes"] * args.steps / elapsed / 1e9}
-        if world == 1 and not args.no_cpu_baseline and not long_mode:
-            result["cpu_baseline"] = cpu_baseline(args, prof)
-        print(json.dumps(result), flush=True)
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the CPU leg runs on rank 0 after the ranks have parted (nobody waits in a collective while it runs)
+        result["reference_toolchain"] = reference_toolchain()
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_long(args, prof) if long_mode else cpu_baseline(args, prof)
+        print(json.dumps(result), flush=True)
 
 
 PMC_RECORD = ROOT / "profiles" / "r3" / "pmc_traffic.json"
@@ -492,6 +530,76 @@ def usable_cores():
     return n
 
 
+def reference_toolchain():
+    """the reference is Rust; say whether this box could have built it."""
+    import shutil
+    import subprocess
+    exe = shutil.which("cargo")
+    if exe is None:
+        return "absent (no cargo on PATH: the reference cannot be built or timed here; cpu_baseline is the C restatement)"
+    try:
+        return subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=20).stdout.strip() or "cargo present, no version"
+    except (OSError, subprocess.SubprocessError) as e:
+        return f"cargo at {exe} does not run ({e.__class__.__name__})"
+
+
+def _reference_mode_copy(prof):
+    import ctypes
+    from simmr_amd import _abi
+    ref = type(prof)()
+    ctypes.memmove(ctypes.byref(ref), ctypes.byref(prof), ctypes.sizeof(prof))
+    ref.rng_mode = _abi.RNG_REFERENCE
+    return ref
+
+
+def cpu_baseline_long(args, prof):
+    """BASELINE.md section 3, run B4: the CPU oracle's simulate_long_reads (simulate.rs:323-406,
+    minimal_long.rs:58-73 / custom_short.rs for the model) on the first reads of the same run, one thread and
+    all of this host's, with the reference's generator.  The default figure leaves out what the reference does
+    on top of the algorithm — a clone of every usable sequence of the genome plus one of the chosen sequence
+    per read (simulate.rs:362-375) — and `faithful_cost` times a smaller sample with those copies made."""
+    from tests import _oracle, _synth
+    lib = _oracle.load()
+    prof = _reference_mode_copy(prof)
+    genome = _oracle.HostGenome(_synth.synthetic_contigs([args.genome_bases], 2))
+    cores = usable_cores()
+    total_reads = 2 * (args.reads // 2) * args.gpus
+
+    def timed(n, threads, faithful=False):
+        lib.orc_set_faithful_cost(1 if faithful else 0)
+        try:
+            _oracle.simulate_long(lib, [genome], [total_reads], prof, args.seed, 0, min(n, 64), threads=threads)  # pages, tables
+            t = time.perf_counter()
+            o = _oracle.simulate_long(lib, [genome], [total_reads], prof, args.seed, 0, n, threads=threads)
+            return time.perf_counter() - t, o
+        finally:
+            lib.orc_set_faithful_cost(0)
+    # sized for about 10-30 s of CPU work in all: the model's k-mer splice builds an alias table per visited k-mer
+    # (custom_short.rs:497-500), which makes a custom long read cost 0.2 s on one thread
+    custom = args.profile == "custom-long"
+    n = min(args.cpu_sample_long_reads or (1000 if custom else 100_000), total_reads)
+    n1 = max(n // (16 if custom else 8), 1)
+    t1, _ = timed(n1, 1)
+    tn, o = timed(n, cores)
+    nf = max(min(n // (50 if custom else 1000), 60), 1)
+    tf, of = timed(nf, 1, faithful=True)
+    return {
+        "value": n / tn, "unit": "reads/s", "cores": cores, "kind": "port",
+        "sample": f"first {n} long reads of the same run (same genome, profile, seed; the reference's ChaCha12 streams), OpenMP over "
+                  f"reads on {cores} threads, {tn:.1f} s; without the reference's per-read clones of the genome (simulate.rs:362-375)",
+        "gbases_per_sec": o.total_bases / tn / 1e9,
+        "single_thread_value": n1 / t1, "single_thread_gbases_per_sec": _bases_of(o, n1) / t1 / 1e9,
+        "single_thread_sample": f"first {n1} reads, 1 thread, {t1:.1f} s",
+        "faithful_cost": {"value": nf / tf, "unit": "reads/s", "cores": 1, "gbases_per_sec": of.total_bases / tf / 1e9,
+                          "sample": f"first {nf} reads, 1 thread, {tf:.1f} s, with the clones of simulate.rs:362-375 made "
+                                    f"(every usable sequence once, the chosen one again: {2 * args.genome_bases} bytes per read)"},
+    }
+
+
+def _bases_of(o, n):
+    return int(o.seq_off[n])
+
+
 def cpu_baseline(args, prof):
     """The CPU oracle — a port of the reference algorithm with the reference's own
     generator (the Rust reference cannot be built here) — on a bounded sample of the
@@ -501,11 +609,7 @@ def cpu_baseline(args, prof):
     from simmr_amd import _abi
     from tests import _oracle, _synth
     lib = _oracle.load()
-    import ctypes
-    ref = type(prof)()
-    ctypes.memmove(ctypes.byref(ref), ctypes.byref(prof), ctypes.sizeof(prof))
-    prof = ref
-    prof.rng_mode = _abi.RNG_REFERENCE
+    prof = _reference_mode_copy(prof)
     contigs = _synth.synthetic_contigs([args.genome_bases], 2)
     genome = _oracle.HostGenome(contigs)
     cores = usable_cores()
@@ -517,9 +621,11 @@ def cpu_baseline(args, prof):
         t = time.perf_counter()
         o = _oracle.simulate_pe(lib, genome, prof, n, args.seed, threads=threads, out=out)
         return time.perf_counter() - t, o
-    n1 = min(args.cpu_sample_reads // 8, 250_000)
+    # about 10-30 s of CPU work in all (an empirical-model pair costs 100 x a minimal-short one on the CPU)
+    n = args.cpu_sample_reads or (400_000 if args.profile == "custom-short" else 20_000_000)
+    n = min(n, 2 * (args.reads // 2) * args.gpus)
+    n1 = max(2, min(n // 8, 20_000 if args.profile == "custom-short" else 250_000))
     t1, _ = timed(n1, 1)
-    n = args.cpu_sample_reads
     tn, o = timed(n, cores)
     return {
         "value": n / tn,

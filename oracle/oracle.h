@@ -149,6 +149,9 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
                             uint32_t read_id_base, const simmr_reads_out* out,
                             uint64_t* total_bases, uint32_t* const_len, int threads);
 
+/* cpu_baseline only: also pay the reference's per-read clones of the genome (simulate.rs:362-375); results unchanged */
+void orc_set_faithful_cost(int on);
+
 /* ---------------- custom (empirical) profile: custom_short.rs + its crates (custom.c) */
 typedef struct orc_uniform_u32 { uint32_t low, range, z; } orc_uniform_u32;
 typedef struct orc_uniform_f64 { double low, scale; } orc_uniform_f64;

@@ -84,6 +84,7 @@ struct simmr_engine {
   uint32_t plan_slot = 0;   // ... and of the plan in force
   bool plan_coarse = false; // pairs for the counter-mode kernel: u_off64 (first byte of every 64th pair) instead of u_off
   DevBuf w_bytes, u_off64, fq_off64;
+  uint32_t splice_lds_set[2] = {0, 0};  // dynamic-LDS limit already set on this device for k_custom_long_splice<exc, fast>
   bool fq_coarse = false;  // the direct FASTQ plan in force has fq_off64 (first byte of every 64th record) instead of fq_off
   bool fine_offsets = false;  // SIMMR_FINE_OFFSETS=1: per-pair offsets for the counter-mode kernel too (A/B timing)
   bool plan_paired = false;
@@ -1546,10 +1547,11 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
         // one workgroup of 1024 lanes per CU around the LDS count table (kernels.hip section 9c)
         auto kern = exc ? k_custom_long_splice<true, true> : k_custom_long_splice<false, true>;
         const uint32_t lds = splice_fast_lds_bytes(e->prof.custom.kmer_size);
-        static bool attr_set[2] = {false, false};  // once per kernel variant and process, not once per emit
-        if (!attr_set[exc ? 1 : 0]) {
+        // not once per emit: the limit is per device and grows with the model's k (132 KB + 4^k), so each engine keeps
+        // the largest size it has set per kernel variant and sets it again only when a model needs more
+        if (lds > e->splice_lds_set[exc ? 1 : 0]) {
           HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          attr_set[exc ? 1 : 0] = true;
+          e->splice_lds_set[exc ? 1 : 0] = lds;
         }
         const uint32_t fgrid = (uint32_t)std::min<uint64_t>((n_reads + SPLICE_FAST_LANES - 1) / SPLICE_FAST_LANES, (uint64_t)e->n_cu * 8 * e->custom_long_mult);
         hipLaunchKernelGGL(kern, dim3(fgrid), dim3(SPLICE_FAST_LANES), lds, e->stream, e->prof, e->d_genomes.as<GenomeDev>(),
@@ -2172,8 +2174,13 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
 // ---- counters / timing ---------------------------------------------------------------
 int simmr_counters(simmr_engine* e, uint64_t* dst_device, uint64_t* dst_host) {
   if (!e) return SIMMR_EINVAL;
+  HIP_TRY(e, hipSetDevice(e->device));
   // (the counter-mode emit kernel's workgroups add to SIMMR_CNT_SHARDS partial rows behind the counters: fold them in)
   hipLaunchKernelGGL(k_counters_fold, dim3(1), dim3(64), 0, e->stream, e->d_counters.as<unsigned long long>());
+  {
+    hipError_t s = hipGetLastError();
+    if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "counter fold launch failed: %s", hipGetErrorString(s));
+  }
   if (dst_device)
     HIP_TRY(e, hipMemcpyAsync(dst_device, e->d_counters.p, 8 * SIMMR_N_COUNTERS, hipMemcpyDeviceToDevice, e->stream));
   if (dst_host) {
@@ -2185,6 +2192,7 @@ int simmr_counters(simmr_engine* e, uint64_t* dst_device, uint64_t* dst_host) {
 
 int simmr_counters_reset(simmr_engine* e) {
   if (!e) return SIMMR_EINVAL;
+  HIP_TRY(e, hipSetDevice(e->device));
   HIP_TRY(e, hipMemsetAsync(e->d_counters.p, 0, 8 * SIMMR_N_COUNTERS * (1 + SIMMR_CNT_SHARDS), e->stream));
   return SIMMR_OK;
 }

@@ -62,7 +62,7 @@ k_fastq_size_plan(const FqTemplate* __restrict__ tp, FqTables tb, FqPlan pn, uin
     unsigned long long s = len;
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
     if ((threadIdx.x & 63u) == 0) {
-      if (wave_bytes) wave_bytes[((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6] = s;
+      if (wave_bytes) { if (on) wave_bytes[r >> 6] = s; }  // (ceil(n_reads / 64) entries: idle waves of the last block have none)
       else if (s) atomicAdd(&tile_bytes[((uint64_t)blockIdx.x * 256u) / (SCAN_THREADS * SCAN_ITEMS)], s);
     }
   }

@@ -599,7 +599,8 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
     unsigned long long s = 2ull * ((planned + slot_round) & ~slot_round);  // (slot_round = 15 for 16-byte read slots, else 0)
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
     if ((threadIdx.x & 63u) == 0) {
-      if (wave_bytes) wave_bytes[((uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x) >> 6] = s;
+      // (a wave whose first pair lies beyond the shard has no entry: the array holds ceil(n_units / 64) sums)
+      if (wave_bytes) { if (k < n_units) wave_bytes[k >> 6] = s; }
       else if (s) atomicAdd(&tile_bytes[((uint64_t)blockIdx.x * PLAN_THREADS) / (SCAN_THREADS * SCAN_ITEMS)], s);
     }
   }

@@ -181,6 +181,9 @@ static int run_scope(simmr_engine* eng, const CliArgs& args, const std::vector<G
         fclose(drain.f); drain.f = nullptr;
       } else if (rc != SIMMR_OK) {
         return die(simmr_last_error(eng));
+      } else if (bytes == 0) {
+        written = true;  // a scope without a unit (--num-reads < 2, a genome whose share is below one pair): the reference
+                         // writes nothing for it and goes on (simulate.rs:179, main.rs:188-206)
       } else {
         uint8_t* dst = drain.buffer(buf, bytes);
         if (!dst) return die("no device memory for " + std::to_string(bytes) + " bytes of FASTQ text: use a smaller --device-chunk-reads");

@@ -88,6 +88,8 @@ def load():
     lib.orc_simulate_long_reads.argtypes = [
         P(Genome), C.c_uint32, P(C.c_uint64), P(ErrorProfilePOD), C.c_int, C.c_uint64, C.c_uint64,
         C.c_uint64, C.c_uint32, P(ReadsOut), P(C.c_uint64), P(C.c_uint32), C.c_int]
+    lib.orc_set_faithful_cost.argtypes = [C.c_int]
+    lib.orc_set_faithful_cost.restype = None
     lib.orc_profile_simulate_phred_scores.argtypes = [P(ErrorProfilePOD), C.c_uint64, C.c_uint64, C.c_void_p]
     lib.orc_profile_simulate_point_mutations.argtypes = [P(ErrorProfilePOD), C.c_void_p, C.c_void_p,
                                                          C.c_uint64, C.c_uint64, C.c_void_p]

@@ -240,3 +240,33 @@ def test_cli_device_chunks_do_not_change_the_output(workdir):
             subprocess.check_call([str(EXE), "--output", str(out), "--device-chunk-reads", c] + argv)
             assert out.read_bytes() == whole.read_bytes(), (argv, c)
             assert (d / f"chunk_{i}_{c}.fq.tsv").read_text() == (d / f"chunk_ref_{i}.fq.tsv").read_text()
+
+
+def test_cli_a_genome_without_a_pair_is_skipped(workdir, oracle):
+    """A scope with zero units — a genome whose abundance share is below one pair, or --num-reads 1 — writes nothing and
+    the run goes on to the next genome, as the reference's loop does (simulate.rs:179: num_reads / 2 pairs)."""
+    from simmr_amd import CustomShortErrorProfile
+    from simmr_amd.profiles import CustomAbundanceProfile
+    from tests import _model
+    d, genomes = workdir
+    blob = _model.synthetic_short_model()
+    (d / "model0.bin").write_bytes(blob)
+    # genome A gets one read = no pair, genome B everything else (custom-short plans genome by genome)
+    (d / "skew.tsv").write_text("path\tid\tabundance\n" + f"{d}/g0.fna\tgA\t0.001\n{d}/g1.fna\tgB\t0.999\n")
+    counts = [n for n, _ in CustomAbundanceProfile([0.001, 0.999]).determine_abundances(600, 2)]
+    assert counts[0] == 1
+    fmt = "@{:read_id:}/{:pair:} {:genome_id:} sp={:start_position:}"
+    out = d / "skew.fq"
+    subprocess.check_call([str(EXE), "--genome-file", str(d / "skew.tsv"), "--output", str(out), "--num-reads", "600", "--seed", "5",
+                           "--error-profile", "custom-short", "--custom-profile", str(d / "model0.bin"),
+                           "--abundance-profile", "custom", "--read-header-format", fmt])
+    contigs, names = genomes[1]
+    o = _oracle.simulate_pe(oracle, _oracle.HostGenome(contigs), CustomShortErrorProfile(blob).pod(), counts[1], 5, qual_offset=33)
+    assert out.read_bytes() == fastq_of(o.trimmed(), o.n_reads, names, "gB", True, fmt=fmt)
+    # and a whole run without a pair
+    for profile in ("perfect-short", "minimal-short"):
+        one = d / f"one_{profile}.fq"
+        r = subprocess.run([str(EXE), "--genome", str(d / "g1.fna"), "--output", str(one), "--num-reads", "1", "--seed", "5",
+                            "--error-profile", profile], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert not one.exists() or one.stat().st_size == 0
