@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
                     help="cpu_baseline sample of the paired-end profiles (default 20 M reads, 400 000 for custom-short)")
     ap.add_argument("--cpu-sample-long-reads", type=int, default=None,
-                    help="cpu_baseline sample of the long-read profiles (BASELINE.md B4; default 100 000 reads, 1000 for custom-long)")
+                    help="cpu_baseline sample of the long-read profiles (BASELINE.md B4; default 400 000 reads, 1000 for custom-long)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only for rehearsing N>1 on a single GPU (all ranks then share --rehearse-device)")
     ap.add_argument("--rehearse-device", type=int, default=None)
@@ -577,7 +577,7 @@ def cpu_baseline_long(args, prof):
     # sized for about 10-30 s of CPU work in all: the model's k-mer splice builds an alias table per visited k-mer
     # (custom_short.rs:497-500), which makes a custom long read cost 0.2 s on one thread
     custom = args.profile == "custom-long"
-    n = min(args.cpu_sample_long_reads or (1000 if custom else 100_000), total_reads)
+    n = min(args.cpu_sample_long_reads or (1000 if custom else 400_000), total_reads)
     n1 = max(n // (16 if custom else 8), 1)
     t1, _ = timed(n1, 1)
     tn, o = timed(n, cores)

@@ -62,13 +62,21 @@ enum simmr_profile_kind {
  *   by PCG32 seed expansion) consumed exactly as simulate.rs / the profiles
  *   consume them.  Output is bit-identical to the reference for everything the
  *   reference itself makes deterministic under --seed.
- * PHILOX: counter-based Philox4x32-10 keyed by the read's Phred seed, counter
- *   = base index / 4, one output word per base; that word draws (Phred,
- *   substitution) from their joint law with one alias-table lookup (the law
- *   is stated in DESIGN.md section 4 and restated in oracle/philox.c); every
- *   profile with per-base draws except the custom ones.
- *   Positions, lengths and seeds still come from the reference streams.
- *   Statistical tolerance only (BASELINE.json north_star). */
+ * PHILOX: counter-based Philox4x32-10 (Random123 constants) keyed by the read's Phred seed (key = its low and high
+ *   words).  Specification, version 3 — stated in DESIGN.md section 4, restated independently in oracle/philox.c, which
+ *   the kernels are compared with bit for bit:
+ *     a base draws its Phred score q and its substitution s (0 = none, 1..3 = "ACGT"[(code + s) & 3]) TOGETHER from
+ *     their joint law over the 1024 outcomes o = q | s << 8;
+ *     level 1: 24 bits per base.  The 16 bases of group g = b >> 4 share the 384 bits of the three calls with counters
+ *       (3g + {0, 1, 2}, 0, 0x73696D6D, 0x72000003) ('simm', 'r', version 3); base b takes bits [24 (b & 15), +24) = F;
+ *       column F >> 14 of a 1024-column alias table (integer Vose construction over the 2^24 cells), fraction
+ *       F & 0x3fff against the column's threshold in 16384ths;
+ *     level 2, only for the E of 2^24 cells (E = 118 at mean Phred 30) that the integer split leaves over: counter
+ *       (b >> 2, 1, 0x73696D6D, 0x72000003), word b & 3, a 1024-column alias table over the residual law with 22-bit
+ *       thresholds.
+ *   Every profile with per-base draws except the custom ones.  Positions, lengths and seeds still come from the
+ *   reference's streams.  Statistical tolerance only (BASELINE.json north_star): the law is the reference's
+ *   (minimal_short.rs:83-140), the bits are not. */
 enum simmr_rng_mode { SIMMR_RNG_REFERENCE = 0, SIMMR_RNG_PHILOX = 1 };
 
 /* Long-read length policy (Appendix A Q5 of SURVEY.md).
@@ -161,19 +169,21 @@ typedef struct simmr_reads_out {
  * below is "the" reference layout).
  * compact (default): read r's bases are seq[seq_off[r] .. seq_off[r+1]) and its qualities the same bytes of qual[]:
  *   two byte streams without gaps.
- * SIMMR_SLOT16 (opt-in, simmr_engine_set_read_slots(e, 16) before the plan call): every read owns a slot of
- *   ceil(L / 16) * 16 bytes that starts on a 16-byte boundary of both streams (total_bases counts the slots), so that the
- *   counter-mode emit kernel writes nothing but whole aligned 16-byte groups (no byte-granular stores at the reads'
- *   ends: 12.0 instead of 12.9 ms per 100 M reads).  Qualities are left-aligned in the slot.
+ * SIMMR_SLOT16 (simmr_engine_set_read_slots(e, 16) before the plan call; what INTEGRATION.md's call sequence, the Python
+ *   host and simmr-hip select): every read owns a slot of ceil(L / 16) * 16 bytes that starts on a 16-byte boundary of
+ *   both streams (total_bases counts the slots), so that the counter-mode emit kernel writes nothing but whole aligned
+ *   16-byte groups — no byte-granular stores at the reads' ends.  Qualities are left-aligned in the slot.
  *   Bases are left-aligned too, except for a reverse-complemented mate (SIMMR_FLAG_REVCOMP), whose bases are written
  *   back to front and therefore RIGHT-aligned: its 16-base draw groups then land on aligned 16 bytes as well.
  *     seq_off[r]         = first base of read r in seq[]   (for a reverse-complemented mate not a multiple of 16)
  *     seq_off[r] & ~15   = first quality of read r in qual[]
  *     L(r)               = |end[r] - start[r]|   (seq_off[r+1] - seq_off[r] is NOT the length in this layout)
  *     seq_off[n_reads]   = total_bases
- *   Padding bytes are written as 0 in both streams.  Offered by the kernels that gain from it — SIMMR_RNG_PHILOX with
- *   minimal-short, minimal-long and perfect-long profiles; a plan call for any other profile answers SIMMR_ENOTSUP
- *   while the engine is set to slots.  simmr_fastq_plan / simmr_fastq_emit read either layout. */
+ *   Padding bytes are written as 0 in both streams.  The setting is a preference: the kernels that gain from slots write
+ *   them — SIMMR_RNG_PHILOX with the minimal-short, minimal-long and perfect-long profiles — and a plan for any other
+ *   profile is made for the compact layout.  simmr_plan_info.slot_bytes says which one a plan got; size the buffers
+ *   from total_bases of the same info and pass that slot_bytes on in simmr_reads_out.  simmr_fastq_plan /
+ *   simmr_fastq_emit read either layout. */
 #define SIMMR_SLOT16 16u
 
 /* Device-side counters a run accumulates (reduced across GPUs by the caller
@@ -203,7 +213,8 @@ const char* simmr_last_error(const simmr_engine* e);
 /* All work is enqueued on this hipStream_t (default: the null stream). */
 int simmr_engine_set_stream(simmr_engine* e, void* hip_stream);
 /* Layout of the reads that plans made FROM NOW ON will emit: 0 (or 1) = compact, SIMMR_SLOT16 = 16-byte read slots
- * (see simmr_reads_out).  Anything else: SIMMR_EINVAL.  The plan in force keeps the layout it was made with. */
+ * wherever the plan's emit kernel writes them (see simmr_reads_out; simmr_plan_info.slot_bytes reports what a plan
+ * got).  Anything else: SIMMR_EINVAL.  The plan in force keeps the layout it was made with. */
 int simmr_engine_set_read_slots(simmr_engine* e, uint32_t slot_bytes);
 
 /* ---- reference staging -------------------------------------------------- */

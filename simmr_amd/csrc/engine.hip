@@ -20,7 +20,9 @@
 #include <vector>
 
 #include "kernels.hip"
+#if defined(SIMMR_VARIANTS)  /* `make extras`: forms that were measured and lost, kept buildable for their tests (LAB.md) */
 #include "emit_tile.hip"
+#endif
 #include "fastq_kernels.hip"
 #include "custom_model.hpp"
 
@@ -86,7 +88,6 @@ struct simmr_engine {
   DevBuf w_bytes, u_off64, fq_off64;
   uint32_t splice_lds_set[2] = {0, 0};  // dynamic-LDS limit already set on this device for k_custom_long_splice<exc, fast>
   bool fq_coarse = false;  // the direct FASTQ plan in force has fq_off64 (first byte of every 64th record) instead of fq_off
-  bool fine_offsets = false;  // SIMMR_FINE_OFFSETS=1: per-pair offsets for the counter-mode kernel too (A/B timing)
   bool plan_paired = false;
   bool plan_multi = false;    // paired-end plan over several genomes (u_genome per pair)
   bool plan_any_exc = false;  // some genome of the plan has an exception plane
@@ -94,7 +95,7 @@ struct simmr_engine {
   DevBuf u_contig, u_genome, u_seed, u_len, u_a, u_b, u_qs2, u_ms2, u_flags, u_off;
   DevBuf scan_tmp, u_order, len_hist;
   bool plan_sorted = false;
-  int emit_variant = 0;  // 0 = lane-per-read kernel for short reads, 1 = wave-per-unit kernel
+  int emit_variant = 0;  // 0 = lane-per-read kernel for short reads; 1 = wave-per-unit kernel (SIMMR_VARIANTS builds only)
   // measurement knobs, read ONCE when the engine is made (a stray variable cannot change a running engine's launches)
   int philox_form = 1;          // SIMMR_PHILOX_FORM: 1 = the item kernel (default), 2 = the tile kernel where it applies (emit_tile.hip; measured slower: profiles/r3/tile_form_*)
   uint32_t philox_wgs_per_cu = 128;  // SIMMR_PHILOX_WGS_PER_CU (item kernel), clamped to 1..4096.  More workgroups than the 4 per CU that
@@ -109,7 +110,6 @@ struct simmr_engine {
   uint32_t tile_cap = 0;        // SIMMR_TILE_CAP: bytes per LDS tile (0 = from the profile's read length)
   uint32_t tile_wgs_per_cu = 0; // SIMMR_TILE_WGS_PER_CU: 0 = what fits
   int splice_variant = 0;       // SIMMR_SPLICE_VARIANT: 1 = the two-load splice kernel on every model
-  int fastq_headers_form = 0;   // SIMMR_FASTQ_HEADERS: 0 = simmr_emit_fastq's emit kernel writes the headers, 1 = k_fastq_headers does
   bool plan_tile_ok = false;    // the current paired plan has no read longer than TILE_MAXL
   // outer-stream scratch
   DevBuf o_last_idx, o_wg_sums, o_wg_prefix, o_result;
@@ -722,14 +722,11 @@ int read_err_word(simmr_engine* e, uint32_t* w) {
 }
 
 // The layout a plan for `prof` gets (simmr_engine_set_read_slots): *round = 15 for 16-byte read slots, else 0.  Slots
-// are written by the counter-mode item kernel (k_emit_philox) only.
+// are a preference: the counter-mode item kernel (k_emit_philox) writes them; a plan whose emit kernel does not gets the
+// compact layout and says so in simmr_plan_info.slot_bytes, which is what the caller sizes and labels its buffers from.
 int plan_slot_round(simmr_engine* e, const ProfileDev& prof, uint32_t* round) {
-  *round = 0;
-  if (e->read_slots != SIMMR_SLOT16) return SIMMR_OK;
-  if (prof.kind == SIMMR_K_CUSTOM || prof.kind == SIMMR_K_PERFECT_SHORT || prof.rng_mode != SIMMR_RNG_PHILOX)
-    return e->fail(SIMMR_ENOTSUP, "16-byte read slots are written in SIMMR_RNG_PHILOX mode by the minimal and perfect-long profiles only "
-                                  "(simmr_engine_set_read_slots(e, 0) for the compact layout)");
-  *round = 15;
+  const bool offered = !(prof.kind == SIMMR_K_CUSTOM || prof.kind == SIMMR_K_PERFECT_SHORT || prof.rng_mode != SIMMR_RNG_PHILOX);
+  *round = (e->read_slots == SIMMR_SLOT16 && offered) ? 15u : 0u;
   return SIMMR_OK;
 }
 
@@ -750,8 +747,7 @@ int launch_plan_pe(simmr_engine* e, const ProfileDev& prof, uint32_t genome, uin
 }
 
 bool plan_is_coarse(simmr_engine* e, const ProfileDev& prof) {
-  return prof.rng_mode == SIMMR_RNG_PHILOX && prof.kind != SIMMR_K_CUSTOM && prof.kind != SIMMR_K_PERFECT_SHORT && e->philox_form != 2 &&
-         !e->fine_offsets;
+  return prof.rng_mode == SIMMR_RNG_PHILOX && prof.kind != SIMMR_K_CUSTOM && prof.kind != SIMMR_K_PERFECT_SHORT && e->philox_form != 2;
 }
 
 int check_out(simmr_engine* e, const simmr_reads_out* out, uint64_t n_reads, uint64_t total) {
@@ -780,19 +776,31 @@ OutCols out_cols(const simmr_reads_out* out) {
 
 // the instantiation of the counter-mode item kernel for (exception plane, contig bases in LDS, escapes noticed through
 // the quality byte, 16-byte read slots, block offsets from the coarse scan)
+// Paired plans are coarse (the block places its reads) and may keep their contig bases in LDS; long-read plans have
+// per-read offsets and never do.  The flag-bit form (ESCQ = false: some offset-encoded level-1 answer is above 127, i.e. a
+// mean Phred far above what the profiles of the reference use) exists in its most general shape only — with the
+// exception plane, without the contig cache — which serves every plan.  16 instantiations (tests/test_resource_guard.py).
 using PhiloxKernel = decltype(&k_emit_philox<false, false, false, false, false, false, false>);
-template <bool EXC, bool CACHED, bool ESCQ>
-static PhiloxKernel philox_kernel3(bool slot, bool coarse) {
-  return slot ? (coarse ? k_emit_philox<EXC, false, CACHED, false, ESCQ, true, true> : k_emit_philox<EXC, false, CACHED, false, ESCQ, true, false>)
-              : (coarse ? k_emit_philox<EXC, false, CACHED, false, ESCQ, false, true> : k_emit_philox<EXC, false, CACHED, false, ESCQ, false, false>);
+template <bool EXC, bool CACHED, bool ESCQ, bool COARSE>
+static PhiloxKernel philox_kernel2(bool slot) {
+  return slot ? k_emit_philox<EXC, false, CACHED, false, ESCQ, true, COARSE> : k_emit_philox<EXC, false, CACHED, false, ESCQ, false, COARSE>;
 }
 static PhiloxKernel philox_kernel(bool exc, bool cached, bool escq, bool slot, bool coarse) {
-  if (exc) return cached ? (escq ? philox_kernel3<true, true, true>(slot, coarse) : philox_kernel3<true, true, false>(slot, coarse))
-                         : (escq ? philox_kernel3<true, false, true>(slot, coarse) : philox_kernel3<true, false, false>(slot, coarse));
-  return cached ? (escq ? philox_kernel3<false, true, true>(slot, coarse) : philox_kernel3<false, true, false>(slot, coarse))
-                : (escq ? philox_kernel3<false, false, true>(slot, coarse) : philox_kernel3<false, false, false>(slot, coarse));
+  if (!escq) return coarse ? philox_kernel2<true, false, false, true>(slot) : philox_kernel2<true, false, false, false>(slot);
+  if (!coarse) return exc ? philox_kernel2<true, false, true, false>(slot) : philox_kernel2<false, false, true, false>(slot);
+  if (exc) return cached ? philox_kernel2<true, true, true, true>(slot) : philox_kernel2<true, false, true, true>(slot);
+  return cached ? philox_kernel2<false, true, true, true>(slot) : philox_kernel2<false, false, true, true>(slot);
+}
+// the same for the TEXT form (simmr_emit_fastq): always coarse; `copy_only` = perfect-short (no draws)
+static PhiloxKernel philox_text_kernel(bool exc, bool cached, bool escq, bool copy_only) {
+  if (copy_only) return cached ? (exc ? k_emit_philox<true, true, true, true, false, false, true> : k_emit_philox<false, true, true, true, false, false, true>)
+                               : (exc ? k_emit_philox<true, true, false, true, false, false, true> : k_emit_philox<false, true, false, true, false, false, true>);
+  if (!escq) return k_emit_philox<true, false, false, true, false, false, true>;
+  return cached ? (exc ? k_emit_philox<true, false, true, true, true, false, true> : k_emit_philox<false, false, true, true, true, false, true>)
+                : (exc ? k_emit_philox<true, false, false, true, true, false, true> : k_emit_philox<false, false, false, true, true, false, true>);
 }
 
+#if defined(SIMMR_VARIANTS)
 int stream_grid(simmr_engine* e, uint64_t n_units) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_emit_stream, 64, 0) != hipSuccess || per_cu < 1)
@@ -802,6 +810,7 @@ int stream_grid(simmr_engine* e, uint64_t n_units) {
   if (g == 0) g = 1;
   return (int)g;
 }
+#endif
 
 }  // namespace
 
@@ -845,19 +854,21 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
   simmr_engine* e = new simmr_engine();
   e->device = device_ordinal;
   e->n_cu = prop.multiProcessorCount;
+  // Four measurement knobs, read once here (the defaults are what the sweeps of LAB.md found); a `make extras` build
+  // reads the ones of its extra kernels as well.
+#if defined(SIMMR_VARIANTS)
   if (const char* v = getenv("SIMMR_EMIT_VARIANT")) e->emit_variant = atoi(v);
   if (const char* v = getenv("SIMMR_PHILOX_FORM")) e->philox_form = atoi(v);
+  if (const char* v = getenv("SIMMR_TILE_UPB")) e->tile_upb = (uint32_t)std::min<unsigned long long>(32, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
+  if (const char* v = getenv("SIMMR_TILE_CAP")) e->tile_cap = (uint32_t)std::min<unsigned long long>(16384, strtoull(v, nullptr, 10)) & ~15u;
+  if (const char* v = getenv("SIMMR_TILE_WGS_PER_CU")) e->tile_wgs_per_cu = (uint32_t)std::min<unsigned long long>(16, strtoull(v, nullptr, 10));
+#endif
   if (const char* v = getenv("SIMMR_GRID_MULT"))
     e->lanes_mult = e->perfect_mult = e->custom_pe_mult = e->custom_long_mult = e->fastq_mult =
         (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_FASTQ_GRID_MULT")) e->fastq_mult = (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_PHILOX_WGS_PER_CU")) e->philox_wgs_per_cu = (uint32_t)std::min<unsigned long long>(4096, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
-  if (const char* v = getenv("SIMMR_TILE_UPB")) e->tile_upb = (uint32_t)std::min<unsigned long long>(32, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
-  if (const char* v = getenv("SIMMR_TILE_CAP")) e->tile_cap = (uint32_t)std::min<unsigned long long>(16384, strtoull(v, nullptr, 10)) & ~15u;
-  if (const char* v = getenv("SIMMR_TILE_WGS_PER_CU")) e->tile_wgs_per_cu = (uint32_t)std::min<unsigned long long>(16, strtoull(v, nullptr, 10));
   if (const char* v = getenv("SIMMR_SPLICE_VARIANT")) e->splice_variant = atoi(v);
-  if (const char* v = getenv("SIMMR_FASTQ_HEADERS")) e->fastq_headers_form = atoi(v);
-  if (const char* v = getenv("SIMMR_FINE_OFFSETS")) e->fine_offsets = atoi(v) != 0;
   bool ok = e->d_tables.ensure(sizeof(Tables)) && e->d_counters.ensure(8 * SIMMR_N_COUNTERS * (1 + SIMMR_CNT_SHARDS)) &&
             e->d_err.ensure(64) && e->d_scalars.ensure(256);
   ok = ok && hipEventCreate(&e->ev_a) == hipSuccess && hipEventCreate(&e->ev_b) == hipSuccess &&
@@ -1485,6 +1496,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       // pairs of one genome with few contigs: the contig bases live in LDS (no dependent load per record)
       const bool cached = paired && !e->plan_multi && e->plan_genome < e->genomes.size() &&
                           e->genomes[e->plan_genome].contigs.size() <= PHILOX_CBASE;
+#if defined(SIMMR_VARIANTS)
       if (paired && e->plan_tile_ok && e->philox_form == 2 && !e->plan_slot) {
         // tile form (emit_tile.hip): the block's piece of both streams is built in LDS and flushed in whole lines
         const uint32_t upb = e->tile_upb;  // (1..32: one lane of the prologue wave per read)
@@ -1514,13 +1526,15 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
           (void)hipMemcpyToSymbol(HIP_SYMBOL(tile_diag), z, sizeof z);
         }
 #endif
-      } else {
+      } else
+#endif
+      {
         const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * e->philox_wgs_per_cu);
         // an escaped base is noticed through its quality byte when no real one has bit 7 set (kernels.hip: esc_q)
         bool escq = (out->qual_offset & 0xffu) + e->prof.philox_qmax1 <= 127u;
 #if defined(SIMMR_NO_ESCQ)
-        escq = false;  // measurement build: the flag-bit form on every input
+        escq = false;  // test build: the flag-bit form on every input
 #endif
         const bool coarse = paired && e->plan_coarse;
         auto kern = philox_kernel(exc, cached, escq, e->plan_slot != 0, coarse);
@@ -1528,7 +1542,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                            e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(),
                            e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), out->seq, out->qual,
                            out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters,
-                           (const uint64_t*)nullptr, (const uint8_t*)nullptr, (const FqTemplate*)nullptr, FqTables{}, 0u, 0u, 0u,
+                           (const uint8_t*)nullptr, (const FqTemplate*)nullptr, FqTables{}, 0u, 0u, 0u,
                            coarse ? (const uint64_t*)e->u_off64.as<uint64_t>() : (const uint64_t*)nullptr);
       }
     } else if (e->prof.kind == SIMMR_K_CUSTOM && !paired) {
@@ -1578,9 +1592,9 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       hipLaunchKernelGGL(copy, dim3(cgrid), dim3(256), 0, e->stream, e->prof, 1u, e->d_genomes.as<GenomeDev>(),
                          e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(),
                          (const uint32_t*)nullptr, e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset,
-                         e->plan_first, read_id_base, out_cols(out), counters, (const uint64_t*)nullptr, (const uint8_t*)nullptr,
+                         e->plan_first, read_id_base, out_cols(out), counters, (const uint8_t*)nullptr,
                          (const FqTemplate*)nullptr, FqTables{}, 0u, 0u, 0u, (const uint64_t*)nullptr);
-    } else if (e->emit_variant == 0) {
+    } else if (e->emit_variant == 0) {  // (always, outside SIMMR_VARIANTS builds)
       // lane-per-read kernel: template on (exception plane present, paired, perfect-long Phred)
       bool exc = false;
       if (paired) exc = e->plan_any_exc;
@@ -1603,11 +1617,13 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(),
                          out->seq, out->qual, out->qual_offset, e->d_tables.as<Tables>(), counters);
     } else {
+#if defined(SIMMR_VARIANTS)
       hipLaunchKernelGGL(k_emit_stream, dim3(stream_grid(e, n_units)), dim3(64), 0, e->stream, e->prof,
                          paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl,
                          e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome,
                          e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset,
                          e->d_tables.as<Tables>(), counters);
+#endif
     }
   }
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
@@ -2029,7 +2045,7 @@ int simmr_fastq_plan_direct(simmr_engine* e, const char* header_format, const si
   const FqTables tb = fq_tables(e, n_slots);
   // When the emit kernel writes into the text and formats the headers itself it also places its own records: it asks for
   // the first byte of every 64th record only (fq_off64, the scan of the size kernel's per-wave sums), not for fq_off.
-  const bool coarse = fq_direct_kernel(e) && e->fastq_headers_form == 0 && !e->fine_offsets;
+  const bool coarse = fq_direct_kernel(e);
   const uint64_t n_w = (n_reads + 63) / 64;
   unsigned long long* tiles = coarse ? nullptr : tile_sums_begin(e, n_reads);
   if (!coarse && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
@@ -2120,52 +2136,18 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
 #if defined(SIMMR_NO_ESCQ)
     escq = false;
 #endif
-    auto kern = escq ? (cached ? (exc ? k_emit_philox<true, false, true, true, true> : k_emit_philox<false, false, true, true, true>)
-                               : (exc ? k_emit_philox<true, false, false, true, true> : k_emit_philox<false, false, false, true, true>))
-                     : (cached ? (exc ? k_emit_philox<true, false, true, true> : k_emit_philox<false, false, true, true>)
-                               : (exc ? k_emit_philox<true, false, false, true> : k_emit_philox<false, false, false, true>));
-    if (e->fq_coarse)  // the kernel places its own records (fq_off64)
-      kern = escq ? (cached ? (exc ? k_emit_philox<true, false, true, true, true, false, true> : k_emit_philox<false, false, true, true, true, false, true>)
-                            : (exc ? k_emit_philox<true, false, false, true, true, false, true> : k_emit_philox<false, false, false, true, true, false, true>))
-                  : (cached ? (exc ? k_emit_philox<true, false, true, true, false, false, true> : k_emit_philox<false, false, true, true, false, false, true>)
-                            : (exc ? k_emit_philox<true, false, false, true, false, false, true> : k_emit_philox<false, false, false, true, false, false, true>));
-    if (e->prof.kind == SIMMR_K_PERFECT_SHORT) {  // the copy-only form: bases of the plan, every quality 60
-      kern = e->fq_coarse ? (cached ? (exc ? k_emit_philox<true, true, true, true, false, false, true> : k_emit_philox<false, true, true, true, false, false, true>)
-                                    : (exc ? k_emit_philox<true, true, false, true, false, false, true> : k_emit_philox<false, true, false, true, false, false, true>))
-                          : (cached ? (exc ? k_emit_philox<true, true, true, true> : k_emit_philox<false, true, true, true>)
-                                    : (exc ? k_emit_philox<true, true, false, true> : k_emit_philox<false, true, false, true>));
-    }
+    auto kern = philox_text_kernel(exc, cached, escq, e->prof.kind == SIMMR_K_PERFECT_SHORT);  // (perfect-short: bases of the plan, every quality 60)
     // windows per run: the power of two that covers the longest run ('\n' + header + '\n'), at most 32 (512 bytes)
     uint32_t wshift = 0;
     while ((16u << wshift) < e->fq_maxhdr + 2u) wshift++;
-    const bool own_headers = e->fastq_headers_form == 0;  // the emit kernel writes the headers itself
-#if FQ_OVERLAP
-    const uint32_t slots_lds = own_headers ? FQ_WAVE * e->fq_hpitch : 0u;  // one wave's headers at a time
-#else
-    const uint32_t slots_lds = std::max<uint32_t>(PHILOX_MAP_ITEMS, own_headers ? FQ_GROUP * e->fq_hpitch : 0u);  // (the item map lives there too)
-#endif
+    const uint32_t slots_lds = std::max<uint32_t>(PHILOX_MAP_ITEMS, FQ_GROUP * e->fq_hpitch);  // header slots; the item map lives there too
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), slots_lds, e->stream, e->prof, paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(),
                        e->plan_genome, n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome,
                        e->u_seed.as<uint64_t>(), dst, dst, 33u, e->plan_first, e->fq_read_id_base, OutCols{}, counters,
-                       e->fq_off.as<uint64_t>(), e->fq_hlen.as<uint8_t>(),
-                       own_headers ? e->fq_tpl_dev.as<FqTemplate>() : (const FqTemplate*)nullptr, tb, e->fq_lit_bytes, e->fq_hpitch, wshift,
-                       e->fq_coarse ? (const uint64_t*)e->fq_off64.as<uint64_t>() : (const uint64_t*)nullptr);
+                       e->fq_hlen.as<uint8_t>(), e->fq_tpl_dev.as<FqTemplate>(), tb, e->fq_lit_bytes, e->fq_hpitch, wshift,
+                       (const uint64_t*)e->fq_off64.as<uint64_t>());
   }
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
-  if (e->fastq_headers_form != 0) {  // SIMMR_FASTQ_HEADERS=1: headers by a kernel of their own (measurement)
-    const uint64_t n_batches = (n_reads + FQH_BATCH - 1) / FQH_BATCH;
-    const uint32_t hdr_lds = 4 * FQH_BATCH * e->fq_hpitch;
-    if (hdr_lds > 48 * 1024)
-      HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fastq_headers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_lds));
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fastq_headers, 256, hdr_lds) != hipSuccess || per_cu < 1) per_cu = 4;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_batches + 3) / 4, (uint64_t)e->n_cu * (uint64_t)per_cu * 2);
-    // windows per run: the power of two that covers the longest run ('\n' + header + '\n'), at most 16 (256 bytes)
-    uint32_t wshift = 0;
-    while ((16u << wshift) < e->fq_maxhdr + 2u) wshift++;
-    hipLaunchKernelGGL(k_fastq_headers, dim3(grid), dim3(256), hdr_lds, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, fq_plan_view(e), n_reads,
-                       e->fq_lit_bytes, e->fq_hpitch, wshift, e->fq_off.as<uint64_t>(), dst);
-  }
   hipError_t s = hipGetLastError();
   if (s != hipSuccess) return e->fail(SIMMR_ENODEV, "fastq launch failed: %s", hipGetErrorString(s));
   return SIMMR_OK;

@@ -51,7 +51,7 @@ k_fastq_size_plan(const FqTemplate* __restrict__ tp, FqTables tb, FqPlan pn, uin
   FqFields f{};
   if (on) { f = fq_fields(pn, r); h = fq_header_len(tp, tb, f); }
   const bool bad = h >= FQ_HMAX;  // (also a genome / contig without a name)
-  uint32_t wmax = bad ? 0u : h;  // the longest header sizes the LDS slots of k_fastq_headers: one atomic per wave
+  uint32_t wmax = bad ? 0u : h;  // the longest header sizes the LDS slots of the emit kernel's header phase: one atomic per wave
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d, 64); wmax = o > wmax ? o : wmax; }
   if ((threadIdx.x & 63u) == 0 && wmax > *(volatile uint32_t*)(err + 1)) atomicMax(err + 1, wmax);  // (rarely: see k_fastq_size)
@@ -201,77 +201,6 @@ k_fastq_write(const FqTemplate* __restrict__ tp, FqTables tb, FqReads rd, uint64
           for (uint32_t j = 0; j < R.L; j++) recC[j] = rd.qual[(rd.slot16 ? (R.so & ~15ull) : R.so) + j];
           recC[R.L] = '\n';
         }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();  // the next batch overwrites the LDS slots
-  }
-}
-
-// Headers and line ends of a text whose bases and qualities the emit kernel writes itself (simmr_emit_fastq).  The
-// run of read r is the '\n' that ends record r - 1, the header, and its '\n' — so the only bytes of a record no 16-byte
-// window of some run covers are "\n+\n" (written by the emit kernel's lane that holds the read's first qualities) and
-// the last record's final '\n'.  A read without bases has no such lane: its "\n+\n" is written here.
-#define FQH_BATCH 64u /* headers per wave and step (32, for twice the waves per CU, measured no faster: 10.7 vs 10.0 ms) */
-extern "C" __global__ void __launch_bounds__(256)
-k_fastq_headers(const FqTemplate* __restrict__ tp, FqTables tb, FqPlan pn, uint64_t n_reads, uint32_t lit_bytes, uint32_t hpitch,
-                uint32_t wshift, const uint64_t* __restrict__ rec_off, uint8_t* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t hdr_all[];  // [4 waves][FQH_BATCH][hpitch]
-  __shared__ __attribute__((aligned(16))) uint8_t lit[FQ_LIT_MAX + 8];
-  __shared__ uint64_t run_at[4][FQH_BATCH];     // where the run starts in the output
-  __shared__ uint32_t run_len[4][FQH_BATCH];
-  __shared__ FqSeg segs[FQ_MAX_SEGS];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint8_t* hdr = hdr_all + (size_t)wave * FQH_BATCH * hpitch;
-  for (uint32_t i = threadIdx.x; i < lit_bytes; i += 256) lit[i] = tb.blob[i];
-  const uint32_t n_segs = fq_stage_template(tp, segs);
-  __syncthreads();
-  const uint64_t n_batches = (n_reads + FQH_BATCH - 1) / FQH_BATCH;
-  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + wave, n_waves = (uint64_t)gridDim.x * 4;
-  for (uint64_t batch = wave_id; batch < n_batches; batch += n_waves) {
-    const uint64_t r0 = batch * FQH_BATCH;
-    const uint32_t nb = (n_reads - r0) < FQH_BATCH ? (uint32_t)(n_reads - r0) : FQH_BATCH;
-    if (lane < nb) {
-      const uint64_t r = r0 + lane;
-      uint8_t* h = hdr + lane * hpitch;
-      const FqFields f = fq_fields(pn, r);
-      const uint32_t lead = r > 0 ? 1u : 0u;
-      h[0] = '\n';  // ends record r - 1
-#if defined(FQH_ABLATE_FORMAT)
-      uint32_t at = lead + fq_header_len_lds(segs, n_segs, tb, f);  // timing only: the slot keeps whatever it held
-#else
-      uint32_t at = fq_format_header(h, lead, segs, n_segs, tb, lit, f, (pn.paired && (r & 1u)) ? '2' : '1');
-#endif
-      h[at++] = '\n';
-      const uint64_t rec = rec_off[r];
-      run_at[wave][lane] = rec - lead;
-      run_len[wave][lane] = at;
-      if (f.L == 0) { uint8_t* p = out + rec + (at - lead); p[0] = '\n'; p[1] = '+'; p[2] = '\n'; }
-      if (r + 1 == n_reads) out[rec_off[n_reads] - 1] = '\n';
-    }
-    // Windows: every run of the batch gets the same number of 16-byte windows, W = a power of two that covers the
-    // longest header (`wshift` from the host), so lane -> (run, window) is a shift and a mask: no search, no prefix; the
-    // lanes whose window lies past their run's end idle.  64 >> wshift runs per step.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS only: s_waitcnt 0 would also wait for the previous batch's stores to be acknowledged)
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t per_step = 64u >> wshift, piece = lane & ((1u << wshift) - 1u);
-    for (uint32_t i0 = 0; i0 < nb; i0 += per_step) {
-      const uint32_t i = i0 + (lane >> wshift);
-      if (i >= nb) continue;
-      const uint32_t n = run_len[wave][i];
-      uint8_t* dst = out + run_at[wave][i];
-      const uint8_t* src = hdr + i * hpitch;
-      if (n >= 16u) {  // the last window ends where the run ends (it overlaps its neighbour with the same bytes)
-        if (piece * 16u < n) {
-          const uint32_t w = (piece + 1u) * 16u <= n ? piece * 16u : n - 16u;
-#if defined(FQH_ABLATE_STORES)
-          const u32x4 val = *reinterpret_cast<const u32x4_unaligned*>(src + w);
-          asm volatile("" :: "v"(val), "v"(dst));  // timing only
-#else
-          *reinterpret_cast<u32x4_unaligned*>(dst + w) = *reinterpret_cast<const u32x4_unaligned*>(src + w);
-#endif
-        }
-      } else if (piece == 0u) {
-        for (uint32_t j = 0; j < n; j++) dst[j] = src[j];
       }
     }
     __builtin_amdgcn_wave_barrier();  // the next batch overwrites the LDS slots

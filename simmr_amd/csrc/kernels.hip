@@ -1421,6 +1421,7 @@ SIMMR_DEV void load_codes(const GenomeDev& G, uint64_t pos0, uint32_t nb, uint8_
   }
 }
 
+#if defined(SIMMR_VARIANTS)  /* the first-generation wave-per-unit kernel: only in `make extras` builds (SIMMR_EMIT_VARIANT=1), as an independently written cross-check */
 extern "C" __global__ void __launch_bounds__(64)
 k_emit_stream(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes,
               uint32_t genome_const, uint64_t n_units, PlanArrays pl,
@@ -1524,6 +1525,7 @@ k_emit_stream(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     shard_add(counters, SIMMR_CNT_QUAL_SUM, (unsigned long long)qsum);
   }
 }
+#endif  // SIMMR_VARIANTS
 
 // ===========================================================================
 // 8. Emit, lane-per-read form (the fast path for short reads)
@@ -2054,16 +2056,7 @@ SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1,
 #define PHILOX_READS 256u  /* 128 pairs x 2 mates */
 #define PHILOX_MAP_ITEMS 4096u
 #define PHILOX_CBASE 64u /* contig bases kept in LDS by the CACHED kernels */
-#ifndef FQ_GROUP
-#define FQ_GROUP 128u /* TEXT, phase form: headers formatted at a time (LDS slots; they share their memory with the item map, see `owner`) */
-#endif
-#ifndef FQ_OVERLAP
-#define FQ_OVERLAP 0 /* TEXT: 0 = a block's headers are formatted in phases of their own (FQ_GROUP at a time); 1 = wave by wave in the shadow of
-                        the other waves' items, one barrier per step — bit-identical and no faster (19.6-19.9 vs 19.3-19.7 ms,
-                        profiles/r3/ab_fastq_overlap_vs_phases.log): what the headers cost is their bytes and their formatting, not the waves
-                        that wait meanwhile (the kernel without any header work: 13.8 ms, text_header_probe.log) */
-#endif
-#define FQ_WAVE 64u /* TEXT, overlapped form: one wave's reads = the header slots */
+#define FQ_GROUP 128u /* TEXT: headers formatted at a time (LDS slots; they share their memory with the item map, see `owner`) */
 
 // bytes a + b with per-byte wrap-around (u8 add of util.rs:46-50)
 SIMMR_DEV uint32_t add_bytes(uint32_t a, uint32_t b) {
@@ -2081,31 +2074,8 @@ SIMMR_DEV void store16(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi) {
   if (NT) stream_store(reinterpret_cast<v4u32_unaligned*>(d), (v4u32_unaligned)v);
   else *reinterpret_cast<v4u32_unaligned*>(d) = v;
 }
-// Measurement builds (-DSIMMR_SLOT_STORE_POLICY=n): the slot layout's 16-byte stores with other cache-policy bits than
-// the `nt` of __builtin_nontemporal_store (MI355X_MICROARCH.md: plain / sc0 / nt keep the line in the XCD's L2 behind the
-// write, sc1 / sc0 sc1 drop it).  `base` is the block's (wave-uniform) first byte, `off` the lane's offset from it.
-#if defined(SIMMR_SLOT_STORE_POLICY)
-#if SIMMR_SLOT_STORE_POLICY == 1
-#define SLOT_STORE_BITS "sc1"
-#elif SIMMR_SLOT_STORE_POLICY == 2
-#define SLOT_STORE_BITS "sc0 sc1"
-#elif SIMMR_SLOT_STORE_POLICY == 3
-#define SLOT_STORE_BITS "sc1 nt"
-#elif SIMMR_SLOT_STORE_POLICY == 4
-#define SLOT_STORE_BITS "sc0 sc1 nt"
-#elif SIMMR_SLOT_STORE_POLICY == 5
-#define SLOT_STORE_BITS "sc0 nt"
-#else
-#define SLOT_STORE_BITS "nt"
-#endif
-SIMMR_DEV void slot_store16(uint8_t* __restrict__ base, uint32_t off, uint64_t lo, uint64_t hi) {
-  v4u32 v;
-  v.x = (uint32_t)lo; v.y = (uint32_t)(lo >> 32); v.z = (uint32_t)hi; v.w = (uint32_t)(hi >> 32);
-  asm volatile("global_store_dwordx4 %0, %1, %2 " SLOT_STORE_BITS :: "v"(off), "v"(v), "s"(base));
-}
-#else
+// the slot layout's 16-byte stores: nontemporal (other cache-policy bits lose to `nt`: LAB.md, round 3)
 SIMMR_DEV void slot_store16(uint8_t* __restrict__ base, uint32_t off, uint64_t lo, uint64_t hi) { store16<true>(base + off, lo, hi); }
-#endif
 // store the low n (< 16) bytes of the 128-bit value (lo, hi)
 SIMMR_DEV void store_tail(uint8_t* __restrict__ d, uint64_t lo, uint64_t hi, uint32_t n) {
   uint64_t v = lo;
@@ -2220,24 +2190,23 @@ SIMMR_DEV void philox_repair(const uint32_t k0, const uint32_t k1, const uint32_
 // CACHED: every pair comes from one genome (u_genome == null) with at most PHILOX_CBASE contigs, whose bases sit in
 // LDS: a record then needs no load that depends on another load's result.
 // TEXT: bases and qualities go straight into FASTQ text (simmr_emit_fastq; fastq.rs:58-66): `seq` is the text, read rd's
-// record starts at rec_off[rd] with a header of hlen[rd] bytes, so its bases start at rec_off[rd] + hlen[rd] + 1 and its
+// record starts where the block's scan of the record lengths puts it (off64[w] = first byte of record 64 w; a record is
+// header + 1 + L + 3 + L + 1 bytes with a header of hlen[rd] bytes), so its bases start at record + hlen[rd] + 1 and its
 // qualities L + 3 bytes further ("\n+\n"); the lane that holds a read's first qualities also writes those three bytes
 // (one 4-byte store that ends in its own first quality).  The headers are written here as well, block by block: after
 // the prologue the threads that hold the block's reads format them into LDS slots, 128 at a time, and all 256 copy the
 // slots out in 16-byte windows — the run of a read is the '\n' that ends the record before it, its header and the
-// header's '\n' (fq_tp != null; with fq_tp == null the headers are left to k_fastq_headers: the two-kernel form, kept
-// for measurement: 10 ms per 100 M reads against the ~2 ms this costs here).
+// header's '\n'.  TEXT implies COARSE (no per-record offsets exist for it).
 // ESCQ: see `esc_q` below (the host checks the condition: qual_offset + philox_qmax1 <= 127, level-1 answers only:
 // an escaped item is drawn again in full by philox_repair, whatever its level-2 answers are)
 // SLOT: 16-byte read slots (SIMMR_SLOT16, include/simmr_hip.h): every read's place in both streams is ceil(L / 16) * 16
 // bytes on a 16-byte boundary (u_off is the scan of the padded lengths), qualities and forward bases left-aligned, the
 // bases of a reverse-complemented mate right-aligned — so EVERY item, the partial group at a read's end included, is one
 // whole aligned 16-byte store per stream (padding written as 0) and the byte ladder of store_tail2 is gone.
-#if defined(PHILOX_WAVES_PER_SIMD)  /* measurement builds: the register budget of that many waves per SIMD (5: 96 VGPRs, four reloads per block; 12.7 vs 12.1 ms, profiles/r3/ab_slot16_five_waves_per_simd.log) */
-#define PHILOX_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PHILOX_WAVES_PER_SIMD, PHILOX_WAVES_PER_SIMD)))
-#else
-#define PHILOX_OCCUPANCY
-#endif
+// Four waves per SIMD is this kernel's register budget (128 VGPRs): said to the compiler so that no instantiation slips over
+// it unnoticed (round 3's TEXT + COARSE form had: 130 VGPRs, three waves); tests/test_resource_guard.py holds every
+// instantiation to occupancy 4 without scratch.
+#define PHILOX_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4)))
 template <bool HAS_EXC, bool COPY_ONLY, bool CACHED, bool TEXT = false, bool ESCQ = false, bool SLOT = false, bool COARSE = false>
 __global__ void __launch_bounds__(256) PHILOX_OCCUPANCY
 k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes, uint32_t genome_const,
@@ -2245,25 +2214,22 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
               const uint32_t* __restrict__ u_contig, const uint32_t* __restrict__ u_genome,
               const uint64_t* __restrict__ u_seed, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
               uint32_t qual_offset, uint64_t first_unit, uint32_t read_id_base, OutCols o,
-              unsigned long long* __restrict__ counters, const uint64_t* __restrict__ rec_off = nullptr,
+              unsigned long long* __restrict__ counters,
               const uint8_t* __restrict__ hlen = nullptr, const FqTemplate* __restrict__ fq_tp = nullptr, FqTables fq_tb = FqTables{},
               uint32_t fq_lit_bytes = 0, uint32_t fq_hpitch = 0, uint32_t fq_wshift = 0,
               const uint64_t* __restrict__ off64 = nullptr) {
   // off64 != null ("coarse" plans, engine.hip): u_off does not exist; off64[w] = first output byte of pair 64 w (the scan
   // of the plan kernel's per-wave byte sums), and a block places its reads with a scan of their (padded) lengths
   constexpr bool coarse = COARSE && !TEXT;
-  // TEXT with COARSE: rec_off does not exist either; off64[w] = first byte of record 64 w, and a block places its records
-  // with a scan of their lengths (header + 1 + L + 3 + L + 1, fastq.rs:58-66) before anything else
-  constexpr bool tcoarse = COARSE && TEXT;
+  // TEXT: off64[w] = first byte of record 64 w, and a block places its records with a scan of their lengths
+  // (header + 1 + L + 3 + L + 1, fastq.rs:58-66) before anything else
+  static_assert(!TEXT || COARSE, "the TEXT form places its own records");
+  constexpr bool tcoarse = TEXT;
   // COPY_ONLY with TEXT: perfect-short straight into FASTQ text (perfect_short.rs:42-44: every quality is 60): the copied
   // bases, a constant quality line, headers and counters as in the drawing form
   constexpr bool FULL = !COPY_ONLY || TEXT;  // this launch writes qualities, headers / metadata and all run counters
   const uint32_t const_q4 = (((60u + (qual_offset & 0xffu)) & 0xffu) * 0x01010101u);
-#if defined(SIMMR_NT_PLAN_LOADS)  /* measurement: the plan rows (read once) as nontemporal loads */
-#define PL(x) __builtin_nontemporal_load(&(x))
-#else
 #define PL(x) (x)
-#endif
 #define COL_STORE(p, v) do { if (SLOT) stream_store((p), (v)); else *(p) = (v); } while (0)  /* the metadata columns, as the streams */
   // TEXT: header slots of FQ_GROUP reads at a time (dynamic LDS, FQ_GROUP * fq_hpitch bytes), the template and its literals
   extern __shared__ __attribute__((aligned(16))) uint8_t fq_slots[];
@@ -2272,7 +2238,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   __shared__ uint64_t fq_run_at[TEXT ? FQ_GROUP : 1];
   __shared__ uint32_t fq_run_len[TEXT ? FQ_GROUP : 1];
   uint32_t fq_n_segs = 0;
-  if (TEXT && fq_tp) {
+  if (TEXT) {
     for (uint32_t i = threadIdx.x; i < fq_lit_bytes; i += 256) fq_lit[i] = fq_tb.blob[i];
     fq_n_segs = fq_stage_template(fq_tp, fq_segs);
   }
@@ -2285,9 +2251,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   // item -> read, when the block has few enough items.  TEXT: the map lives in the dynamic LDS under the header slots —
   // the slots are dead once the block's headers are copied out (a barrier closes the header phase), the map is dead
   // until then — which is what lets 128 slots and four workgroups per CU fit (engine.hip sizes it: max of the two)
-  // (the overlapped TEXT form formats headers WHILE items run: its 64 slots and the map are both live, nothing is shared)
-  constexpr bool fq_overlap = TEXT && (FQ_OVERLAP != 0);
-  constexpr bool fq_shared_map = TEXT && !fq_overlap;
+  constexpr bool fq_shared_map = TEXT;
   __shared__ uint8_t owner_static[fq_shared_map ? 1 : PHILOX_MAP_ITEMS];
   uint8_t* const owner = fq_shared_map ? fq_slots : owner_static;
   __shared__ uint64_t cbase[CACHED ? PHILOX_CBASE : 1];
@@ -2342,46 +2306,55 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   }
   const uint4* rec4 = reinterpret_cast<const uint4*>(recs);
   uint64_t qsum = 0;  // adds encoded qualities; the offset is taken off at the end (every base is drawn exactly once: p_bases)
-  uint32_t n_subst = 0, n_acgt = 0, n_wrap = 0;
-  uint64_t p_bases = 0;  // plan-derived counters, gathered while the read records are written
-  uint32_t p_redrawn = 0, p_seedsubst = 0;
+  uint32_t n_subst = 0, n_acgt = 0;
+  // Plan-derived counters, gathered while the read records are written — kept out of the vector registers the item loop
+  // needs: the flag counts are ballots (wave-uniform: scalar registers), the bases of this thread's reads a 32-bit sum
+  // that moves to LDS long before it could overflow, wrapped qualities (never, with the offsets FASTQ uses) an LDS count.
+  uint32_t p_bases32 = 0;
+  uint32_t s_redrawn = 0, s_seedsubst = 0;  // per wave
+  __shared__ unsigned long long spill_bases, spill_wrap;
+  if (threadIdx.x == 0) { spill_bases = 0ull; spill_wrap = 0ull; }
   const uint64_t n_reads = paired ? 2 * n_units : n_units;
   const bool q_nowrap = qoff + prof.philox_qmax <= 255u;  // then no encoded quality wraps
   const uint32_t rpu = paired ? 2u : 1u;
   const uint64_t n_blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
   for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    // (the thread's number as a value the compiler cannot see through: addresses made from it in the per-block part are
+    // then computed where they are used instead of being kept in registers across the item loop — they were what the
+    // TEXT forms spilled)
+    uint32_t tix = threadIdx.x;
+    asm volatile("" : "+v"(tix));
     const uint64_t u0 = blk * PHILOX_UNITS;
     const uint32_t nu = (n_units - u0) < PHILOX_UNITS ? (uint32_t)(n_units - u0) : PHILOX_UNITS;
     const uint32_t nr = nu * rpu;
     // the block's first output byte (same for every lane: a scalar load)
-    const uint64_t out0 = TEXT ? (tcoarse ? off64[(paired ? 2 * u0 : u0) >> 6] : rec_off[paired ? 2 * u0 : u0]) : (coarse ? off64[u0 >> 6] : u_off[u0]);
+    const uint64_t out0 = TEXT ? off64[(paired ? 2 * u0 : u0) >> 6] : (coarse ? off64[u0 >> 6] : u_off[u0]);
     uint8_t* const seq_blk = seq + out0;
     uint8_t* const qual_blk = (TEXT ? seq : qual) + out0;
     lds_barrier();  // the previous block's items are done with the records
-#if defined(SIMMR_PROLOGUE_PRIO)  /* measurement: the latency-bound per-block part at a raised wave priority */
-    __builtin_amdgcn_s_setprio(SIMMR_PROLOGUE_PRIO);
-#endif
     uint32_t g = 0;
     uint32_t n_items = 0, ex = 0;
     uint64_t rec_place = 0;  // tcoarse: this thread's record, relative to the block's first
     if (tcoarse) {
       uint32_t L0 = 0, h0 = 0;
-      const bool on = threadIdx.x < nr;
+      const bool on = tix < nr;
       if (on) {
-        const uint64_t u = u0 + (paired ? (threadIdx.x >> 1) : threadIdx.x);
+        const uint64_t u = u0 + (paired ? (tix >> 1) : tix);
         L0 = PL(pl.len[u]);
-        h0 = hlen[paired ? 2 * u + (threadIdx.x & 1u) : u];
+        h0 = hlen[paired ? 2 * u + (tix & 1u) : u];
       }
       uint64_t tot2;
-      const uint64_t ex2 = wg_exclusive_scan_2x32((uint64_t)((L0 + 15u) >> 4) | ((uint64_t)(on ? h0 + 2u * L0 + 5u : 0u) << 32), lds4w, &tot2, threadIdx.x);
+      const uint64_t ex2 = wg_exclusive_scan_2x32((uint64_t)((L0 + 15u) >> 4) | ((uint64_t)(on ? h0 + 2u * L0 + 5u : 0u) << 32), lds4w, &tot2, tix);
       ex = (uint32_t)ex2; n_items = (uint32_t)tot2; rec_place = ex2 >> 32;
     }
     uint32_t my_Lp = 0, my_pad = 0;  // this thread's read: its place in the streams, and (SLOT, reverse mate) the padding in front
     uint64_t my_rd = 0, my_dst = 0;
-    FqFields hf{};           // TEXT: what this thread's read shows in its header
-    uint64_t h_rec = 0, h_rd = 0;
-    if (threadIdx.x < nr) {
-      const uint32_t t = threadIdx.x;
+    // TEXT: what this thread's read shows in its header and cannot be had again from the thread's number (the read's
+    // number, its id and which end of the window is the start can: they are put together where the header is formatted)
+    uint64_t h_pos = 0, h_rec = 0;
+    uint32_t h_L = 0, h_genome = 0, h_contig = 0, h_flags = 0;
+    if (tix < nr) {
+      const uint32_t t = tix;
       const uint64_t u = u0 + (paired ? (t >> 1) : t);
       const uint32_t rev = paired ? (t & 1u) : 0u;
       const uint32_t L = PL(pl.len[u]);
@@ -2390,7 +2363,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       const uint32_t genome = (!CACHED && u_genome) ? u_genome[u] : genome_const;
       const uint64_t rd = paired ? 2 * u + rev : u;
       const uint32_t Lp = SLOT ? ((L + 15u) & ~15u) : L;  // the read's place in the streams
-      const uint64_t my_rec = TEXT ? (tcoarse ? out0 + rec_place : rec_off[rd]) : 0u;
+      const uint64_t my_rec = TEXT ? out0 + rec_place : 0u;
       const uint64_t dst = TEXT ? my_rec + hlen[rd] + 1u : (coarse ? out0 : u_off[u] + (rev ? Lp : 0u));  // (coarse: after the scan below)
       my_Lp = Lp; my_pad = (SLOT && rev) ? Lp - L : 0u; my_rd = rd; my_dst = dst;
       const uint64_t pos = rev ? PL(pl.b[u]) : PL(pl.a[u]);  // first source base of this read on the contig
@@ -2424,15 +2397,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #endif
         // metadata columns of this read (the other emit kernels leave them to k_write_meta)
         const uint32_t fl = PL(pl.flags[u]);
-        if (TEXT) {  // the same values, for the header (fastq.rs:34-56)
-          hf.start = paired ? (rev ? pos + L : pos) : pos;   // simulate.rs:289,295 / :515
-          hf.end = paired ? (rev ? pos : pos + L) : pl.b[u];  // simulate.rs:290,296 / :516
-          hf.genome = genome; hf.contig = contig;
-          hf.read_id = read_id_base + (uint32_t)(first_unit + u);  // simulate.rs:85-89,274
-          hf.flags = (paired && !rev) ? 0u : fl;
-          hf.L = L;
-          h_rec = my_rec; h_rd = rd;
-        }
+        if (TEXT) { h_pos = pos; h_L = L; h_genome = genome; h_contig = contig; h_flags = (paired && !rev) ? 0u : fl; h_rec = my_rec; }
         if (!TEXT) {
           if (paired) {
             if (o.start) COL_STORE(&o.start[rd], (uint64_t)(rev ? pos + L : pos));  // simulate.rs:289,295
@@ -2447,37 +2412,48 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           if (o.flags) COL_STORE(&o.flags[rd], (paired && !rev) ? (uint8_t)0 : (uint8_t)fl);
         }
         if (!rev) {
-          p_bases += paired ? 2ull * L : (uint64_t)L;
-          p_redrawn += (fl & SIMMR_FLAG_REDRAWN) ? 1u : 0u;
-          p_seedsubst += ((fl & SIMMR_FLAG_QSEED_SUBST) ? 1u : 0u) + ((fl & SIMMR_FLAG_MSEED_SUBST) ? 1u : 0u);
+          p_bases32 += paired ? 2u * L : L;  // (L <= 65535)
+          if (p_bases32 >= 0x80000000u) { atomicAdd(&spill_bases, (unsigned long long)p_bases32); p_bases32 = 0u; }
         }
+        s_redrawn += (uint32_t)__builtin_popcountll(__ballot(!rev && (fl & SIMMR_FLAG_REDRAWN)));
+        s_seedsubst += (uint32_t)__builtin_popcountll(__ballot(!rev && (fl & SIMMR_FLAG_QSEED_SUBST))) +
+                       (uint32_t)__builtin_popcountll(__ballot(!rev && (fl & SIMMR_FLAG_MSEED_SUBST)));
       }
     }
-    if (TEXT && fq_tp && !fq_overlap) {
+    if (TEXT) {
       // headers of the block's reads, FQ_GROUP at a time (128: two waves format while two wait; 64 was the most that fit
       // beside four workgroups per CU before the slots shared their memory with the item map): the threads that hold them
       // format, everybody copies
       const uint32_t W = 1u << fq_wshift;  // 16-byte windows per run (covers the longest)
       for (uint32_t half = 0; half * FQ_GROUP < nr; half++) {
         lds_barrier();  // the slots are free (and, the first time, template and literals are staged)
-        if (threadIdx.x < nr && (threadIdx.x / FQ_GROUP) == half) {
-          uint8_t* h = fq_slots + (threadIdx.x & (FQ_GROUP - 1u)) * fq_hpitch;
+        if (tix < nr && (tix / FQ_GROUP) == half) {
+          uint8_t* h = fq_slots + (tix & (FQ_GROUP - 1u)) * fq_hpitch;
+          // the header's fields (fastq.rs:34-56), the same values the column form writes as metadata
+          const uint32_t h_rev = paired ? (tix & 1u) : 0u;
+          const uint64_t h_u = u0 + (paired ? (tix >> 1) : tix);
+          const uint64_t h_rd = (uint64_t)rpu * u0 + tix;
+          FqFields hf;
+          hf.start = h_rev ? h_pos + h_L : h_pos;  // simulate.rs:289,295 / :515
+          hf.end = h_rev ? h_pos : h_pos + h_L;    // simulate.rs:290,296 / :516 (a long read's end is its start + its length: k_plan_long_*)
+          hf.genome = h_genome; hf.contig = h_contig; hf.flags = h_flags; hf.L = h_L;
+          hf.read_id = read_id_base + (uint32_t)(first_unit + h_u);  // simulate.rs:85-89,274
           const uint32_t lead = h_rd > 0 ? 1u : 0u;
           h[0] = '\n';  // ends the record before this one
 #if defined(FQH_ABLATE_FORMAT)
           uint32_t at = lead + fq_header_len_lds(fq_segs, fq_n_segs, fq_tb, hf);  // timing only: the slot keeps whatever it held
 #else
-          uint32_t at = fq_format_header(h, lead, fq_segs, fq_n_segs, fq_tb, fq_lit, hf, (paired && (threadIdx.x & 1u)) ? '2' : '1');
+          uint32_t at = fq_format_header(h, lead, fq_segs, fq_n_segs, fq_tb, fq_lit, hf, (paired && (tix & 1u)) ? '2' : '1');
 #endif
           h[at++] = '\n';
-          fq_run_at[threadIdx.x & (FQ_GROUP - 1u)] = h_rec - lead;
-          fq_run_len[threadIdx.x & (FQ_GROUP - 1u)] = at;
+          fq_run_at[tix & (FQ_GROUP - 1u)] = h_rec - lead;
+          fq_run_len[tix & (FQ_GROUP - 1u)] = at;
           if (hf.L == 0) { uint8_t* p = seq + h_rec + (at - lead); p[0] = '\n'; p[1] = '+'; p[2] = '\n'; }  // (no item writes it)
-          if (h_rd + 1 == n_reads) seq[(tcoarse ? off64[(n_reads + 63u) >> 6] : rec_off[n_reads]) - 1] = '\n';
+          if (h_rd + 1 == n_reads) seq[off64[(n_reads + 63u) >> 6] - 1] = '\n';
         }
         lds_barrier();
         const uint32_t n_runs = nr - FQ_GROUP * half < FQ_GROUP ? nr - FQ_GROUP * half : FQ_GROUP;
-        for (uint32_t wi = threadIdx.x; wi < (n_runs << fq_wshift); wi += 256u) {
+        for (uint32_t wi = tix; wi < (n_runs << fq_wshift); wi += 256u) {
           const uint32_t i = wi >> fq_wshift, piece = wi & (W - 1u);
           const uint32_t n = fq_run_len[i];
           uint8_t* d = seq + fq_run_at[i];
@@ -2498,32 +2474,32 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       // (scanned above)
     } else if (coarse) {  // the reads' places too: the scan of their (padded) lengths rides in the upper half
       uint64_t tot2;
-      const uint64_t ex2 = wg_exclusive_scan_2x32((uint64_t)g | ((uint64_t)my_Lp << 32), lds4w, &tot2, threadIdx.x);
+      const uint64_t ex2 = wg_exclusive_scan_2x32((uint64_t)g | ((uint64_t)my_Lp << 32), lds4w, &tot2, tix);
       ex = (uint32_t)ex2; n_items = (uint32_t)tot2;
-      if (threadIdx.x < nr) { recs[threadIdx.x].dst = (uint32_t)(ex2 >> 32); my_dst = out0 + (ex2 >> 32); }
+      if (tix < nr) { recs[tix].dst = (uint32_t)(ex2 >> 32); my_dst = out0 + (ex2 >> 32); }
     } else {
-      ex = wg_exclusive_scan_u32<true>(g, lds4, &n_items, threadIdx.x);
+      ex = wg_exclusive_scan_u32<true>(g, lds4, &n_items, tix);
     }
 #if !defined(SIMMR_ABLATE_META)
-    if (!TEXT && !COPY_ONLY && threadIdx.x < nr) {
+    if (!TEXT && !COPY_ONLY && tix < nr) {
       COL_STORE(&o.seq_off[my_rd], (uint64_t)(my_dst + my_pad));  // first base (SLOT: a reverse mate's bases are right-aligned)
       if (my_rd + 1 == n_reads) o.seq_off[n_reads] = coarse ? off64[(n_units + 63u) >> 6] : u_off[n_units];  // closing CSR offset
     }
 #endif
-    if (threadIdx.x < nr) recs[threadIdx.x].gs = ex;
-    r_gs[threadIdx.x] = threadIdx.x < nr ? ex : 0xffffffffu;
-    if (threadIdx.x == 0) r_gs[PHILOX_READS] = 0xffffffffu;
+    if (tix < nr) recs[tix].gs = ex;
+    r_gs[tix] = tix < nr ? ex : 0xffffffffu;
+    if (tix == 0) r_gs[PHILOX_READS] = 0xffffffffu;
     // short reads: every read writes its index over its items, so an item finds its read with one LDS load
     const bool use_map = n_items <= PHILOX_MAP_ITEMS;
-    if (use_map && threadIdx.x < nr) {
+    if (use_map && tix < nr) {
       // (8 <= g <= 16, every 150 bp-class read: two 8-byte LDS writes at any byte address, the second ending where the
       // read's items end, instead of g byte writes in a loop)
-      const uint64_t t8 = (uint64_t)threadIdx.x * 0x0101010101010101ull;
+      const uint64_t t8 = (uint64_t)tix * 0x0101010101010101ull;
       if (g >= 8u && g <= 16u) {
         *reinterpret_cast<u64_unaligned*>(owner + ex) = t8;
         *reinterpret_cast<u64_unaligned*>(owner + ex + g - 8u) = t8;
       } else {
-        for (uint32_t j = 0; j < g; j++) owner[ex + j] = (uint8_t)threadIdx.x;
+        for (uint32_t j = 0; j < g; j++) owner[ex + j] = (uint8_t)tix;
       }
     }
     lds_barrier();
@@ -2534,9 +2510,6 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
 #endif
     // long reads (64 items and more each on average): a lane's items ascend 256 apart, so its read moves on by one
     // now and then — one look at the next read's first item instead of the eight dependent ones of the search
-#if defined(SIMMR_PROLOGUE_PRIO)
-    __builtin_amdgcn_s_setprio(0);
-#endif
     const bool walk = !use_map && n_items >= nr * 64u;
     uint32_t r_walk = 0;
     // read of an item: last r with r_gs[r] <= item (items are asked for in ascending order per lane)
@@ -2564,63 +2537,11 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       return *reinterpret_cast<global_u64_unaligned_ptr>(wa);
 #endif
     };
-    // One item ahead (lever b of the round-2 verdict): the NEXT item's read and plane word are fetched before this item's
-    // stores are issued, so the wait for that load no longer stands behind them in the in-order counter.  Measured with
-    // the drawing forms (-DSIMMR_PREFETCH_CODES): no gain (13.34 vs 13.22 ms, long reads 50.5 vs 49.6; the TEXT form loses
-    // its registers to it: profiles/r3/ab_prefetch_*).  The copy-only forms have nothing but that wait between two items
-    // and registers to spare: there it is on.
-#if defined(SIMMR_PREFETCH_CODES)
-    constexpr bool prefetch = true;
-#else
+    // One item ahead: the NEXT item's read and plane word are fetched before this item's stores are issued, so the wait for
+    // that load does not stand behind them in the in-order counter.  Only in the copy-only forms, which have nothing but
+    // that wait between two items and registers to spare (the drawing forms gain nothing from it: LAB.md, round 3).
     constexpr bool prefetch = COPY_ONLY;
-#endif
-    // TEXT, overlapped form: the block's headers are formatted wave by wave — in step s wave s formats the headers of the
-    // 64 reads its lanes hold into the LDS slots and copies them out itself (a run = the '\n' that closes the record
-    // before, the header, its '\n'; 16-byte windows, the last one ending where the run ends), while the other three waves
-    // walk the s-th part of the block's items; one barrier per step hands the slots on.  Formatting 64 headers and
-    // copying them out costs a wave about what a third of a quarter of the items costs each of the others (~1000
-    // instructions), so nobody waits for long, and no wave sits at a barrier while headers are formatted.
-    const uint32_t n_steps = (fq_overlap && fq_tp) ? (nr + FQ_WAVE - 1u) / FQ_WAVE : 1u;  // (nr >= 1: 1..4)
-    for (uint32_t step = 0; step < n_steps; step++) {
-    const bool formatter = fq_overlap && fq_tp && (threadIdx.x >> 6) == step;
-    if (formatter) {
-      const uint32_t lane = threadIdx.x & 63u;
-      if (threadIdx.x < nr) {
-        uint8_t* h = fq_slots + lane * fq_hpitch;
-        const uint32_t lead = h_rd > 0 ? 1u : 0u;
-        h[0] = '\n';  // ends the record before this one
-        uint32_t at = fq_format_header(h, lead, fq_segs, fq_n_segs, fq_tb, fq_lit, hf, (paired && (threadIdx.x & 1u)) ? '2' : '1');
-        h[at++] = '\n';
-        fq_run_at[lane] = h_rec - lead;
-        fq_run_len[lane] = at;
-        if (hf.L == 0) { uint8_t* p = seq + h_rec + (at - lead); p[0] = '\n'; p[1] = '+'; p[2] = '\n'; }  // (no item writes it)
-        if (h_rd + 1 == n_reads) seq[(tcoarse ? off64[(n_reads + 63u) >> 6] : rec_off[n_reads]) - 1] = '\n';
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's slot writes are done (LDS serves a wave in order)
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t W = 1u << fq_wshift;
-      const uint32_t n_runs = nr - FQ_WAVE * step < FQ_WAVE ? nr - FQ_WAVE * step : FQ_WAVE;
-      for (uint32_t wi = lane; wi < (n_runs << fq_wshift); wi += 64u) {
-        const uint32_t i = wi >> fq_wshift, piece = wi & (W - 1u);
-        const uint32_t n = fq_run_len[i];
-        uint8_t* d = seq + fq_run_at[i];
-        const uint8_t* sl = fq_slots + i * fq_hpitch;
-        if (n >= 16u) {  // the last window ends where the run ends (it overlaps its neighbour with the same bytes)
-          if (piece * 16u < n) {
-            const uint32_t w0 = (piece + 1u) * 16u <= n ? piece * 16u : n - 16u;
-            *reinterpret_cast<v4u32_unaligned*>(d + w0) = *reinterpret_cast<const v4u32_unaligned*>(sl + w0);
-          }
-        } else if (piece == 0u) {
-          for (uint32_t j = 0; j < n; j++) d[j] = sl[j];
-        }
-      }
-    } else {
-    // the items of this step: all of them (one step), or the step-th part dealt to the 192 lanes that are not formatting
-    const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t it_rank = (fq_overlap && fq_tp) ? ((wv - (wv > step ? 1u : 0u)) << 6) + (threadIdx.x & 63u) : threadIdx.x;
-    const uint32_t it_stride = (fq_overlap && fq_tp) ? 192u : 256u;
-    const uint32_t it_lo = (fq_overlap && fq_tp) ? (uint32_t)(((uint64_t)i_end * step) / n_steps) : 0u;
-    const uint32_t it_hi = (fq_overlap && fq_tp) ? (uint32_t)(((uint64_t)i_end * (step + 1u)) / n_steps) : i_end;
+    const uint32_t it_rank = threadIdx.x, it_stride = 256u, it_lo = 0u, it_hi = i_end;
     uint32_t r_next = 0;
     uint64_t raw_next = 0;
     if (prefetch && it_lo + it_rank < it_hi) { r_next = locate(it_lo + it_rank); raw_next = plane_word(it_lo + it_rank, r_next); }
@@ -2686,7 +2607,9 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         qsum += qs;  // 255 x the sum of the live bytes (<= 16 * 255 * 255 per item)
       }
       if (!COPY_ONLY && !q_nowrap) {
-        for (uint32_t j = 0; j < n; j++) n_wrap += ((qr[j >> 2] >> (8 * (j & 3u))) & 0xffu) < qoff ? 1u : 0u;
+        uint32_t nw = 0;
+        for (uint32_t j = 0; j < n; j++) nw += ((qr[j >> 2] >> (8 * (j & 3u))) & 0xffu) < qoff ? 1u : 0u;
+        if (nw) atomicAdd(&spill_wrap, (unsigned long long)nw);
       }
       // substitutions in the 2-bit code domain: code' = (code + s) mod 4, 16 bases at once
       // (two-bit addition without the field masks: the low bits add as xor, their carry = and goes into the high bit;
@@ -2782,13 +2705,13 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       }
 #endif
     }
-    }  // (not the formatter)
-    if (fq_overlap && fq_tp) lds_barrier();  // the slots pass to the next step's wave (and, at the end, to the next block's)
-    }  // steps
   }
   // sum of the raw Phred values (per lane modulo 2^64: a lane that wrote records but drew few bases goes "negative";
   // the sum over the lanes is exact)
   // (the masks of the dot products are 0xff bytes: qsum is a multiple of 255, divided exactly by the inverse of 255 modulo 2^64)
+  __syncthreads();  // (the spilled counts)
+  uint64_t p_bases = (uint64_t)p_bases32 + (threadIdx.x == 0 ? (uint64_t)spill_bases : 0ull);
+  const uint64_t n_wrap = threadIdx.x == 0 ? (uint64_t)spill_wrap : 0ull;
   qsum = qsum * 0xFEFEFEFEFEFEFEFFull + 256ull * n_wrap - (uint64_t)qoff * p_bases;
   if (COPY_ONLY && TEXT) qsum = 60ull * p_bases;  // perfect_short.rs:42-44
   uint64_t acgt = (HAS_EXC || !FULL) ? (uint64_t)n_acgt : p_bases;
@@ -2797,8 +2720,6 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     acgt += __shfl_down(acgt, d, 64);
     qsum += __shfl_down(qsum, d, 64);
     p_bases += __shfl_down(p_bases, d, 64);
-    p_redrawn += __shfl_down(p_redrawn, d, 64);
-    p_seedsubst += __shfl_down(p_seedsubst, d, 64);
   }
   // One add per counter and WORKGROUP, into one of SIMMR_CNT_SHARDS rows behind the run's counters (k_counters_fold sums
   // the rows when the counters are read): every wave adding to the same eight addresses served the adds one at a time —
@@ -2811,8 +2732,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     w[SIMMR_CNT_ACGT_BASES] = (unsigned long long)acgt;
     w[SIMMR_CNT_SUBSTITUTIONS] = COPY_ONLY ? 0ull : (unsigned long long)n_subst;
     w[SIMMR_CNT_OUTER_REJECTS] = 0ull;
-    w[SIMMR_CNT_REDRAWN] = !FULL ? 0ull : (unsigned long long)p_redrawn;
-    w[SIMMR_CNT_SEED_SUBST] = !FULL ? 0ull : (unsigned long long)p_seedsubst;
+    w[SIMMR_CNT_REDRAWN] = !FULL ? 0ull : (unsigned long long)s_redrawn;
+    w[SIMMR_CNT_SEED_SUBST] = !FULL ? 0ull : (unsigned long long)s_seedsubst;
     w[SIMMR_CNT_QUAL_SUM] = !FULL ? 0ull : (unsigned long long)qsum;
   }
   __syncthreads();

@@ -1,6 +1,7 @@
 // main.cpp — `simmr-hip`: the reference's run_main (simmr/src/main.rs:20-268)
 // over the C ABI of libsimmr_hip.so.  Same flags, same output files:
 // interleaved FASTQ (fastq.rs) and "<output>.tsv" metadata (files.rs:100-134).
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,7 +33,8 @@ struct DeviceOut {
     *dst = (T*)p;
     return true;
   }
-  bool init(uint64_t n_reads, uint64_t total_bases) {
+  bool init(uint64_t n_reads, uint64_t total_bases, uint32_t slot_bytes) {
+    o.slot_bytes = slot_bytes;  // simmr_plan_info.slot_bytes: the layout the plan in force emits
     o.seq_capacity = total_bases + 32;
     o.reads_capacity = n_reads;
     o.qual_offset = 33;  // util::encode_quality_scores (util.rs:46-57)
@@ -46,11 +48,28 @@ struct DeviceOut {
     h->seq_off.resize(n_reads + 1); h->start.resize(n_reads); h->end.resize(n_reads);
     h->contig.resize(n_reads); h->genome.resize(n_reads); h->read_id.resize(n_reads); h->flags.resize(n_reads);
     auto cp = [](void* d, const void* s, size_t n) { return n == 0 || hipMemcpy(d, s, n, hipMemcpyDeviceToHost) == hipSuccess; };
-    return cp(h->seq.data(), o.seq, total_bases) && cp(h->qual.data(), o.qual, total_bases) &&
-           cp(h->seq_off.data(), o.seq_off, (n_reads + 1) * 8) && cp(h->start.data(), o.start, n_reads * 8) &&
-           cp(h->end.data(), o.end, n_reads * 8) && cp(h->contig.data(), o.contig, n_reads * 4) &&
-           cp(h->genome.data(), o.genome, n_reads * 4) && cp(h->read_id.data(), o.read_id, n_reads * 4) &&
-           cp(h->flags.data(), o.flags, n_reads);
+    if (!(cp(h->seq.data(), o.seq, total_bases) && cp(h->qual.data(), o.qual, total_bases) &&
+          cp(h->seq_off.data(), o.seq_off, (n_reads + 1) * 8) && cp(h->start.data(), o.start, n_reads * 8) &&
+          cp(h->end.data(), o.end, n_reads * 8) && cp(h->contig.data(), o.contig, n_reads * 4) &&
+          cp(h->genome.data(), o.genome, n_reads * 4) && cp(h->read_id.data(), o.read_id, n_reads * 4) &&
+          cp(h->flags.data(), o.flags, n_reads)))
+      return false;
+    if (o.slot_bytes == SIMMR_SLOT16) {
+      // the consumer's side of the slot layout (include/simmr_hip.h): L = |end - start|, bases from seq_off[r], qualities
+      // from seq_off[r] & ~15 — closed up in place into the compact form write_to_fastq reads (reads ascend in both)
+      uint64_t at = 0;
+      for (uint64_t r = 0; r < n_reads; r++) {
+        const uint64_t L = h->end[r] > h->start[r] ? h->end[r] - h->start[r] : h->start[r] - h->end[r];
+        const uint64_t sb = h->seq_off[r], qb = sb & ~15ull;
+        memmove(h->seq.data() + at, h->seq.data() + sb, L);
+        memmove(h->qual.data() + at, h->qual.data() + qb, L);
+        h->seq_off[r] = at;
+        at += L;
+      }
+      h->seq_off[n_reads] = at;
+      h->seq.resize(at); h->qual.resize(at);
+    }
+    return true;
   }
 };
 
@@ -197,7 +216,7 @@ static int run_scope(simmr_engine* eng, const CliArgs& args, const std::vector<G
     }
     if (!written) {  // columns to the host, framed by the restatement of fastq.rs in host.cpp, genome by genome
       DeviceOut d;
-      if (!d.init(pi.n_reads, pi.total_bases)) return die("device allocation failed");
+      if (!d.init(pi.n_reads, pi.total_bases, pi.slot_bytes)) return die("device allocation failed");
       if (sc.emit(sc.id_base, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
       HostReads h;
       if (!d.to_host(pi.n_reads, pi.total_bases, sc.paired, &h)) return die("copy back failed");
@@ -293,6 +312,9 @@ static int run_main(int argc, char** argv) {
 
   simmr_engine* eng = nullptr;
   if (simmr_engine_create(args.device, &eng) != SIMMR_OK) return die(std::string("cannot create engine: ") + simmr_last_error(nullptr));
+  // 16-byte read slots wherever the emit kernel of a plan writes them (include/simmr_hip.h: simmr_reads_out); the columns
+  // only exist on the --host-fastq path (the text path writes no columns), and DeviceOut::to_host reads either layout
+  if (simmr_engine_set_read_slots(eng, SIMMR_SLOT16) != SIMMR_OK) return die(simmr_last_error(eng));
 
   info("Loading genomes");
   std::vector<Genome> genomes;
@@ -390,7 +412,11 @@ static int run_main(int argc, char** argv) {
   const std::string meta_path = args.output + ".tsv";
   if (exists(meta_path)) remove(meta_path.c_str());
 
-  const simmr_error_profile pod = eprofile->pod();
+  simmr_error_profile pod = eprofile->pod();
+  if (args.rng_philox) {  // (extension) the counter mode, for the profiles that draw per base from a parametric law
+    if (pod.kind == SIMMR_CUSTOM) return die("--rng philox is not defined for a custom (empirical) error profile");
+    if (pod.kind != SIMMR_PERFECT_SHORT) pod.rng_mode = SIMMR_RNG_PHILOX;  // (perfect-short draws nothing per base)
+  }
   const int has_seed = args.seed ? 1 : 0;
   const uint64_t seed = args.seed.value_or(0);
 

@@ -197,6 +197,8 @@ struct CliArgs {  // cli.rs:93-220, same flags and defaults
   std::optional<std::pair<float, float>> gamma;  // --gamma mean,std
   bool uniform_start = false;                    // --uniform-start (SIMMR_START_UNIFORM)
   bool per_read_lengths = false;                 // --per-read-lengths (SIMMR_LEN_PER_READ)
+  bool rng_philox = false;  // --rng philox: the counter mode for the per-base draws (SIMMR_RNG_PHILOX; statistical parity,
+                            // BASELINE.json north_star).  Default `reference`: the reference's own streams, byte-identical output
 };
 // returns false and fills err on a usage error (clap would exit(2)); help=true for --help
 bool parse_cli_args(int argc, const char* const* argv, CliArgs* out, std::string* err, bool* help);

@@ -8,6 +8,13 @@ Same argument order and meaning as the reference (num_reads, genomes,
 error_profile, abundance_profile, seed) plus (rank, world).  `backend` is an
 `Engine` (one per GPU); every read byte comes from the HIP kernels behind the C
 ABI.  The only collective of the path is the all-reduce of the run counters.
+
+Output layout: the entry points ask the engine for 16-byte read slots
+(`read_slots=16`, SIMMR_SLOT16 of include/simmr_hip.h) — the layout the
+counter-mode emit kernel writes 20 % faster than gap-free streams — and get
+them wherever the plan's emit kernel offers them, else the compact layout; the
+returned `Reads` knows which (`slot_bytes`), and `Reads.to_host()` hands every
+consumer the same compact form.  `read_slots=0` asks for compact streams.
 """
 from __future__ import annotations
 
@@ -26,6 +33,12 @@ class GenomeRef:
     filepath: str = ""
     uuid: str = ""
     n_contigs: int = 1  # Genome.num_seqs (the range of the contig draw, simulate.rs:181)
+
+
+def _prefer_layout(backend, read_slots: int) -> None:
+    """simmr_engine_set_read_slots: the layout of the plans the entry points below are about to make"""
+    if hasattr(backend, "set_read_slots"):
+        backend.set_read_slots(read_slots)
 
 
 def split_range(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -134,9 +147,10 @@ def compose_outer_summaries(pieces, summaries, want):
 
 def simulate_pe_reads(backend, num_reads: int, genomes: Sequence[GenomeRef], error_profile: ErrorProfile,
                       abundance_profile: AbundanceProfile, seed: Optional[int], rank: int = 0, world: int = 1,
-                      qual_offset: int = 0):
+                      qual_offset: int = 0, read_slots: int = 16):
     """Returns one tuple per genome, like simulate.rs:119:
     (filepath, uuid, genome_reads, abundance, reads-of-this-rank or None)."""
+    _prefer_layout(backend, read_slots)
     ab = determine_reads(num_reads, genomes, error_profile, abundance_profile, True)
     reads_per_genome = [r for r, _ in ab]
     shards = pe_shards(reads_per_genome, rank, world)
@@ -173,12 +187,13 @@ def simulate_pe_reads(backend, num_reads: int, genomes: Sequence[GenomeRef], err
 
 def simulate_pe_reads_batched(backend, num_reads: int, genomes: Sequence[GenomeRef], error_profile: ErrorProfile,
                               abundance_profile: AbundanceProfile, seed: Optional[int], rank: int = 0,
-                              world: int = 1, qual_offset: int = 0):
+                              world: int = 1, qual_offset: int = 0, read_slots: int = 16):
     """simulate_pe_reads (simulate.rs:110-150) with all genomes in ONE device plan
     (`simmr_pe_plan_multi`): same reads, ids and order as the per-genome loop, returned like
     simulate_long_reads as (per-genome metadata, reads of this rank's range of the global pair
     index).  For runs over many genomes (BASELINE config 4) this removes the per-genome launch
     and synchronisation cost."""
+    _prefer_layout(backend, read_slots)
     ab = determine_reads(num_reads, genomes, error_profile, abundance_profile, True)
     reads_per_genome = [r for r, _ in ab]
     first, count = split_range(sum(r // 2 for r in reads_per_genome), rank, world)
@@ -190,9 +205,10 @@ def simulate_pe_reads_batched(backend, num_reads: int, genomes: Sequence[GenomeR
 
 def simulate_long_reads(backend, num_reads: int, genomes: Sequence[GenomeRef], error_profile: ErrorProfile,
                         abundance_profile: AbundanceProfile, seed: Optional[int], rank: int = 0, world: int = 1,
-                        qual_offset: int = 0):
+                        qual_offset: int = 0, read_slots: int = 16):
     """One StdRng stream spans all genomes (simulate.rs:348): the shard is a
     range of global read indices.  Returns (per-genome metadata, reads)."""
+    _prefer_layout(backend, read_slots)
     ab = determine_reads(num_reads, genomes, error_profile, abundance_profile, False)
     total = sum(r for r, _ in ab)
     first, count = split_range(total, rank, world)

@@ -9,6 +9,8 @@ substitute (include/simmr_hip.h) and the reads are flagged.
 import numpy as np
 import pytest
 
+from tests.conftest import needs_extras
+
 from simmr_amd import (MinimalLongErrorProfile, MinimalShortErrorProfile, PerfectLongErrorProfile,
                        PerfectShortErrorProfile, _abi)
 from tests import _oracle, _synth
@@ -130,6 +132,7 @@ def test_minimal_short_params(engine, oracle, genome_multi, L, I, q):
     assert_same(dev.to_host(), ora.trimmed())
 
 
+@needs_extras
 def test_minimal_short_wave_per_pair_variant(oracle, genome_1m, monkeypatch):
     """The wave-per-unit emit kernel (used for long reads) on pairs: same bytes."""
     from simmr_amd.engine import Engine
@@ -145,6 +148,7 @@ def test_minimal_short_wave_per_pair_variant(oracle, genome_1m, monkeypatch):
         e2.close()
 
 
+@needs_extras
 def test_long_wave_per_read_variant(oracle, genome_multi, monkeypatch):
     """k_emit_stream (wave per read, LDS windows) stays covered for long reads."""
     from simmr_amd.engine import Engine

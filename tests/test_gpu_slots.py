@@ -180,13 +180,13 @@ def test_slot16_refusals(engine, genome_multi):
     engine.set_read_slots(16)
     try:
         keep = CustomShortErrorProfile(model_io.synthetic_short_model(n_positions=40, seed=5))
+        # slots are a preference: plans whose emit kernel writes the compact layout only say so, and emit into it
         for pod in (PerfectShortErrorProfile().pod(), MinimalShortErrorProfile().pod(), keep.pod()):
-            with pytest.raises(SimmrError) as ei:  # these kernels write the compact layout only
-                engine.pe_plan(1, pod, 1000, 1)
-            assert ei.value.code == _abi.ENOTSUP
-        with pytest.raises(SimmrError) as ei:
-            engine.long_plan([1], [10], MinimalLongErrorProfile().pod(), 1)
-        assert ei.value.code == _abi.ENOTSUP
+            info = engine.pe_plan(1, pod, 1000, 1)
+            assert info.slot_bytes == 0
+            engine.pe_emit(0, Reads.allocate(info.n_reads, info.total_bases, engine.device, 33, slot_bytes=0))
+        assert engine.long_plan([1], [10], MinimalLongErrorProfile().pod(), 1).slot_bytes == 0
+        assert engine.pe_plan(1, ph, 1000, 1).slot_bytes == 16
         # a caller that expects the compact layout is not handed slots (and the other way round)
         info = engine.pe_plan(1, ph, 1000, 1)
         out = Reads.allocate(info.n_reads, info.total_bases, engine.device, 33, slot_bytes=0)

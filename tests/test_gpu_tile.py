@@ -1,6 +1,8 @@
 """GPU parity of the tile form of the counter-mode emit kernel (simmr_amd/csrc/emit_tile.hip).
 
-The tile form is opt-in (SIMMR_PHILOX_FORM=2: it measured slower than the item kernel, profiles/r3/tile_form_*), for
+The tile form measured slower than the item kernel (profiles/r3/tile_form_*) and is not in the product library: it is
+compiled into the `make extras` build only, and this module runs only against that build (tests/conftest.py:
+needs_extras).  There it is opt-in (SIMMR_PHILOX_FORM=2), for
 paired plans whose reads are at most TILE_MAXL bases; here it and its corners are forced:
 block sizes from one pair to 32, tiles too small for their block (the direct-store path inside the kernel, for
 some or for all blocks), the item kernel on the same plan (SIMMR_PHILOX_FORM=1), reads of fewer than 16 bases
@@ -15,7 +17,9 @@ from simmr_amd import MinimalShortErrorProfile, _abi
 from tests import _oracle, _synth
 from tests.test_gpu_parity import assert_same
 
-pytestmark = pytest.mark.gpu
+from tests.conftest import needs_extras
+
+pytestmark = [pytest.mark.gpu, needs_extras]
 
 LENS = [300_000, 90_001, 30_017, 70_000, 123_457]
 
