@@ -328,7 +328,20 @@ def main():
     # (the padding of the slot layout is traffic, not credit: bases and qualities count L bytes each in either layout)
     lens = ((out.end[:info.n_reads] - out.start[:info.n_reads]).abs() if slot16 else
             out.seq_off[1:info.n_reads + 1] - out.seq_off[:info.n_reads])
-    alg_bytes = int(((lens + 3) // 4).sum().item()) + 2 * int(lens.sum().item()) + 16 * int(info.n_reads)
+    plane_bytes = int(((lens + 3) // 4).sum().item())
+    alg_bytes = plane_bytes + 2 * int(lens.sum().item()) + 16 * int(info.n_reads)
+    # ... and of one launch of the TEXT form (simmr_emit_fastq): the packed-reference bytes read + every byte of the FASTQ
+    # text written (headers, bases, "+" lines, qualities, line ends: fastq.rs:58-66); the text replaces the SoA columns
+    text_alg_bytes = plane_bytes + int(fq["bytes"])
+    if through is not None and through["emit_kernel_ms"] > 0:
+        a = text_alg_bytes / (through["emit_kernel_ms"] * 1e-3) / 1e9
+        through["roofline"] = {"bound": "hbm", "kernel": "k_emit_philox<TEXT>" if args.profile != "perfect-short" else "k_emit_philox<COPY_ONLY, TEXT>",
+                               "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
+                               "traffic": measured_traffic(args, 2 * pairs_per_gpu, text=True),
+                               "alg_bytes_per_launch": text_alg_bytes, "kernel_ms": through["emit_kernel_ms"],
+                               "note": "algorithmic bytes = FASTQ text written + 2-bit reference read; one launch, HIP events on the engine's stream"}
+    if args.through_fastq:
+        alg_bytes = text_alg_bytes
     if other_layout is not None and other_layout["kernel_ms"] > 0:
         other_layout["achieved_GBps"] = alg_bytes / (other_layout["kernel_ms"] * 1e-3) / 1e9
         other_layout["roofline_frac"] = other_layout["achieved_GBps"] / HBM_PEAK_GBPS
@@ -394,7 +407,8 @@ def main():
                             if args.rng == "reference" else
                             "VALU issue (integer RNG and table lookups) next to the issue of the store instructions and the "
                             "HBM write path behind them: see `valu` and DESIGN.md section 4"),
-                "kernel": ("k_emit_perfect_pe" if args.profile == "perfect-short" else
+                "kernel": (("k_emit_philox<COPY_ONLY, TEXT>" if args.profile == "perfect-short" else "k_emit_philox<TEXT>") if args.through_fastq else
+                           "k_emit_perfect_pe" if args.profile == "perfect-short" else
                            "k_emit_custom_pe" if args.profile == "custom-short" else
                            "k_custom_long_qual + k_custom_long_splice" if custom is not None else
                            "k_emit_lanes" if args.rng == "reference" else "k_emit_philox"),
@@ -439,8 +453,10 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-PMC_RECORD = ROOT / "profiles" / "r3" / "pmc_traffic.json"
-KERNEL_SOURCES = ("simmr_amd/csrc/kernels.hip", "simmr_amd/csrc/rng_device.hpp", "simmr_amd/csrc/device_types.hpp")
+PMC_RECORD = ROOT / "profiles" / "r4" / "pmc_traffic.json"
+# everything the counters of a launch depend on: the kernels, and the launch geometry and kernel selection in engine.hip
+KERNEL_SOURCES = ("simmr_amd/csrc/kernels.hip", "simmr_amd/csrc/rng_device.hpp", "simmr_amd/csrc/device_types.hpp",
+                  "simmr_amd/csrc/fastq_format.hpp", "simmr_amd/csrc/fastq_kernels.hip", "simmr_amd/csrc/engine.hip")
 
 
 def kernel_source_hash():
@@ -453,7 +469,7 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def _profile_record(args, reads_per_gpu):
+def _profile_record(args, reads_per_gpu, text=False):
     """(record, why_not): the committed rocprofv3 PMC record of this very command (profiles/r3/pmc_traffic.json: one
     counter set per run, no tracing) — only for the workload it was measured on and only if the kernel sources still
     hash to what they were when it was collected."""
@@ -464,8 +480,10 @@ def _profile_record(args, reads_per_gpu):
     if t.get("source_sha256") != kernel_source_hash():
         return None, (f"{PMC_RECORD.relative_to(ROOT)} was collected from other kernel sources "
                       f"(sha256 {str(t.get('source_sha256'))[:12]}.. != {kernel_source_hash()[:12]}..): collect it again")
-    if args.through_fastq:
-        return None, "not collected for --through-fastq"
+    if args.through_fastq or text:
+        if reads_per_gpu == 100_000_000 and args.genome_bases == 100_000_000 and args.profile == "minimal-short" and args.rng == "philox":
+            return (t.get("k_emit_philox_text"), None) if t.get("k_emit_philox_text") else (None, "not collected for k_emit_philox_text")
+        return None, "the TEXT form's counters were collected for the default workload only"
     if args.profile == "custom-long" and reads_per_gpu == 1_000_000 and args.genome_bases == 100_000_000:
         return t.get("k_custom_long_splice"), None
     if reads_per_gpu != 100_000_000 or args.genome_bases != 100_000_000:
@@ -478,12 +496,12 @@ def _profile_record(args, reads_per_gpu):
     return None, "not collected for this profile"
 
 
-def measured_traffic(args, reads_per_gpu):
+def measured_traffic(args, reads_per_gpu, text=False):
     """HBM bytes per launch of the dominant kernel: FETCH_SIZE + WRITE_SIZE of separate --pmc passes, raw (the guide's
     x2 correction of FETCH_SIZE applies to wide coalesced reads; this kernel reads 8-byte gathers and plan columns, so
     the raw figure is reported and the doubled one is in the file).  Not measured by this run: a constant from the
     committed profile, null for any other workload or when the kernel sources have changed since."""
-    t, _ = _profile_record(args, reads_per_gpu)
+    t, _ = _profile_record(args, reads_per_gpu, text)
     return None if t is None else t.get("bytes_raw")
 
 

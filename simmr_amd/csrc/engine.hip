@@ -1827,6 +1827,7 @@ bool compile_header_format(const char* fmt, std::vector<uint8_t>* blob, FqTempla
   };
   auto flush = [&](size_t end) {
     if (end == lit0) return true;
+    while (blob->size() & 7u) blob->push_back(0);  // literals start on 8-byte boundaries: aligned 8-byte LDS reads (fq_put_bytes)
     const uint32_t off = (uint32_t)blob->size();
     blob->insert(blob->end(), fmt + lit0, fmt + end);
     return push(FQ_LITERAL, off, (uint32_t)(end - lit0));

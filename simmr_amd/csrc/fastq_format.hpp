@@ -8,7 +8,7 @@
 
 #define FQ_MAX_SEGS 24
 #define FQ_HMAX 256u  /* longest header, including the '\n' */
-#define FQ_LIT_MAX 256u /* template literals kept in LDS (they are part of a header, so < FQ_HMAX) */
+#define FQ_LIT_MAX 448u /* template literals kept in LDS, each padded to a multiple of 8 bytes (they are part of a header: < FQ_HMAX + 7 * FQ_MAX_SEGS) */
 #define FQ_BATCH 64u  /* reads per wave iteration */
 
 enum FqKind : uint32_t {
@@ -118,97 +118,138 @@ SIMMR_DEV uint32_t fq_header_len(const FqTemplate* __restrict__ tp, const FqTabl
   return n;
 }
 
-// Decimal digits of v at dst[at ...] (LDS).  Below 10^8 — every position of a genome under 100 Mbp, most read ids — the
-// eight digits are made in registers and go out as ONE 8-byte store with the leading zeros shifted off (the bytes
-// behind the number are overwritten by the next piece of the header; every slot has that much slack).
+// ---- a header into an LDS slot, through ALIGNED 32-bit stores ------------------------------------------------------
+// A DS access off its natural alignment is replayed at 64 cycles per wave-instruction (cdna_hip_programming.md,
+// guideline 17): the first form of these routines stored a header's pieces as 8-byte LDS writes at whatever byte the
+// header had reached — sixteen of them per header — and the TEXT form of the emit kernel spent 3.0e9 of its 6.2e9
+// LDS-array cycles per launch in that replay (SQ_LDS_UNALIGNED_STALL, profiles/r4/lds_probe.log).  The writer below
+// keeps the bytes of the unfinished word in a register and stores whole words at 4-byte-aligned addresses only (slot
+// bases are 4-byte aligned: fq_slot_pitch is an odd number of words, which also keeps the lanes of a wave on different
+// banks).  Every piece rewrites the word it continues, so the slot is complete after the last piece, and it writes up
+// to two words past its bytes (zeros, or the next piece's start): every slot has that slack.
+struct FqW {
+  uint32_t* w;   // the slot, as words
+  uint32_t at;   // bytes written
+  uint32_t acc;  // the bytes of the word at (at & ~3): its low (at & 3) bytes are the header's, the rest 0
+};
+SIMMR_DEV FqW fq_begin(uint8_t* slot) { return FqW{reinterpret_cast<uint32_t*>(slot), 0u, 0u}; }
+// the low n (1..8) bytes of v
+SIMMR_DEV void fq_put8(FqW& o, uint64_t v, uint32_t n) {
+  const uint32_t f = o.at & 3u, sh = 8u * f;
+  if (n < 8u) v &= (1ull << (8u * n)) - 1ull;
+  const uint64_t t = v << sh;
+  const uint32_t w0 = o.acc | (uint32_t)t, w1 = (uint32_t)(t >> 32);
+  const uint32_t w2 = f ? ((uint32_t)(v >> 32) >> (32u - sh)) : 0u;
+  uint32_t* p = o.w + (o.at >> 2);
+  p[0] = w0; p[1] = w1; p[2] = w2;
+  const uint32_t k = (f + n) >> 2;
+  o.acc = k == 0u ? w0 : (k == 1u ? w1 : w2);
+  o.at += n;
+  asm volatile("" ::: "memory");  // piece by piece: interleaving the pieces of a header buys nothing and costs the kernel its registers
+}
+SIMMR_DEV void fq_put1(FqW& o, uint32_t c) {
+  const uint32_t f = o.at & 3u;
+  o.acc |= c << (8u * f);
+  o.w[o.at >> 2] = o.acc;
+  o.at++;
+  if (f == 3u) o.acc = 0u;
+}
+
+// Decimal digits of v.  Below 10^8 — every position of a genome under 100 Mbp, most read ids — the eight digits are made
+// in registers and go out as one piece with the leading zeros shifted off.
 SIMMR_DEV uint32_t fq_four_digits(uint32_t y) {  // y < 10000 -> its four digits as bytes, most significant first in memory
   const uint32_t a = y / 100u, b = y - a * 100u;
   const uint32_t a1 = a / 10u, a0 = a - a1 * 10u, b1 = b / 10u, b0 = b - b1 * 10u;
   return a1 | (a0 << 8) | (b1 << 16) | (b0 << 24);
 }
-SIMMR_DEV uint32_t fq_put_dec(uint8_t* dst, uint32_t at, uint64_t v) {
+SIMMR_DEV uint64_t fq_eight_digits(uint32_t x) {  // x < 10^8 -> its eight digits as ASCII bytes, most significant first in memory
+  const uint32_t hi = x / 10000u, lo = x - hi * 10000u;
+  return ((uint64_t)fq_four_digits(hi) | ((uint64_t)fq_four_digits(lo) << 32)) + 0x3030303030303030ull;
+}
+SIMMR_DEV void fq_put_dec(FqW& o, uint64_t v) {
   if (v < 100000000ull) {
     const uint32_t x = (uint32_t)v;
-    const uint32_t hi = x / 10000u, lo = x - hi * 10000u;
-    uint64_t p = ((uint64_t)fq_four_digits(hi) | ((uint64_t)fq_four_digits(lo) << 32)) + 0x3030303030303030ull;
     const uint32_t n = dec_digits(x);
-    p >>= 8u * (8u - n);
-    *reinterpret_cast<u64_unaligned*>(dst + at) = p;
-    return at + n;
+    fq_put8(o, fq_eight_digits(x) >> (8u * (8u - n)), n);
+    return;
   }
-  if ((v >> 32) == 0) {  // no 64-bit division
-    uint32_t x = (uint32_t)v, n = 1;
-    for (uint32_t t = x; t >= 10u; t /= 10u) n++;
-    for (uint32_t i = n; i-- > 0;) { dst[at + i] = (uint8_t)('0' + x % 10u); x /= 10u; }
-    return at + n;
+  if ((v >> 32) == 0) {  // below 2^32 (read ids of a run of a billion reads): one or two digits, then eight
+    const uint32_t x = (uint32_t)v, hi = x / 100000000u, lo = x - hi * 100000000u;  // hi = 1..42
+    const uint32_t h1 = hi / 10u, h0 = hi - h1 * 10u;
+    fq_put8(o, h1 ? (uint64_t)(('0' + h1) | (('0' + h0) << 8)) : (uint64_t)('0' + h0), h1 ? 2u : 1u);
+    fq_put8(o, fq_eight_digits(lo), 8u);
+    return;
   }
-  const uint32_t n = dec_digits(v);
-  for (uint32_t i = n; i-- > 0;) { dst[at + i] = (uint8_t)('0' + (uint32_t)(v % 10u)); v /= 10u; }
-  return at + n;
+  // positions beyond 4 Gbases: v = c * 10^16 + d * 10^8 + b (divisions by constants only: a division by a run-time
+  // divisor is a hundred instructions and thirty registers, inlined once per field)
+  const uint64_t a = v / 100000000ull;
+  const uint32_t b = (uint32_t)(v - a * 100000000ull);
+  const uint32_t c = (uint32_t)(a / 100000000ull), d = (uint32_t)(a - (uint64_t)c * 100000000ull);  // c < 1845
+  if (c) {
+    const uint32_t n = dec_digits(c);
+    fq_put8(o, (uint64_t)((fq_four_digits(c) + 0x30303030u) >> (8u * (4u - n))), n);
+    fq_put8(o, fq_eight_digits(d), 8u);
+  } else {
+    const uint32_t n = dec_digits(d);
+    fq_put8(o, fq_eight_digits(d) >> (8u * (8u - n)), n);
+  }
+  fq_put8(o, fq_eight_digits(b), 8u);
 }
-// LDS -> LDS, eight bytes at a time (src is the same for every lane: one broadcast read per piece; both buffers have
-// eight spare bytes, and what is written past n is overwritten by the header's next piece)
-SIMMR_DEV uint32_t fq_put_bytes(uint8_t* dst, uint32_t at, const uint8_t* src, uint32_t n) {
-  for (uint32_t i = 0; i < n; i += 8) *reinterpret_cast<u64_unaligned*>(dst + at + i) = *reinterpret_cast<const u64_unaligned*>(src + i);
-  return at + n;
+// a template literal, LDS -> LDS, eight bytes at a time (src is the same for every lane — a broadcast read — and starts
+// on an 8-byte boundary: compile_header_format pads the literals to that; the buffer has eight spare bytes)
+SIMMR_DEV void fq_put_bytes(FqW& o, const uint8_t* src, uint32_t n) {
+  for (uint32_t i = 0; i < n; i += 8u) fq_put8(o, *reinterpret_cast<const uint64_t*>(src + i), n - i < 8u ? n - i : 8u);
 }
-// device memory -> LDS in 8-byte pieces (the blob is padded; the slot has spare bytes behind the longest header).
-// The first 48 bytes are fetched before the first is stored: one memory latency for an id, not one per piece (a
-// header has two ids; piece by piece they were a third of the header kernel's time).
-SIMMR_DEV uint32_t fq_put_global(uint8_t* dst, uint32_t at, const uint8_t* __restrict__ src, uint32_t n) {
+// an id, device memory -> LDS in 8-byte pieces (the blob is padded).  The first 48 bytes are fetched before the first is
+// stored: one memory latency for an id, not one per piece (a header has two ids).
+SIMMR_DEV void fq_put_global(FqW& o, const uint8_t* __restrict__ src, uint32_t n) {
   uint64_t v[6];
 #pragma unroll
   for (uint32_t k = 0; k < 6; k++) v[k] = (8u * k < n) ? *(global_u64_unaligned_ptr)(src + 8u * k) : 0ull;
 #pragma unroll
-  for (uint32_t k = 0; k < 6; k++) if (8u * k < n) *reinterpret_cast<u64_unaligned*>(dst + at + 8u * k) = v[k];
-  for (uint32_t i = 48; i < n; i += 8) {
-    const uint64_t w = *(global_u64_unaligned_ptr)(src + i);
-    *reinterpret_cast<u64_unaligned*>(dst + at + i) = w;
-  }
-  return at + n;
+  for (uint32_t k = 0; k < 6; k++) if (8u * k < n) fq_put8(o, v[k], n - 8u * k < 8u ? n - 8u * k : 8u);
+  for (uint32_t i = 48; i < n; i += 8) fq_put8(o, *(global_u64_unaligned_ptr)(src + i), n - i < 8u ? n - i : 8u);
 }
 
-#if defined(FQH_ABLATE_FORMAT)
-SIMMR_DEV uint32_t fq_header_len_lds(const FqSeg* segs, uint32_t n_segs, const FqTables& tb, const FqFields& f) {
-  const uint32_t g = f.genome;
-  uint32_t n = 0;
-  for (uint32_t s = 0; s < n_segs; s++) {
-    const FqSeg sg = segs[s];
-    switch (sg.kind) {
-      case FQ_LITERAL: n += sg.len; break;
-      case FQ_GENOME_ID: n += tb.g_id_len[g]; break;
-      case FQ_READ_ID: n += dec_digits(f.read_id); break;
-      case FQ_SEQUENCE_ID: n += tb.c_len[tb.g_cbase[g] + f.contig]; break;
-      case FQ_START: n += dec_digits(f.start); break;
-      case FQ_END: n += dec_digits(f.end); break;
-      default: n += 1; break;
-    }
-  }
-  return n;
-}
-#endif
-
-// the header of a read into an LDS slot at h[at ...] (fastq.rs:34-56); returns the position behind it
+// the header of a read and its '\n' into an LDS slot (fastq.rs:34-56); returns the bytes written.  `lead`: the run starts
+// with the '\n' that ends the record before (the TEXT form of the emit kernel).
 // `segs` / `n_segs`: the template's pieces, staged in LDS by the caller (fq_stage_template)
-SIMMR_DEV uint32_t fq_format_header(uint8_t* h, uint32_t at, const FqSeg* segs, uint32_t n_segs, const FqTables& tb, const uint8_t* lit,
-                                    const FqFields& f, uint8_t pair_char) {
+SIMMR_DEV uint32_t fq_format_header(uint8_t* slot, uint32_t lead, const FqSeg* segs, uint32_t n_segs, const FqTables& tb,
+                                    const uint8_t* lit, const FqFields& f, uint32_t pair_char) {
+  FqW o = fq_begin(slot);
+  if (lead) fq_put1(o, '\n');
   const uint32_t g = f.genome;
   const uint32_t row = tb.g_cbase[g] + f.contig;
   const uint32_t gid_off = tb.g_id_off[g], gid_len = tb.g_id_len[g], sid_off = tb.c_off[row], sid_len = tb.c_len[row];
   for (uint32_t s = 0; s < n_segs; s++) {
     const FqSeg sg = segs[s];
-    switch (sg.kind) {
-      case FQ_LITERAL: at = fq_put_bytes(h, at, lit + sg.off, sg.len); break;
-      case FQ_GENOME_ID: at = fq_put_global(h, at, tb.blob + gid_off, gid_len); break;
-      case FQ_READ_ID: at = fq_put_dec(h, at, f.read_id); break;
-      case FQ_SEQUENCE_ID: at = fq_put_global(h, at, tb.blob + sid_off, sid_len); break;
-      case FQ_START: at = fq_put_dec(h, at, f.start); break;
-      case FQ_END: at = fq_put_dec(h, at, f.end); break;
-      case FQ_REVCOMP: h[at++] = (f.flags & SIMMR_FLAG_REVCOMP) ? 't' : 'f'; break;
-      default: h[at++] = pair_char; break;  // mates are interleaved
+    // (one copy of each routine: the two ids share one, the three numbers one, the two letters one — inlined per field
+    // they made the header code three times as long and pushed the emit kernel into scratch)
+    if (sg.kind == FQ_LITERAL) {
+      fq_put_bytes(o, lit + sg.off, sg.len);
+    } else if (sg.kind == FQ_GENOME_ID || sg.kind == FQ_SEQUENCE_ID) {
+      const bool gid = sg.kind == FQ_GENOME_ID;
+      fq_put_global(o, tb.blob + (gid ? gid_off : sid_off), gid ? gid_len : sid_len);
+    } else if (sg.kind == FQ_READ_ID || sg.kind == FQ_START || sg.kind == FQ_END) {
+      fq_put_dec(o, sg.kind == FQ_READ_ID ? (uint64_t)f.read_id : (sg.kind == FQ_START ? f.start : f.end));
+    } else {
+      fq_put1(o, sg.kind == FQ_REVCOMP ? ((f.flags & SIMMR_FLAG_REVCOMP) ? 't' : 'f') : pair_char);  // mates are interleaved
     }
   }
-  return at;
+  fq_put1(o, '\n');
+  return o.at;
+}
+
+// 16 bytes at byte `b` of an LDS slot (4-byte-aligned base) as five aligned words funnelled together: an unaligned
+// ds_read_b128 is replayed at 64 cycles per wave-instruction
+SIMMR_DEV v4u32 fq_read16(const uint8_t* slot, uint32_t b) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(slot) + (b >> 2);
+  const uint32_t x0 = w[0], x1 = w[1], x2 = w[2], x3 = w[3], x4 = w[4];
+  const uint32_t sh = b & 3u;  // v_alignbyte_b32: (hi:lo) >> 8 * sh
+  v4u32 v;
+  v.x = __builtin_amdgcn_alignbyte(x1, x0, sh); v.y = __builtin_amdgcn_alignbyte(x2, x1, sh);
+  v.z = __builtin_amdgcn_alignbyte(x3, x2, sh); v.w = __builtin_amdgcn_alignbyte(x4, x3, sh);
+  return v;
 }
 
 // the template's pieces from device memory into LDS, once per workgroup (a scalar load per piece and header was a chain of

@@ -121,9 +121,7 @@ k_fastq_write(const FqTemplate* __restrict__ tp, FqTables tb, FqReads rd, uint64
       uint8_t* h = hdr + lane * hpitch;
       const uint64_t so = rd.seq_off[r];
       const FqFields f = fq_fields(rd, r);
-      uint32_t at = fq_format_header(h, 0u, segs, n_segs, tb, lit, f, (paired && (r & 1u)) ? '2' : '1');
-      h[at] = '\n';
-      const uint32_t H = at + 1, L = f.L;
+      const uint32_t H = fq_format_header(h, 0u, segs, n_segs, tb, lit, f, (paired && (r & 1u)) ? '2' : '1'), L = f.L;
       recs[wave][lane] = FqRead{rec_off[r], so, H, L};
       // windows: runs shorter than 16 bytes are one bytewise "window"
       nwin = (H >= 16u ? (H + 15u) >> 4 : 1u) + (L >= 16u ? ((L + 3u + 15u) >> 4) + ((L + 1u + 15u) >> 4) : 2u);
@@ -176,7 +174,7 @@ k_fastq_write(const FqTemplate* __restrict__ tp, FqTables tb, FqReads rd, uint64
         // both loads are always issued (no branch): the one that is not needed reads a harmless address
         const uint8_t* gsrc = (isB ? rd.seq + R.so : rd.qual + (rd.slot16 ? (R.so & ~15ull) : R.so)) + ((fast && !isA) ? ld : 0u);
         const u32x4 vg = *(global_u128_unaligned_ptr)(fast && !isA ? gsrc : rd.seq);
-        const u32x4 vl = *reinterpret_cast<const u32x4_unaligned*>(hdr + i * hpitch + ((fast && isA) ? w : 0u));
+        const u32x4 vl = fq_read16(hdr + i * hpitch, (fast && isA) ? w : 0u);  // (aligned words funnelled: no replay in the LDS)
         v[u] = isA ? vl : fq_shift_in(vg, t, fill);
         dst[u] = fast ? out + R.rec + run_off + w : nullptr;
         slow[u] = (on && !fast) ? (i | (isA ? 0x100u : isB ? 0x200u : 0x400u)) : 0u;

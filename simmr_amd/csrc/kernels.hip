@@ -2439,13 +2439,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           hf.genome = h_genome; hf.contig = h_contig; hf.flags = h_flags; hf.L = h_L;
           hf.read_id = read_id_base + (uint32_t)(first_unit + h_u);  // simulate.rs:85-89,274
           const uint32_t lead = h_rd > 0 ? 1u : 0u;
-          h[0] = '\n';  // ends the record before this one
-#if defined(FQH_ABLATE_FORMAT)
-          uint32_t at = lead + fq_header_len_lds(fq_segs, fq_n_segs, fq_tb, hf);  // timing only: the slot keeps whatever it held
-#else
-          uint32_t at = fq_format_header(h, lead, fq_segs, fq_n_segs, fq_tb, fq_lit, hf, (paired && (tix & 1u)) ? '2' : '1');
-#endif
-          h[at++] = '\n';
+          const uint32_t at = fq_format_header(h, lead, fq_segs, fq_n_segs, fq_tb, fq_lit, hf, (paired && (tix & 1u)) ? '2' : '1');
           fq_run_at[tix & (FQ_GROUP - 1u)] = h_rec - lead;
           fq_run_len[tix & (FQ_GROUP - 1u)] = at;
           if (hf.L == 0) { uint8_t* p = seq + h_rec + (at - lead); p[0] = '\n'; p[1] = '+'; p[2] = '\n'; }  // (no item writes it)
@@ -2461,7 +2455,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           if (n >= 16u) {  // the last window ends where the run ends (it overlaps its neighbour with the same bytes)
             if (piece * 16u < n) {
               const uint32_t w0 = (piece + 1u) * 16u <= n ? piece * 16u : n - 16u;
-              *reinterpret_cast<v4u32_unaligned*>(d + w0) = *reinterpret_cast<const v4u32_unaligned*>(sl + w0);
+              *reinterpret_cast<v4u32_unaligned*>(d + w0) = (v4u32_unaligned)fq_read16(sl, w0);
             }
           } else if (piece == 0u) {
             for (uint32_t j = 0; j < n; j++) d[j] = sl[j];

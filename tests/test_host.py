@@ -174,3 +174,15 @@ def test_missing_rccl_answers_enodev_without_a_gpu():
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert out.stdout.split() == [str(_abi.ENODEV)] * 2
+
+
+def test_header_states_the_shipped_philox_specification():
+    """include/simmr_hip.h is what a maintainer reads: it must describe the generator the library implements (version 3:
+    24 bits per base, three calls per 16 bases, two levels), not an earlier one."""
+    text = (ROOT / "include" / "simmr_hip.h").read_text()
+    for needle in ("0x73696D6D", "0x72000003", "24 bits per base", "3g + {0, 1, 2}", "level 2", "oracle/philox.c"):
+        assert needle in text, needle
+    assert "one output word per base" not in text and "base index / 4" not in text
+    # the same constants in the specification's restatement and in the kernel
+    assert "0x73696D6D" in (ROOT / "oracle" / "philox.c").read_text().upper().replace("0X", "0x")
+    assert "0x73696D6Du" in (ROOT / "simmr_amd" / "csrc" / "kernels.hip").read_text()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r3/pmc_traffic.json from the PMC summaries of tools/profile_round.sh, stamped with the hash of the kernel
+"""profiles/r4/pmc_traffic.json from the PMC summaries of tools/profile_round.sh, stamped with the hash of the kernel
 sources it was collected from (bench.py reports its numbers only while that hash still matches).
 
 usage: tools/make_pmc_traffic.py <dir with pmc_default.txt [pmc_compact.txt pmc_perfect.txt pmc_custom_long.txt]>
@@ -50,14 +50,15 @@ def main():
     for name, key, workload in (("pmc_default.txt", "k_emit_philox_slot16", "bench.py default (minimal-short 150 bp PE, 100 Mbp, 100 M reads, counter mode, 16-byte read slots)"),
                                 ("pmc_compact.txt", "k_emit_philox", "bench.py --layout compact (the same run with byte streams without gaps)"),
                                 ("pmc_perfect.txt", "k_emit_perfect_pe", "bench.py --profile perfect-short"),
-                                ("pmc_custom_long.txt", "k_custom_long_splice", "bench.py --profile custom-long --reads 1000000")):
+                                ("pmc_custom_long.txt", "k_custom_long_splice", "bench.py --profile custom-long --reads 1000000"),
+                                ("pmc_through_fastq.txt", "k_emit_philox_text", "bench.py --through-fastq: the TEXT form of the counter-mode kernel (simmr_emit_fastq), its launches only")):
         f = src / name
         if f.exists():
             out[key] = record(read(f), workload, "separate --pmc passes of the bench command with --steps 1 --warmup 0 "
                                                  "(tools/profile_round.sh), per launch")
             if key in mixes:
                 out[key]["valu_class_mix"] = mixes[key]
-    dst = ROOT / "profiles" / "r3" / "pmc_traffic.json"
+    dst = ROOT / "profiles" / "r4" / "pmc_traffic.json"
     dst.parent.mkdir(parents=True, exist_ok=True)
     dst.write_text(json.dumps(out, indent=1) + "\n")
     print(dst, out["source_sha256"][:12])
