@@ -2455,7 +2455,17 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           if (n >= 16u) {  // the last window ends where the run ends (it overlaps its neighbour with the same bytes)
             if (piece * 16u < n) {
               const uint32_t w0 = (piece + 1u) * 16u <= n ? piece * 16u : n - 16u;
+#if defined(SIMMR_ABLATE_LINES)  /* timing only: the window stores of a wave as sixteen whole lines inside the text */
+              {
+                const uint64_t tot = off64[(n_reads + 63u) >> 6];
+                const uint64_t last = tot >= 1024u ? ((tot - 1024u) & ~1023ull) : 0u;
+                uint64_t a = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fq_run_at[i] >> 10)) << 10;
+                a = a < last ? a : last;
+                if (tot >= 1024u) *reinterpret_cast<v4u32*>(seq + a + 16u * (tix & 63u)) = fq_read16(sl, w0);
+              }
+#else
               *reinterpret_cast<v4u32_unaligned*>(d + w0) = (v4u32_unaligned)fq_read16(sl, w0);
+#endif
             }
           } else if (piece == 0u) {
             for (uint32_t j = 0; j < n; j++) d[j] = sl[j];
@@ -2650,7 +2660,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       // timing only: every 16-byte store instruction of a wave writes sixteen WHOLE 64-byte lines (the wave's first
       // lane's place rounded down to 1 KB, then lane by lane); wrong places, and clamped so that the 1 KB stays
       // inside the total_bases bytes of the streams (a shard of less than 1 KB writes nothing at all)
-      const uint64_t abl_total = coarse ? off64[(n_units + 63u) >> 6] : u_off[n_units];
+      const uint64_t abl_total = TEXT ? off64[(n_reads + 63u) >> 6] : (coarse ? off64[(n_units + 63u) >> 6] : u_off[n_units]);
       const uint64_t abl_last = abl_total >= 1024u ? ((abl_total - 1024u) & ~1023ull) : 0u;
       uint64_t abl_q = ((uint64_t)__builtin_amdgcn_readfirstlane(o_q) + out0) & ~1023ull;
       uint64_t abl_s = ((uint64_t)__builtin_amdgcn_readfirstlane(o_s) + out0) & ~1023ull;
@@ -2671,7 +2681,11 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       uint8_t* qd = qual_blk + o_q;
       uint8_t* sd = seq_blk + o_s;
 #endif
+#if !defined(SIMMR_ABLATE_LINES)
       if (TEXT && ci == 0u)  // "\n+\n" and, once more, the first quality
+#else
+      if (false)
+#endif
         *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(qd - 3) = 0x000a2b0au | ((uint32_t)q_lo << 24);
 #if defined(SIMMR_ABLATE_ALL16) && defined(SIMMR_ABLATE_LINES)
       if (true) {  // timing only (the clamped whole-line places above hold 16 bytes for every lane)
@@ -3229,7 +3243,22 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
 #pragma unroll
             for (uint32_t tt = 0; tt < 8u; tt++) {
               const uint32_t t = t8 + tt;
+              // (the words of this step are there whatever the refill below does: after the last one at least 17 were
+              // ready and 8 steps take 16)
+              const uint32_t cnt = s_cnt8[win];
+              const uint32_t zn = s_zone[cnt];
+              const uint32_t w1 = row[(wpos & 31u) * RS], w2 = row[((wpos + 1u) & 31u) * RS];
+              const uint64_t m = (uint64_t)w1 * cnt;
+              const bool hit = cnt - 1u < 254u;
+              // every lane loads (a lane that is not on a k-mer of the model: column 0 of its row, not used): a 32-bit
+              // byte offset from the table's base, so the address is one multiply-add away from the draw
+              const uint32_t c16 = hit ? (uint32_t)(m >> 32) << 4 : 0u;
+              const Rec16 rec = *reinterpret_cast<const Rec16*>(cols_bytes + (__umul24(win, stride16) + c16));
               if (tt == 0u) {
+                // The refill of the lanes' next block goes HERE, behind the first step's column load: its 600
+                // instructions run while that load — the longest link of the step's chain — is in flight (round 4;
+                // in front of the step it stood between two chains and overlapped nothing).
+                asm volatile("" ::: "memory");  // (the load stays in front of the refill; nothing waits for it here)
                 const bool need = have < (wpos >> 4) + 2u;  // then at least 17 words are ready: 8 steps take 16
                 if (__any(need)) {
                   if (need) {  // (inline: a call here makes everything that lives across the group callee-saved)
@@ -3242,15 +3271,6 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
                   }
                 }
               }
-              const uint32_t cnt = s_cnt8[win];
-              const uint32_t zn = s_zone[cnt];
-              const uint32_t w1 = row[(wpos & 31u) * RS], w2 = row[((wpos + 1u) & 31u) * RS];
-              const uint64_t m = (uint64_t)w1 * cnt;
-              const bool hit = cnt - 1u < 254u;
-              // every lane loads (a lane that is not on a k-mer of the model: column 0 of its row, not used): a 32-bit
-              // byte offset from the table's base, so the address is one multiply-add away from the draw
-              const uint32_t c16 = hit ? (uint32_t)(m >> 32) << 4 : 0u;
-              const Rec16 rec = *reinterpret_cast<const Rec16*>(cols_bytes + (__umul24(win, stride16) + c16));
               const float v12 = __uint_as_float((w2 >> 9) | 0x3F800000u);
               const float x = __fadd_rn(__fmul_rn(__fsub_rn(v12, 1.0f), __uint_as_float(rec.w)), 0.0f);
               const uint32_t alt = x < __uint_as_float(rec.x) ? rec.y : rec.z;
