@@ -422,10 +422,9 @@ def main():
                 "note": ("HBM-write bound data movement" if args.profile == "perfect-short" else
                          "see DESIGN.md section 4 (kernel table)" if (custom is not None or args.profile == "custom-short"
                                                                      or args.rng == "reference") else
-                         "see DESIGN.md section 4 (profiles/r2, profiles/r3): VALU issue is the first limiter (class-priced share in `valu`), "
-                         "the store path next to it; round 3 took the kernel from 13.1 to 10.4 ms with the 16-byte slot layout, "
-                         "nontemporal whole-line stores, mask tables instead of multiplies, and 128 workgroups per CU over sharded "
-                         "run counters"),
+                         "see DESIGN.md section 4: VALU issue is the first limiter (class-priced share in `valu`), the store path "
+                         "next to it; 16-byte read slots, nontemporal whole-line stores, 128 workgroups per CU over sharded run "
+                         "counters; LAB.md has the history"),
             },
         }
         valu = measured_valu(args, 2 * pairs_per_gpu, emit_avg_ms)

@@ -1923,6 +1923,23 @@ static int fq_prepare(simmr_engine* e, const char* header_format, const simmr_fa
   return SIMMR_OK;
 }
 
+// what the sizing kernels need of the compiled template (fastq_format.hpp: FqLenCoef)
+static FqLenCoef fq_len_coef(const FqTemplate& t) {
+  FqLenCoef c{0u, 0u, 0u, 0u, 0u, 0u};
+  for (uint32_t s = 0; s < t.n_segs; s++) {
+    switch (t.segs[s].kind) {
+      case FQ_LITERAL: c.h0 += t.segs[s].len; break;
+      case FQ_GENOME_ID: c.n_gid++; break;
+      case FQ_READ_ID: c.n_rid++; break;
+      case FQ_SEQUENCE_ID: c.n_sid++; break;
+      case FQ_START: c.n_start++; break;
+      case FQ_END: c.n_end++; break;
+      default: c.h0 += 1u; break;  // 't' / 'f', '1' / '2'
+    }
+  }
+  return c;
+}
+
 // bytes between the LDS header slots of neighbouring lanes: an ODD number of words, so that the 64 lanes of a wave,
 // each writing byte k of its own header, hit 64 different banks (a multiple of 16 bytes made every byte store a
 // 4-way bank conflict: SQ_LDS_BANK_CONFLICT was 70 % of the LDS-busy cycles of the header kernel)
@@ -1957,7 +1974,7 @@ int simmr_fastq_plan(simmr_engine* e, const char* header_format, const simmr_fas
   const FqReads rd{reads->seq, reads->qual, reads->seq_off, reads->start, reads->end, reads->contig, reads->genome,
                    reads->read_id, reads->flags, reads->slot_bytes == SIMMR_SLOT16 ? 1u : 0u};
   if (n_reads > 0)
-    hipLaunchKernelGGL(k_fastq_size, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, rd, n_reads,
+    hipLaunchKernelGGL(k_fastq_size, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, fq_len_coef(e->fq_tpl), tb, rd, n_reads,
                        e->fq_len.as<uint64_t>(), e->d_err.as<uint32_t>());
   uint64_t total = 0;
   if ((rc = scan_u64(e, e->fq_len, n_reads, e->fq_off, &total))) return rc;  // also waits for the uploads
@@ -2052,7 +2069,7 @@ int simmr_fastq_plan_direct(simmr_engine* e, const char* header_format, const si
   if (!coarse && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
   if (coarse && !e->w_bytes.ensure(std::max<uint64_t>(n_w, 1) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
   if (n_reads > 0)
-    hipLaunchKernelGGL(k_fastq_size_plan, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, fq_plan_view(e),
+    hipLaunchKernelGGL(k_fastq_size_plan, dim3(grid_for(n_reads, 256)), dim3(256), 0, e->stream, fq_len_coef(e->fq_tpl), tb, fq_plan_view(e),
                        n_reads, coarse ? (uint64_t*)nullptr : e->fq_len.as<uint64_t>(), e->fq_hlen.as<uint8_t>(), e->d_err.as<uint32_t>(), tiles,
                        coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr);
   uint64_t total = 0;

@@ -95,26 +95,19 @@ SIMMR_DEV uint32_t dec_digits(uint64_t v) {
   return n;
 }
 
-// bytes of the header of read r (without the '\n'); 0xffffffff if a table index is out of range
-// (the template is read through a pointer to device memory: indexing a by-value kernel argument with a loop counter
-// makes every thread copy the whole struct to scratch first — 58 GB of traffic per 100 M reads, 17 ms, measured)
-SIMMR_DEV uint32_t fq_header_len(const FqTemplate* __restrict__ tp, const FqTables& tb, const FqFields& f) {
+// A header's length without a walk over the template: the template's constant bytes and how often each field occurs
+// (the host fills this from the compiled template, engine.hip: fq_len_coef) — the sizing kernels were latency chains of
+// one scalar load per template piece and wave (1.3 ms per 100 M reads, 7 us per wave)
+struct FqLenCoef { uint32_t h0, n_gid, n_rid, n_sid, n_start, n_end; };
+SIMMR_DEV uint32_t fq_header_len(const FqLenCoef& c, const FqTables& tb, const FqFields& f) {
   const uint32_t g = f.genome;
   if (g >= tb.n_slots || f.contig >= tb.g_ncontig[g]) return 0xffffffffu;
-  uint32_t n = 0;
-  const uint32_t n_segs = tp->n_segs;
-  for (uint32_t s = 0; s < n_segs; s++) {
-    const FqSeg sg = tp->segs[s];
-    switch (sg.kind) {
-      case FQ_LITERAL: n += sg.len; break;
-      case FQ_GENOME_ID: n += tb.g_id_len[g]; break;
-      case FQ_READ_ID: n += dec_digits(f.read_id); break;
-      case FQ_SEQUENCE_ID: n += tb.c_len[tb.g_cbase[g] + f.contig]; break;
-      case FQ_START: n += dec_digits(f.start); break;
-      case FQ_END: n += dec_digits(f.end); break;
-      default: n += 1; break;  // 't' / 'f', '1' / '2'
-    }
-  }
+  uint32_t n = c.h0;
+  if (c.n_gid) n += c.n_gid * tb.g_id_len[g];
+  if (c.n_sid) n += c.n_sid * tb.c_len[tb.g_cbase[g] + f.contig];
+  if (c.n_rid) n += c.n_rid * dec_digits(f.read_id);
+  if (c.n_start) n += c.n_start * dec_digits(f.start);
+  if (c.n_end) n += c.n_end * dec_digits(f.end);
   return n;
 }
 

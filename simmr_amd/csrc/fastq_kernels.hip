@@ -26,7 +26,7 @@ namespace simmr {
 
 
 extern "C" __global__ void __launch_bounds__(256)
-k_fastq_size(const FqTemplate* __restrict__ tp, FqTables tb, FqReads rd, uint64_t n_reads, uint64_t* __restrict__ rec_len,
+k_fastq_size(FqLenCoef tp, FqTables tb, FqReads rd, uint64_t n_reads, uint64_t* __restrict__ rec_len,
              uint32_t* __restrict__ err) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n_reads) return;
@@ -42,7 +42,7 @@ k_fastq_size(const FqTemplate* __restrict__ tp, FqTables tb, FqReads rd, uint64_
 
 // The same from the plan (simmr_fastq_plan_direct); hlen[r] = the header's bytes, for the emit kernel that writes into the text.
 extern "C" __global__ void __launch_bounds__(256)
-k_fastq_size_plan(const FqTemplate* __restrict__ tp, FqTables tb, FqPlan pn, uint64_t n_reads, uint64_t* __restrict__ rec_len,
+k_fastq_size_plan(FqLenCoef tp, FqTables tb, FqPlan pn, uint64_t n_reads, uint64_t* __restrict__ rec_len,
                   uint8_t* __restrict__ hlen, uint32_t* __restrict__ err, unsigned long long* __restrict__ tile_bytes,
                   unsigned long long* __restrict__ wave_bytes) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
