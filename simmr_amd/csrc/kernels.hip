@@ -2224,7 +2224,6 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   // TEXT: off64[w] = first byte of record 64 w, and a block places its records with a scan of their lengths
   // (header + 1 + L + 3 + L + 1, fastq.rs:58-66) before anything else
   static_assert(!TEXT || COARSE, "the TEXT form places its own records");
-  constexpr bool tcoarse = TEXT;
   // COPY_ONLY with TEXT: perfect-short straight into FASTQ text (perfect_short.rs:42-44: every quality is 60): the copied
   // bases, a constant quality line, headers and counters as in the drawing form
   constexpr bool FULL = !COPY_ONLY || TEXT;  // this launch writes qualities, headers / metadata and all run counters
@@ -2251,9 +2250,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
   // item -> read, when the block has few enough items.  TEXT: the map lives in the dynamic LDS under the header slots —
   // the slots are dead once the block's headers are copied out (a barrier closes the header phase), the map is dead
   // until then — which is what lets 128 slots and four workgroups per CU fit (engine.hip sizes it: max of the two)
-  constexpr bool fq_shared_map = TEXT;
-  __shared__ uint8_t owner_static[fq_shared_map ? 1 : PHILOX_MAP_ITEMS];
-  uint8_t* const owner = fq_shared_map ? fq_slots : owner_static;
+  __shared__ uint8_t owner_static[TEXT ? 1 : PHILOX_MAP_ITEMS];
+  uint8_t* const owner = TEXT ? fq_slots : owner_static;
   __shared__ uint64_t cbase[CACHED ? PHILOX_CBASE : 1];
   // byte masks (0xff) of the first n bytes of 16; SLOT: a second row at +32 with the LAST n bytes (a reverse mate's live bytes)
   __shared__ uint4 nmask[SLOT ? 64 : 17];
@@ -2334,8 +2332,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     lds_barrier();  // the previous block's items are done with the records
     uint32_t g = 0;
     uint32_t n_items = 0, ex = 0;
-    uint64_t rec_place = 0;  // tcoarse: this thread's record, relative to the block's first
-    if (tcoarse) {
+    uint64_t rec_place = 0;  // TEXT: this thread's record, relative to the block's first
+    if (TEXT) {
       uint32_t L0 = 0, h0 = 0;
       const bool on = tix < nr;
       if (on) {
@@ -2473,8 +2471,8 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
         }
       }
     }
-    if (fq_shared_map) lds_barrier();  // the header slots are read out: their memory becomes the item map
-    if (tcoarse) {
+    if (TEXT) lds_barrier();  // the header slots are read out: their memory becomes the item map
+    if (TEXT) {
       // (scanned above)
     } else if (coarse) {  // the reads' places too: the scan of their (padded) lengths rides in the upper half
       uint64_t tot2;
@@ -2545,11 +2543,10 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
     // that load does not stand behind them in the in-order counter.  Only in the copy-only forms, which have nothing but
     // that wait between two items and registers to spare (the drawing forms gain nothing from it: LAB.md, round 3).
     constexpr bool prefetch = COPY_ONLY;
-    const uint32_t it_rank = threadIdx.x, it_stride = 256u, it_lo = 0u, it_hi = i_end;
     uint32_t r_next = 0;
     uint64_t raw_next = 0;
-    if (prefetch && it_lo + it_rank < it_hi) { r_next = locate(it_lo + it_rank); raw_next = plane_word(it_lo + it_rank, r_next); }
-    for (uint32_t item = it_lo + it_rank; item < it_hi; item += it_stride) {
+    if (prefetch && threadIdx.x < i_end) { r_next = locate(threadIdx.x); raw_next = plane_word(threadIdx.x, r_next); }
+    for (uint32_t item = threadIdx.x; item < i_end; item += 256u) {
       const uint32_t r = prefetch ? r_next : locate(item);
       const uint64_t raw = prefetch ? raw_next : plane_word(item, r);
       const uint4 ra = rec4[2 * r], rb = rec4[2 * r + 1];
@@ -2652,7 +2649,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
       // qualities are already offset-encoded, forward order
       const uint64_t q_lo = (uint64_t)qr[0] | ((uint64_t)qr[1] << 32), q_hi = (uint64_t)qr[2] | ((uint64_t)qr[3] << 32);
       const uint64_t s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32), s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
-      if (prefetch && item + it_stride < it_hi) { r_next = locate(item + it_stride); raw_next = plane_word(item + it_stride, r_next); }
+      if (prefetch && item + 256u < i_end) { r_next = locate(item + 256u); raw_next = plane_word(item + 256u, r_next); }
 #if defined(SIMMR_ABLATE_STORES)
       asm volatile("" :: "v"(q_lo), "v"(q_hi), "v"(s_lo), "v"(s_hi), "v"(o_q), "v"(o_s));  // alive, not stored
 #else

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End to end through the CLI on short reads: N reads of 150 bp PE on a 50 Mbp FASTA, FASTQ + TSVs to tmpfs / /dev/null.
-# usage: tools/cli_short_run.sh [reads] ; prints one line per error profile (process start to exit).
-reads="${1:-10000000}"
+# usage: tools/cli_short_run.sh [reads] [extra simmr-hip flags, e.g. "--rng philox"] ; prints one line per error profile (process start to exit).
+reads="${1:-10000000}"; extra="${2:-}"
 make -s -C simmr_amd/host
 python3 - <<'PY'
 import numpy as np
@@ -17,10 +17,10 @@ PY
 for prof in perfect-short minimal-short; do
   for dst in /dev/null /dev/shm/cli_out.fastq; do
     t0=$(date +%s%N)
-    timeout -k 10 300 simmr_amd/host/simmr-hip --genome-file /tmp/cli_genomes.tsv --output $dst --num-reads $reads --seed 42 --error-profile $prof > /tmp/cli_run.log 2>&1
+    timeout -k 10 300 simmr_amd/host/simmr-hip --genome-file /tmp/cli_genomes.tsv --output $dst --num-reads $reads --seed 42 --error-profile $prof $extra > /tmp/cli_run.log 2>&1
     rc=$?
     sz=$(stat -c %s $dst 2>/dev/null || echo 0)
-    echo "profile=$prof output=$dst exit=$rc reads=$reads bytes=$sz wall_ms=$(( ($(date +%s%N) - t0) / 1000000 ))"
+    echo "profile=$prof $extra output=$dst exit=$rc reads=$reads bytes=$sz wall_ms=$(( ($(date +%s%N) - t0) / 1000000 ))"
     rm -f /dev/shm/cli_out.fastq*
   done
 done
