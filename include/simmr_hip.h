@@ -74,6 +74,12 @@ enum simmr_profile_kind {
  *     level 2, only for the E of 2^24 cells (E = 118 at mean Phred 30) that the integer split leaves over: counter
  *       (b >> 2, 1, 0x73696D6D, 0x72000003), word b & 3, a 1024-column alias table over the residual law with 22-bit
  *       thresholds.
+ *   In rocRAND's terms (the library north_star names; tests/test_oracle_kat.py runs rocRAND's own engine class against
+ *   the specification): a read's draws are the stream of rocrand_state_philox4x32_10 after
+ *   rocrand_init(seed = the read's Phred seed, subsequence = 0x7200000373696D6D, offset = 4 * (c0 | c1 << 32), &state)
+ *   — level 1 reads it from offset 4 * 3g (twelve consecutive outputs per group), level 2 at offset
+ *   4 * ((b >> 2) | 1 << 32).  The kernels compute the same words with a hand-written round (two v_mad_u64_u32 and two
+ *   v_bitop3_b32) rather than through the library's state object.
  *   Every profile with per-base draws except the custom ones.  Positions, lengths and seeds still come from the
  *   reference's streams.  Statistical tolerance only (BASELINE.json north_star): the law is the reference's
  *   (minimal_short.rs:83-140), the bits are not. */

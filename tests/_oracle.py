@@ -35,6 +35,22 @@ def build():
     subprocess.check_call(["make", "-s", "-C", str(ROOT / "oracle")])
 
 
+_rr = None
+
+
+def load_rocrand_pin():
+    """oracle/librocrand_pin.so: rocRAND's own Philox4x32-10 engine class run on the host (oracle/rocrand_pin.hip)."""
+    global _rr
+    if _rr is None:
+        so = ROOT / "oracle" / "librocrand_pin.so"
+        if not so.exists():
+            build()
+        _rr = C.CDLL(str(so))
+        _rr.rr_philox_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+        _rr.rr_philox_block.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    return _rr
+
+
 def load():
     global _lib
     if _lib is not None:

@@ -189,6 +189,68 @@ def test_philox4x32_10_random123_vectors(oracle):
     assert np.abs(Pq - emp).max() < 1.5e-3
 
 
+@provenance("public third-party")
+def test_counter_mode_draws_are_the_rocrand_philox_stream(oracle):
+    """BASELINE.json's north_star names rocRAND's Philox for the per-base draws.  rocRAND's own engine class
+    (rocrand_device::philox4x32_10_engine, members __host__ __device__; oracle/rocrand_pin.hip runs it on the host)
+    yields the words of the counter mode's specification when it is seeded as include/simmr_hip.h says:
+    seed = the read's key, subsequence = 'simm' | 'r\\0\\0\\3' << 32, offset = 4 x the 64-bit counter (c0 | c1 << 32)."""
+    rr = _oracle.load_rocrand_pin()
+    SUB = 0x7200000373696D6D
+    rng = np.random.default_rng(7)
+
+    def spec_block(key64, c0, c1):
+        c = (C.c_uint32 * 4)(c0, c1, SUB & 0xffffffff, SUB >> 32)
+        k = (C.c_uint32 * 2)(key64 & 0xffffffff, key64 >> 32)
+        o = (C.c_uint32 * 4)()
+        oracle.orc_philox4x32_10(c, k, o)
+        return list(o)
+    # block by block, through rocrand_init / rocrand4 (the C-style device API): level-1 counters (3 g + c, 0) and
+    # level-2 counters (b >> 2, 1), random keys, counters up to 2^32 - 1
+    for _ in range(200):
+        key64 = int(rng.integers(0, 2 ** 64, dtype=np.uint64))
+        c0 = int(rng.integers(0, 2 ** 32, dtype=np.uint64))
+        for c1 in (0, 1):
+            o = (C.c_uint32 * 4)()
+            rr.rr_philox_block(key64, SUB, 4 * (c0 | (c1 << 32)), o)
+            assert list(o) == spec_block(key64, c0, c1), (hex(key64), c0, c1)
+    # a whole read: its level-1 bit string is the engine's stream from offset 0 (twelve words per 16 bases), its
+    # level-2 words the stream at offset 4 * ((b >> 2) | 1 << 32); decoded with the mode's tables they are the
+    # qualities and substitutions orc_philox_read makes
+    prof = MinimalShortErrorProfile().pod()  # mean Phred 30 (cli.rs:152)
+    t1, t2 = (C.c_uint64 * 1024)(), (C.c_uint32 * 1024)()
+    oracle.orc_philox_tables(prof.kind, prof.mean_phred, t1, t2)
+    n_esc = 0
+    for trial in range(7):
+        key64 = int(rng.integers(0, 2 ** 64, dtype=np.uint64))
+        L = [150, 1, 16, 17, 4000, 25000, 3_000_000][trial]  # (the last: long enough to meet level 2, 7e-6 per base)
+        seq = rng.integers(0, 4, L).astype(np.uint8)
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[seq].copy()
+        q_want, s_want = np.zeros(L, np.uint8), np.zeros(L, np.uint8)
+        oracle.orc_philox_read(C.byref(prof), seq.ctypes.data_as(C.c_void_p), C.c_uint64(L), C.c_uint64(key64),
+                               q_want.ctypes.data_as(C.c_void_p), s_want.ctypes.data_as(C.c_void_p))
+        n_words = 12 * ((L + 15) // 16)
+        words = np.zeros(n_words + 1, np.uint32)
+        rr.rr_philox_stream(key64, SUB, 0, n_words, words.ctypes.data_as(C.c_void_p))
+        bits = 24 * (np.arange(L) & 15) + 384 * (np.arange(L) >> 4)
+        win = words[bits >> 5].astype(np.uint64) | (words[(bits >> 5) + 1].astype(np.uint64) << np.uint64(32))
+        F = ((win >> (bits & 31).astype(np.uint64)) & np.uint64(0xffffff)).astype(np.int64)
+        e = np.array(list(t1), dtype=np.uint64)[F >> 14]
+        o = np.where((F & 0x3fff) < (e & np.uint64(0xffff)).astype(np.int64), ((e >> np.uint64(16)) & np.uint64(0xffff)).astype(np.int64),
+                     (e >> np.uint64(32)).astype(np.int64))
+        for b in np.nonzero(o == 1024)[0]:
+            n_esc += 1
+            w2 = (C.c_uint32 * 4)()
+            rr.rr_philox_block(key64, SUB, 4 * ((int(b) >> 2) | (1 << 32)), w2)
+            W = w2[int(b) & 3]
+            e2 = t2[W >> 22]
+            o[b] = (W >> 22) if (W & 0x3fffff) < (e2 & 0x3fffff) else (e2 >> 22)
+        assert np.array_equal((o & 0xff).astype(np.uint8), q_want), trial
+        code = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), seq)
+        assert np.array_equal(np.frombuffer(b"ACGT", dtype=np.uint8)[(code + (o >> 8)) & 3], s_want), trial
+    assert n_esc >= 5  # level 2 was exercised
+
+
 # ---- reference unit tests restated ------------------------------------------
 @provenance("reference-held")
 def test_util_tests_rs(oracle):
