@@ -123,8 +123,8 @@ def main():
         prof = custom.pod()  # `custom` owns the model bytes the POD points to
         prof.length_mode = _abi.LEN_PER_READ
         prof.long_start_mode = _abi.START_UNIFORM
-        args.rng = "reference"  # the empirical model has no counter mode
-        args.no_other_mode = True
+        # --rng philox (the default): the draws of the k-mer splice from Philox counters; qualities, lengths and positions are
+        # the reference mode's in both (include/simmr_hip.h, enum simmr_rng_mode)
     elif args.profile == "custom-short":
         from simmr_amd import CustomShortErrorProfile, model_io
         custom = CustomShortErrorProfile(model_io.synthetic_short_model())  # 120 modelled positions, lengths ~ N(140, 12)
@@ -271,7 +271,8 @@ def main():
             "rng": "reference StdRng streams (ChaCha12), bit-exact vs the reference algorithm" if args.rng == "philox"
                    else "Philox4x32-10 counter mode (tolerance parity)",
             "value": info.n_reads / dt, "unit": "reads/s", "ms_per_step": dt * 1e3,
-            "kernel": "k_emit_lanes" if args.rng == "philox" else "k_emit_philox", "kernel_ms": kms,
+            "kernel": ("k_custom_long_qual + k_custom_long_splice" + ("" if args.rng == "philox" else "<CTR>")) if custom is not None
+                      else "k_emit_lanes" if args.rng == "philox" else "k_emit_philox", "kernel_ms": kms,
             "steps": 1, "note": "one step after one warm-up step, same shard, outside the timed region",
         }
         prof.rng_mode = keep_mode
@@ -402,6 +403,8 @@ def main():
                 "limiter": ("hbm write path" if args.profile == "perfect-short" else
                             "per-lane table reads (address unit)" if args.profile == "custom-short" else
                             "latency of the dependent table load per visited k-mer at 4 waves per SIMD, and ChaCha12 issue"
+                            if (custom is not None and args.rng == "reference") else
+                            "the chain count -> draw -> column load of the sequential k-mer walk (one lane per read), and VALU issue"
                             if custom is not None else
                             "VALU issue (ChaCha12 and the per-base state machines of the reference's streams)"
                             if args.rng == "reference" else
@@ -410,7 +413,7 @@ def main():
                 "kernel": (("k_emit_philox<COPY_ONLY, TEXT>" if args.profile == "perfect-short" else "k_emit_philox<TEXT>") if args.through_fastq else
                            "k_emit_perfect_pe" if args.profile == "perfect-short" else
                            "k_emit_custom_pe" if args.profile == "custom-short" else
-                           "k_custom_long_qual + k_custom_long_splice" if custom is not None else
+                           "k_custom_long_qual + k_custom_long_splice" + ("<CTR>" if args.rng == "philox" else "") if custom is not None else
                            "k_emit_lanes" if args.rng == "reference" else "k_emit_philox"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
@@ -484,7 +487,8 @@ def _profile_record(args, reads_per_gpu, text=False):
             return (t.get("k_emit_philox_text"), None) if t.get("k_emit_philox_text") else (None, "not collected for k_emit_philox_text")
         return None, "the TEXT form's counters were collected for the default workload only"
     if args.profile == "custom-long" and reads_per_gpu == 1_000_000 and args.genome_bases == 100_000_000:
-        return t.get("k_custom_long_splice"), None
+        key = "k_custom_long_splice" if args.rng == "reference" else "k_custom_long_splice_ctr"
+        return (t.get(key), None) if t.get(key) else (None, f"not collected for {key}")
     if reads_per_gpu != 100_000_000 or args.genome_bases != 100_000_000:
         return None, "collected at 100 M reads on 100 Mbp only"
     if args.profile == "minimal-short" and args.rng == "philox":

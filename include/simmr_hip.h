@@ -80,8 +80,17 @@ enum simmr_profile_kind {
  *   — level 1 reads it from offset 4 * 3g (twelve consecutive outputs per group), level 2 at offset
  *   4 * ((b >> 2) | 1 << 32).  The kernels compute the same words with a hand-written round (two v_mad_u64_u32 and two
  *   v_bitop3_b32) rather than through the library's state object.
- *   Every profile with per-base draws except the custom ones.  Positions, lengths and seeds still come from the
- *   reference's streams.  Statistical tolerance only (BASELINE.json north_star): the law is the reference's
+ *   Every profile with per-base draws: minimal-short, minimal-long, perfect-long as above, and the long-read path of a
+ *   custom model (SIMMR_CUSTOM with an is_long model), whose base-by-base draws are those of the k-mer splice
+ *   (simulate_errors, custom_short.rs:455-516; its qualities use a handful of words per read and stay the reference's):
+ *     the alternate of the k-mer visited at position i is drawn from words A = 2 (i & 1) and B = 2 (i & 1) + 1 of the
+ *     block with key = the read's seed and counter (i >> 1, 2, 0x73696D6D, 0x72000003), in two levels over the
+ *     reference's law P(alternate j) = w_j / sum(w):  level 1, A >> 8 < T24 -> the k-mer stays what it is, with
+ *     T24 = min(floor(2^24 P(self)), 2^24 - 1);  level 2 otherwise, m = B * n (64 bits), column c = m >> 32 of an
+ *     n-column alias table over the residual law (thresholds in 2^24ths), fraction (m & 0xffffffff) >> 8.
+ *     (oracle/custom.c: ctr_splice_tables / orc_custom_simulate_errors_philox; the paired-end path of a custom model
+ *     has no base-by-base draws and refuses the mode.)
+ *   Positions, lengths and seeds still come from the reference's streams.  Statistical tolerance only (BASELINE.json north_star): the law is the reference's
  *   (minimal_short.rs:83-140), the bits are not. */
 enum simmr_rng_mode { SIMMR_RNG_REFERENCE = 0, SIMMR_RNG_PHILOX = 1 };
 

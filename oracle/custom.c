@@ -114,7 +114,8 @@ uint32_t orc_alias_sample(const orc_alias* a, orc_rng* r) {
 
 float orc_pairwise_sum_f32(const float* v, uint32_t n);
 /* WeightedAliasIndex<f32> one-shot: new(weights) then sample (custom_short.rs:497-503) */
-static int alias_f32_sample_once(const float* w, uint32_t n, orc_rng* r, uint32_t* out) {
+/* the conditions under which WeightedAliasIndex::<f32>::new(weights) is an Err (which the reference unwraps) */
+static int alias_f32_check(const float* w, uint32_t n, float* wsum_out) {
   if (n == 0) return -1;
   /* WeightedAliasIndex::new: every weight in [0, f32::MAX / n] (NaN fails), the sum clamped to f32::MAX, not 0 */
   const float maxw = 3.40282347e38f / (float)n;
@@ -122,6 +123,13 @@ static int alias_f32_sample_once(const float* w, uint32_t n, orc_rng* r, uint32_
   float wsum = orc_pairwise_sum_f32(w, n);
   if (wsum > 3.40282347e38f) wsum = 3.40282347e38f;
   if (wsum == 0.0f) return -2;
+  *wsum_out = wsum;
+  return 0;
+}
+static int alias_f32_sample_once(const float* w, uint32_t n, orc_rng* r, uint32_t* out) {
+  float wsum;
+  int chk = alias_f32_check(w, n, &wsum);
+  if (chk) return chk;
   float* odds = (float*)malloc(sizeof(float) * n);
   uint32_t* al = (uint32_t*)calloc(n, sizeof(uint32_t));
   const float nf = (float)n;
@@ -250,8 +258,63 @@ static int enc3(const uint8_t* k, uint64_t n, uint32_t* out) {
 
 /* CustomShortErrorProfile::simulate_errors (custom_short.rs:455-516): sequential, in-place splice.
  * out must hold len bytes; returns the new length (can only shrink) or < 0. */
-int64_t orc_custom_simulate_errors(const orc_model* m, const uint8_t* seq, uint64_t len, uint64_t seed, uint8_t* out) {
+/* The counter mode's draw of a visited k-mer's alternate: the specification (include/simmr_hip.h, enum simmr_rng_mode;
+ * the product builds the same tables in simmr_amd/csrc/custom_model.hpp).  The law is the reference's —
+ * P(alternate j) = w_j / sum(w) (custom_short.rs:497-503) — split in two levels so that the common outcome, "the k-mer
+ * stays what it is", needs no table:
+ *   level 1: p_s = P(an alternate equal to the k-mer itself) is cut at T24 = min(floor(2^24 p_s), 2^24 - 1) 2^24ths;
+ *   level 2: an alias table (Vose, n columns, thresholds in 2^24ths) over the residual law
+ *            r_j = (p_j - [j is self] (T24 / 2^24) p_j / p_s) / (1 - T24 / 2^24).
+ * All in f64, sums in list order.  A k-mer with an N has no "self" (its alternates with an N are errors, not draws). */
+static uint32_t ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t n, uint32_t self_code, int has_self,
+                                  uint32_t* thr, uint32_t* alias) {
+  double W = 0.0;
+  for (uint32_t j = 0; j < n; j++) W += (double)w[j];
+  double ps = 0.0;
+  if (has_self) for (uint32_t j = 0; j < n; j++) if (alt[j] == self_code) ps += (double)w[j] / W;
+  double t = floor(ps * 16777216.0);
+  if (t > 16777215.0) t = 16777215.0;
+  if (!(t >= 0.0)) t = 0.0;
+  const uint32_t T24 = (uint32_t)t;
+  const double lvl1 = (double)T24 / 16777216.0, rest = 1.0 - lvl1;
+  double* odds = (double*)malloc(sizeof(double) * (n ? n : 1));
+  for (uint32_t j = 0; j < n; j++) {
+    const double p = (double)w[j] / W;
+    double q = (has_self && alt[j] == self_code && ps > 0.0) ? p - lvl1 * (p / ps) : p;
+    if (q < 0.0) q = 0.0;
+    odds[j] = q / rest * (double)n;
+  }
+  uint32_t smalls = 0xFFFFFFFFu, bigs = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < n; i++) {
+    if (odds[i] < 1.0) { alias[i] = smalls; smalls = i; } else { alias[i] = bigs; bigs = i; }
+  }
+  while (smalls != 0xFFFFFFFFu && bigs != 0xFFFFFFFFu) {
+    const uint32_t sm = smalls; smalls = alias[sm];
+    const uint32_t g = bigs; bigs = alias[g];
+    alias[sm] = g;
+    odds[g] = odds[g] - 1.0 + odds[sm];
+    if (odds[g] < 1.0) { alias[g] = smalls; smalls = g; } else { alias[g] = bigs; bigs = g; }
+  }
+  while (smalls != 0xFFFFFFFFu) { const uint32_t sm = smalls; smalls = alias[sm]; odds[sm] = 1.0; alias[sm] = sm; }
+  while (bigs != 0xFFFFFFFFu) { const uint32_t g = bigs; bigs = alias[g]; odds[g] = 1.0; alias[g] = g; }
+  for (uint32_t c = 0; c < n; c++) {
+    double v = floor(odds[c] * 16777216.0 + 0.5);
+    if (v > 16777216.0) v = 16777216.0;
+    if (!(v >= 0.0)) v = 0.0;
+    thr[c] = (uint32_t)v;
+  }
+  free(odds);
+  return T24;
+}
+
+/* `philox` != 0: SIMMR_RNG_PHILOX for a custom long-read model — the walk is the reference's; the alternate of the k-mer
+ * visited at position i is drawn from words A = 2 (i & 1) and B = 2 (i & 1) + 1 of the Philox4x32-10 block with key =
+ * the read's seed and counter (i >> 1, 2, 'simm', 'r\0\0\3'): level 1  A >> 8 < T24 -> the k-mer itself;  otherwise level 2
+ * m = B * n (64 bits), column c = m >> 32, fraction f = (m & 0xffffffff) >> 8, alternate f < thr[c] ? c : alias[c].
+ * Tolerance parity: the law of every draw is the reference's, the bits are not. */
+static int64_t simulate_errors_walk(const orc_model* m, const uint8_t* seq, uint64_t len, uint64_t seed, uint8_t* out, int philox) {
   orc_rng r; orc_rng_seed_from_u64(&r, seed);
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
   memcpy(out, seq, len);
   uint64_t cur = len;
   const uint64_t k = m->kmer_size;
@@ -264,8 +327,36 @@ int64_t orc_custom_simulate_errors(const orc_model* m, const uint8_t* seq, uint6
     for (uint64_t j = 0; j < m->n_prob; j++) if (m->prob_kmer[j] == code) e = j; /* HashMap: last insert wins */
     if (e == m->n_prob) continue;
     uint32_t pick;
-    if (alias_f32_sample_once(m->prob_w[e], (uint32_t)m->prob_n[e], &r, &pick)) return -2;
-    uint32_t alt = m->prob_alt[e][pick];
+    uint32_t alt;
+    if (philox) {
+      const uint32_t n = (uint32_t)m->prob_n[e];
+      float wsum;
+      if (alias_f32_check(m->prob_w[e], n, &wsum)) return -2;  /* the same lists are unusable in both modes */
+      const uint32_t ctr[4] = {(uint32_t)(i >> 1), 2u, 0x73696D6Du, 0x72000003u};
+      uint32_t w4[4];
+      orc_philox4x32_10(ctr, key, w4);
+      const uint32_t A = w4[2 * (i & 1)], B = w4[2 * (i & 1) + 1];
+      int has_n = 0;
+      for (uint64_t j = 0; j < k; j++) has_n |= ((code >> (3 * j)) & 7u) == 4u;
+      uint32_t* thr = (uint32_t*)malloc(4 * n);
+      uint32_t* al = (uint32_t*)malloc(4 * n);
+      uint32_t* codes = (uint32_t*)malloc(4 * n);  /* what of an alternate is ever decoded: its first k fields */
+      const uint32_t kmask = k >= 10 ? 0x3fffffffu : ((1u << (3 * k)) - 1u);
+      for (uint32_t j = 0; j < n; j++) codes[j] = m->prob_alt[e][j] & kmask;
+      const uint32_t T24 = ctr_splice_tables(codes, m->prob_w[e], n, code, !has_n, thr, al);
+      free(codes);
+      if ((A >> 8) < T24) {
+        alt = code;
+      } else {
+        const uint64_t mm = (uint64_t)B * n;
+        const uint32_t c = (uint32_t)(mm >> 32), f = (uint32_t)mm >> 8;
+        alt = m->prob_alt[e][f < thr[c] ? c : al[c]];
+      }
+      free(thr); free(al);
+    } else {
+      if (alias_f32_sample_once(m->prob_w[e], (uint32_t)m->prob_n[e], &r, &pick)) return -2;
+      alt = m->prob_alt[e][pick];
+    }
     uint8_t dec[16]; uint64_t nd = 0;
     for (uint64_t j = 0; j < k; j++) {
       uint32_t v = (alt >> (3 * j)) & 7u;
@@ -278,6 +369,12 @@ int64_t orc_custom_simulate_errors(const orc_model* m, const uint8_t* seq, uint6
     cur = cur - k + nd;
   }
   return (int64_t)cur;
+}
+int64_t orc_custom_simulate_errors(const orc_model* m, const uint8_t* seq, uint64_t len, uint64_t seed, uint8_t* out) {
+  return simulate_errors_walk(m, seq, len, seed, out, 0);
+}
+int64_t orc_custom_simulate_errors_philox(const orc_model* m, const uint8_t* seq, uint64_t len, uint64_t seed, uint8_t* out) {
+  return simulate_errors_walk(m, seq, len, seed, out, 1);
 }
 
 /* ---------------------------------------------- CustomShortErrorProfile (custom_short.rs:155-543) */

@@ -200,6 +200,8 @@ int orc_custom_get_insert_size(const orc_custom* c, uint64_t seed, uint16_t* out
 uint16_t orc_custom_minimum_genome_size(const orc_custom* c);
 int orc_custom_simulate_phred_scores(const orc_custom* c, uint64_t len, uint64_t seed, uint8_t* out);
 int64_t orc_custom_simulate_errors(const orc_model* m, const uint8_t* seq, uint64_t len, uint64_t seed, uint8_t* out);
+/* the same walk with the counter mode's draws (SIMMR_RNG_PHILOX with a custom long-read model) */
+int64_t orc_custom_simulate_errors_philox(const orc_model* m, const uint8_t* seq, uint64_t len, uint64_t seed, uint8_t* out);
 double orc_gaussian_kde(double x, const double* xs, uint64_t n, double bandwidth);  /* custom_long.rs:36-44 */
 
 /* ---------------- SIMMR_RNG_PHILOX mode (philox.c): counter-based per-base draws */

@@ -654,8 +654,8 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
         /* :497 quality; :500 simulate_errors (the k-mer splice); :503 simulate_point_mutations = copy */
         r2 = orc_profile_simulate_phred_scores(p, n, u->read_seed, out->qual + o1);
         if (!r2) {
-          int64_t m = orc_custom_simulate_errors(orc_custom_model(custom_of(p)), G->seq[u->contig] + u->start, n,
-                                                 u->read_seed, out->seq + o1);
+          int64_t m = (p->rng_mode == SIMMR_RNG_PHILOX ? orc_custom_simulate_errors_philox : orc_custom_simulate_errors)(
+              orc_custom_model(custom_of(p)), G->seq[u->contig] + u->start, n, u->read_seed, out->seq + o1);
           /* < 0: the reference panics; < n: a deletion in the last k-mer leaves fewer bases than qualities */
           if (m != (int64_t)n) r2 = SIMMR_ERANGE;
         }

@@ -184,7 +184,58 @@ struct KmerTables {
   std::vector<uint8_t> cnt8;  // by 2-bit k-mer code: n alternates (0 = not in the model, 255 = unusable weights)
   std::vector<Rec16> cols;    // [code * stride + c]
   uint32_t stride = 0;        // 0 = no fixed-stride tables
+  // SIMMR_RNG_PHILOX (the counter mode's two-level draw, ctr_splice_tables below): direct[code].w = the level-1 threshold
+  // T24 of the k-mer; level-2 columns parallel to recs / cols: {threshold in 2^24ths, alternate c, alternate alias(c), -}
+  std::vector<Rec16> recs_ctr, cols_ctr;
+  std::vector<uint32_t> tab32;  // by 2-bit k-mer code: T24 << 8 | cnt8 (the fixed-stride form's LDS table)
 };
+
+// The counter mode's draw of a visited k-mer's alternate (include/simmr_hip.h, enum simmr_rng_mode; restated in
+// the test tree's CPU specification).  The law is the reference's — P(alternate j) = w_j / sum(w) — split in two levels so
+// that the common outcome, "the k-mer stays what it is", needs no table access:
+//   level 1: P(self) = p_s is cut at T24 = min(floor(2^24 p_s), 2^24 - 1) 2^24ths; a 24-bit draw below T24 answers "self";
+//   level 2 (the rest, 1 - T24 / 2^24 of the draws): an alias table (Vose, n columns, thresholds in 2^24ths) over the
+//   residual law r_j = (p_j - [j is self] (T24 / 2^24) p_j / p_s) / (1 - T24 / 2^24).
+// All in f64, sums in list order; `has_self` false for k-mers with an N (their alternates with an N are errors, not draws).
+inline uint32_t ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t n, uint32_t self_code, bool has_self,
+                                  uint32_t* thr, uint32_t* alias) {
+  double W = 0.0;
+  for (uint32_t j = 0; j < n; j++) W += (double)w[j];
+  double ps = 0.0;
+  if (has_self) for (uint32_t j = 0; j < n; j++) if (alt[j] == self_code) ps += (double)w[j] / W;
+  double t = floor(ps * 16777216.0);
+  if (t > 16777215.0) t = 16777215.0;
+  if (!(t >= 0.0)) t = 0.0;
+  const uint32_t T24 = (uint32_t)t;
+  const double lvl1 = (double)T24 / 16777216.0, rest = 1.0 - lvl1;
+  std::vector<double> odds(n);
+  for (uint32_t j = 0; j < n; j++) {
+    const double p = (double)w[j] / W;
+    double q = (has_self && alt[j] == self_code && ps > 0.0) ? p - lvl1 * (p / ps) : p;
+    if (q < 0.0) q = 0.0;
+    odds[j] = q / rest * (double)n;
+  }
+  uint32_t smalls = 0xFFFFFFFFu, bigs = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < n; i++) {
+    if (odds[i] < 1.0) { alias[i] = smalls; smalls = i; } else { alias[i] = bigs; bigs = i; }
+  }
+  while (smalls != 0xFFFFFFFFu && bigs != 0xFFFFFFFFu) {
+    const uint32_t sm = smalls; smalls = alias[sm];
+    const uint32_t g = bigs; bigs = alias[g];
+    alias[sm] = g;
+    odds[g] = odds[g] - 1.0 + odds[sm];
+    if (odds[g] < 1.0) { alias[g] = smalls; smalls = g; } else { alias[g] = bigs; bigs = g; }
+  }
+  while (smalls != 0xFFFFFFFFu) { const uint32_t sm = smalls; smalls = alias[sm]; odds[sm] = 1.0; alias[sm] = sm; }
+  while (bigs != 0xFFFFFFFFu) { const uint32_t g = bigs; bigs = alias[g]; odds[g] = 1.0; alias[g] = g; }
+  for (uint32_t c = 0; c < n; c++) {
+    double v = floor(odds[c] * 16777216.0 + 0.5);
+    if (v > 16777216.0) v = 16777216.0;
+    if (!(v >= 0.0)) v = 0.0;
+    thr[c] = (uint32_t)v;
+  }
+  return T24;
+}
 constexpr uint32_t KMER_FAST_MAX_K = 7;          // 4^7 bytes = 16 KB of LDS
 constexpr uint32_t KMER_FAST_MAX_STRIDE = 32;    // 4^7 * 32 * 16 B = 8 MB at most
 
@@ -234,6 +285,7 @@ inline bool build_kmer_tables(const ModelHost& m, KmerTables* t, std::string* er
   t->slots.assign(n_slots, Rec16{0xFFFFFFFFu, 0u, 0u, 0u});
   t->direct.assign((size_t)1 << (2 * K), Rec16{0u, 0u, 0u, 0u});
   t->recs.clear();
+  t->recs_ctr.clear();
   for (size_t e : last) {
     const uint32_t key = m.probabilities[e].first;
     if (key > kmask) continue;  // not the code of any k-mer of this size
@@ -287,17 +339,24 @@ inline bool build_kmer_tables(const ModelHost& m, KmerTables* t, std::string* er
                                 pack2(alts[al[c] < n ? al[c] : c].first & kmask), f32_to_bits(scale)});
     }
     const uint32_t p2 = pack2(key);
+    uint32_t t24 = 0;
+    if (ok) {  // the counter mode's tables of this k-mer
+      std::vector<uint32_t> codes(n), thr(n), al2(n);
+      for (uint32_t c = 0; c < n; c++) codes[c] = alts[c].first & kmask;
+      t24 = ctr_splice_tables(codes.data(), w.data(), n, key, !(p2 & 0x80000000u), thr.data(), al2.data());
+      for (uint32_t c = 0; c < n; c++) t->recs_ctr.push_back(Rec16{thr[c], pack2(codes[c]), pack2(codes[al2[c]]), 0u});
+    }
     if (!(p2 & 0x80000000u)) {
-      t->direct[p2] = Rec16{first, n_field, zone, 0u};
+      t->direct[p2] = Rec16{first, n_field, zone, t24};
     } else {
       uint32_t h = kmer_hash(key) & t->mask;
       while (t->slots[h].x != 0xFFFFFFFFu) h = (h + 1) & t->mask;
       t->slots[h] = Rec16{key, first, n_field, zone};
     }
   }
-  if (t->recs.empty()) t->recs.push_back(Rec16{0u, 0u, 0u, 0u});
+  if (t->recs.empty()) { t->recs.push_back(Rec16{0u, 0u, 0u, 0u}); t->recs_ctr.push_back(Rec16{0u, 0u, 0u, 0u}); }
   // fixed-stride copy of the direct entries' columns
-  t->cnt8.clear(); t->cols.clear(); t->stride = 0;
+  t->cnt8.clear(); t->cols.clear(); t->cols_ctr.clear(); t->tab32.clear(); t->stride = 0;
   if (K <= KMER_FAST_MAX_K) {
     uint32_t longest = 1;
     for (const Rec16& d : t->direct) if (d.y != 0xFFFFFFFFu && d.y > longest) longest = d.y;
@@ -305,11 +364,15 @@ inline bool build_kmer_tables(const ModelHost& m, KmerTables* t, std::string* er
       t->stride = longest;
       t->cnt8.assign(t->direct.size(), 0);
       t->cols.assign(t->direct.size() * (size_t)longest, Rec16{0u, 0u, 0u, 0u});
+      t->cols_ctr.assign(t->direct.size() * (size_t)longest, Rec16{0u, 0u, 0u, 0u});
+      t->tab32.assign(t->direct.size(), 0u);
       for (size_t code = 0; code < t->direct.size(); code++) {
         const Rec16& d = t->direct[code];
-        if (d.y == 0xFFFFFFFFu) { t->cnt8[code] = 255; continue; }
+        if (d.y == 0xFFFFFFFFu) { t->cnt8[code] = 255; t->tab32[code] = 255u; continue; }
         t->cnt8[code] = (uint8_t)d.y;
+        t->tab32[code] = (d.w << 8) | d.y;
         for (uint32_t c = 0; c < d.y; c++) t->cols[code * (size_t)longest + c] = t->recs[d.x + c];
+        for (uint32_t c = 0; c < d.y; c++) t->cols_ctr[code * (size_t)longest + c] = t->recs_ctr[d.x + c];
       }
     }
   }

@@ -75,6 +75,11 @@ struct CustomDev {
   const Rec16* kmer_cols;    // [code * kmer_stride + c], same records as kmer_recs
   uint32_t kmer_stride;
   uint32_t pad2;
+  // SIMMR_RNG_PHILOX (custom_model.hpp: ctr_splice_tables): kmer_direct[code].w = the k-mer's level-1 threshold T24;
+  // level-2 columns parallel to kmer_recs / kmer_cols: {threshold in 2^24ths, alternate c, alternate alias(c), -}
+  const Rec16* kmer_recs_ctr;
+  const Rec16* kmer_cols_ctr;
+  const uint32_t* kmer_tab32;  // by 2-bit k-mer code: T24 << 8 | n alternates (0 = absent, 255 = the reference panics); null without kmer_cols
 };
 
 // Device form of simmr_error_profile, with host-derived constants.

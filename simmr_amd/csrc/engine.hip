@@ -116,7 +116,7 @@ struct simmr_engine {
   // long-read runs
   DevBuf d_runs, d_usable;
   // custom profile tables
-  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, c_colrec, c_binrec, c_kslots, c_krecs, c_kdirect, c_kcnt8, c_kcols, ph_table;
+  DevBuf c_pdfs, c_odds, c_alias, c_low, c_range, c_zone, c_colrec, c_binrec, c_kslots, c_krecs, c_kdirect, c_kcnt8, c_kcols, c_krecs_ctr, c_kcols_ctr, c_ktab32, ph_table;
   // the custom model whose tables those buffers hold (make_custom_profile)
   bool custom_cached = false, custom_long = false;
   uint64_t custom_hash = 0, custom_bytes = 0;
@@ -354,11 +354,13 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
         (rc = upload_vec(e, e->c_kdirect, kt.direct)))
       return rc;
     if (kt.stride && ((rc = upload_vec(e, e->c_kcnt8, kt.cnt8)) || (rc = upload_vec(e, e->c_kcols, kt.cols)))) return rc;
+    if ((rc = upload_vec(e, e->c_krecs_ctr, kt.recs_ctr))) return rc;  // the counter mode's level-2 columns
+    if (kt.stride && ((rc = upload_vec(e, e->c_kcols_ctr, kt.cols_ctr)) || (rc = upload_vec(e, e->c_ktab32, kt.tab32)))) return rc;
   }
   if ((rc = sync_check(e, "custom table upload"))) return rc;  // the host vectors go out of scope
   ProfileDev d{};
   d.kind = SIMMR_K_CUSTOM;
-  d.rng_mode = SIMMR_RNG_REFERENCE;  // checked by the caller: the empirical PDFs have no counter mode
+  d.rng_mode = SIMMR_RNG_REFERENCE;  // (make_profile puts the caller's mode in: the tables are the same for both)
   // custom_short.rs:535-538: (2.0 * read_length_mean + insert_size_mean) as u16 (saturating)
   const double req = 2.0 * m.read_length_mean + m.insert_size_mean;
   d.required = !(req == req) || req <= 0.0 ? 0u : (req >= 65535.0 ? 65535u : (uint32_t)req);
@@ -385,6 +387,9 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
     d.custom.kmer_stride = kt.stride;
     d.custom.kmer_cnt8 = kt.stride ? e->c_kcnt8.as<uint8_t>() : nullptr;
     d.custom.kmer_cols = kt.stride ? e->c_kcols.as<Rec16>() : nullptr;
+    d.custom.kmer_recs_ctr = e->c_krecs_ctr.as<Rec16>();
+    d.custom.kmer_cols_ctr = kt.stride ? e->c_kcols_ctr.as<Rec16>() : nullptr;
+    d.custom.kmer_tab32 = kt.stride ? e->c_ktab32.as<uint32_t>() : nullptr;
   }
   e->custom_prof = d;
   e->custom_hash = mh;
@@ -401,9 +406,16 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
   if (!p) return e->fail(SIMMR_EINVAL, "profile is NULL");
   if (p->kind > SIMMR_CUSTOM) return e->fail(SIMMR_EINVAL, "unknown profile kind %u", p->kind);
   if (p->rng_mode > SIMMR_RNG_PHILOX) return e->fail(SIMMR_EINVAL, "unknown rng_mode %u", p->rng_mode);
-  if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_CUSTOM)
-    return e->fail(SIMMR_EINVAL, "SIMMR_RNG_PHILOX covers the Normal(mean, 10) Phred profiles (minimal-short, minimal-long)");
-  if (p->kind == SIMMR_CUSTOM) return make_custom_profile(e, p, want_long, out);
+  // a custom model has one place where draws are made base by base: the k-mer splice of its long-read path
+  // (simulate_errors, custom_short.rs:455-516; the qualities use the same few words at every position)
+  if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_CUSTOM && !want_long)
+    return e->fail(SIMMR_EINVAL, "SIMMR_RNG_PHILOX covers the profiles that draw base by base: minimal-short, minimal-long, "
+                                 "perfect-long and the k-mer splice of a custom long-read model");
+  if (p->kind == SIMMR_CUSTOM) {
+    const int rc = make_custom_profile(e, p, want_long, out);
+    if (rc == SIMMR_OK) out->rng_mode = p->rng_mode;  // (the cached tables serve both modes)
+    return rc;
+  }
   const bool is_long = p->kind == SIMMR_PERFECT_LONG || p->kind == SIMMR_MINIMAL_LONG;
   if (is_long != want_long)
     return e->fail(SIMMR_EINVAL, want_long ? "a short-read profile was passed to the long-read path"
@@ -994,7 +1006,7 @@ void simmr_engine_destroy(simmr_engine* e) {
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_qs2,
                     &e->u_ms2, &e->u_flags, &e->u_off, &e->scan_tmp, &e->o_last_idx, &e->o_wg_sums,
-                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->c_kslots, &e->c_krecs, &e->c_kdirect, &e->c_kcnt8, &e->c_kcols, &e->ph_table,
+                    &e->o_wg_prefix, &e->o_result, &e->d_runs, &e->d_usable, &e->u_order, &e->len_hist, &e->c_pdfs, &e->c_odds, &e->c_alias, &e->c_low, &e->c_range, &e->c_zone, &e->c_colrec, &e->c_binrec, &e->c_kslots, &e->c_krecs, &e->c_kdirect, &e->c_kcnt8, &e->c_kcols, &e->c_krecs_ctr, &e->c_kcols_ctr, &e->c_ktab32, &e->ph_table,
                     &e->fq_blob, &e->fq_gid_off, &e->fq_gid_len, &e->fq_cbase, &e->fq_ncontig, &e->fq_coff, &e->fq_clen,
                     &e->fq_len, &e->fq_off, &e->m_genomes, &e->m_contig, &e->m_seed, &e->w_bytes, &e->u_off64, &e->fq_off64};
   for (DevBuf* b : bufs) b->release();
@@ -1489,7 +1501,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->plan_genome, u_genome, e->plan_any_exc ? 1u : 0u, n_units, e->prof.read_length, pl,
                          e->u_contig.as<uint32_t>(), out->seq,
                          out->qual, 60u + out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
-    } else if (e->prof.rng_mode == SIMMR_RNG_PHILOX) {
+    } else if (e->prof.rng_mode == SIMMR_RNG_PHILOX && e->prof.kind != SIMMR_K_CUSTOM) {  // (a custom model's counter mode: below)
       bool exc = false;
       if (paired) exc = e->plan_any_exc;
       else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
@@ -1557,7 +1569,20 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->d_err.as<uint32_t>());
       bool fast = e->prof.custom.kmer_stride != 0;
       if (e->splice_variant == 1) fast = false;  // the two-load kernel (A/B timing)
-      if (fast) {
+      if (e->prof.rng_mode == SIMMR_RNG_PHILOX) {
+        // the counter mode of the splice (kernels.hip section 9c, CTR): the LDS holds one word per k-mer (4^k words);
+        // with k = 7 (64 KB) two workgroups of 768 lanes share a CU — six waves per SIMD, what the kernel's registers allow —
+        // with smaller tables 256-lane workgroups do
+        auto kern = fast ? (exc ? k_custom_long_splice<true, true, true> : k_custom_long_splice<false, true, true>)
+                         : (exc ? k_custom_long_splice<true, false, true> : k_custom_long_splice<false, false, true>);
+        const uint32_t lds = fast ? splice_ctr_lds_bytes(e->prof.custom.kmer_size) : 0u;
+        const uint32_t lanes = lds > 16384u ? SPLICE_CTR_LANES_MAX : 256u;
+        // (many more workgroups than are resident: reads come longest first, and the tail of the launch is short ones)
+        const uint32_t cgrid = (uint32_t)std::min<uint64_t>((n_reads + lanes - 1) / lanes, (uint64_t)e->n_cu * 64 * e->custom_long_mult);
+        hipLaunchKernelGGL(kern, dim3(cgrid), dim3(lanes), lds, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), n_units, order,
+                           pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
+                           e->u_seed.as<uint64_t>(), out->seq, counters, e->d_err.as<uint32_t>());
+      } else if (fast) {
         // one workgroup of 1024 lanes per CU around the LDS count table (kernels.hip section 9c)
         auto kern = exc ? k_custom_long_splice<true, true> : k_custom_long_splice<false, true>;
         const uint32_t lds = splice_fast_lds_bytes(e->prof.custom.kmer_size);
@@ -1763,7 +1788,8 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
     }
   }
   e->plan_sorted = false;
-  if (e->emit_variant == 0 && prof.rng_mode == SIMMR_RNG_REFERENCE && (rc = sort_by_length(e, count, 6))) return rc;
+  // (the lane-per-read kernels: the reference's streams, and a custom model in either mode)
+  if (e->emit_variant == 0 && (prof.rng_mode == SIMMR_RNG_REFERENCE || prof.kind == SIMMR_K_CUSTOM) && (rc = sort_by_length(e, count, 6))) return rc;
   if ((rc = scan_offsets(e, count, 1u, &total, slot_round))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;

@@ -3113,33 +3113,55 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
 // then column) — the kernel is bound by that chain and by the rate of per-lane line requests, not by arithmetic.  One
 // workgroup of 1024 lanes per CU then shares the 16 KB count table: LDS = word rows [32][1024] (word-major: lanes
 // of a wave in consecutive banks whatever word each is at) + the Uniform(0, n) zones + the counts.
+//
+// CTR: SIMMR_RNG_PHILOX with a custom long-read model (include/simmr_hip.h; restated on the CPU by the test tree:
+// orc_custom_simulate_errors_philox).  The walk is the same; a visited k-mer's alternate is drawn from two words of
+// Philox4x32-10 keyed by the read's seed — position i takes words A = 2 (i & 1) and B = 2 (i & 1) + 1 of the block with
+// counter (i >> 1, 2, 'simm', 'r\0\0\3') — in TWO LEVELS (custom_model.hpp: ctr_splice_tables): A >> 8 below the
+// k-mer's threshold T24 answers "the k-mer stays what it is" without any table access; only the rest (the model's error
+// rate: a tenth of the visited k-mers) goes to an alias column, chosen and resolved by B.  That is the point of the mode:
+// the reference's draw needs its column for EVERY visited k-mer, sixty-four different cache lines per wave-step, and the
+// reference-mode kernel is bound by exactly that (the same kernel with Philox words but the reference's one-level draw
+// took the same 86 ms per 20 Gbases; with one lane in ten loading, 43: profiles/r4/ab_splice_ctr_*.log).  Nothing of a
+// stream is kept either: no LDS rows (the reference mode's 128 KB per workgroup), no refill in the middle of a chain, no
+// position to take back; the LDS holds T24 << 8 | count per k-mer (4^k words).
 constexpr uint32_t SPLICE_FAST_LANES = 1024u;
 __host__ __device__ inline uint32_t splice_fast_lds_bytes(uint32_t k) { return 32u * SPLICE_FAST_LANES * 4u + 256u * 4u + (1u << (2u * k)); }
-template <bool HAS_EXC, bool FAST>
-__global__ void __launch_bounds__(FAST ? 1024 : 256)
+__host__ __device__ inline uint32_t splice_ctr_lds_bytes(uint32_t k) { return 4u << (2u * k); }
+constexpr uint32_t SPLICE_CTR_LANES_MAX = 768u;  // two workgroups of 768 beside each other when the table takes 64 KB (k = 7)
+template <bool HAS_EXC, bool FAST, bool CTR = false>
+#if !defined(SPLICE_CTR_WAVES)
+#define SPLICE_CTR_WAVES 1  /* waves per SIMD asked of the compiler for the counter mode's instantiations (1: whatever it finds) */
+#endif
+__global__ void __launch_bounds__(CTR ? SPLICE_CTR_LANES_MAX : (FAST ? 1024 : 256), CTR ? SPLICE_CTR_WAVES : 1)
 k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint64_t n_units,
                      const uint32_t* __restrict__ order, PlanArrays pl,
                      const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
                      const uint32_t* __restrict__ u_genome, const uint64_t* __restrict__ u_seed,
                      uint8_t* __restrict__ seq, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err) {
-  constexpr uint32_t NT = FAST ? SPLICE_FAST_LANES : 256u;
-  constexpr uint32_t RS = FAST ? SPLICE_FAST_LANES : 1u;  // distance between two words of a lane's row
-  __shared__ uint32_t words[FAST ? 1 : 256][33];  // per lane: two blocks of its stream
-  extern __shared__ uint32_t splice_lds[];        // FAST: rows, zones, counts
+  const uint32_t NT = CTR ? blockDim.x : (FAST ? SPLICE_FAST_LANES : 256u);
+  constexpr uint32_t RS = (FAST && !CTR) ? SPLICE_FAST_LANES : 1u;  // distance between two words of a lane's row
+  __shared__ uint32_t words[(FAST || CTR) ? 1 : 256][33];  // per lane: two blocks of its stream
+  extern __shared__ uint32_t splice_lds[];        // FAST: rows, zones, counts (CTR: the counts)
   const CustomDev C = prof.custom;
   const uint32_t K = C.kmer_size;  // 1..10 (checked on the host)
   uint32_t n_acgt = 0, n_subst = 0;
   bool bad_kmer = false;
-  lds_u32* const row = (lds_u32*)(FAST ? splice_lds + threadIdx.x : words[threadIdx.x]);
-  const uint32_t* const s_zone = splice_lds + 32u * SPLICE_FAST_LANES;
-  const uint8_t* const s_cnt8 = reinterpret_cast<const uint8_t*>(s_zone + 256);
-  if (FAST) {
-    uint32_t* zone_w = splice_lds + 32u * SPLICE_FAST_LANES;
-    if (threadIdx.x < 256u) {
+  lds_u32* const row = (lds_u32*)(FAST ? splice_lds + threadIdx.x : words[CTR ? 0u : threadIdx.x]);  // (CTR: not used)
+  const uint32_t* const s_zone = splice_lds + (CTR ? 0u : 32u * SPLICE_FAST_LANES);
+  const uint8_t* const s_cnt8 = reinterpret_cast<const uint8_t*>(s_zone + (CTR ? 0u : 256u));
+  const uint32_t* const s_tab = splice_lds;  // CTR: T24 << 8 | count
+  if (FAST && CTR) {
+    const uint32_t n_w = 1u << (2u * K);
+    for (uint32_t w = threadIdx.x; w < n_w; w += NT) splice_lds[w] = C.kmer_tab32[w];
+    __syncthreads();
+  } else if (FAST) {
+    uint32_t* zone_w = splice_lds + (CTR ? 0u : 32u * SPLICE_FAST_LANES);
+    if (!CTR && threadIdx.x < 256u) {
       const uint32_t c = threadIdx.x;  // Uniform::new(0u32, c): the largest accepted low word
       zone_w[c] = c ? 0xFFFFFFFFu - (uint32_t)((0x100000000ULL - c) % c) : 0u;
     }
-    uint32_t* cnt_w = zone_w + 256;
+    uint32_t* cnt_w = zone_w + (CTR ? 0u : 256u);
     const uint32_t n_w = (1u << (2u * K)) >> 2;  // 4^K bytes
     const uint32_t* src_w = reinterpret_cast<const uint32_t*>(C.kmer_cnt8);
     for (uint32_t w = threadIdx.x; w < n_w; w += NT) cnt_w[w] = src_w[w];
@@ -3161,8 +3183,9 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
       src0 = G->contigs[u_contig[u]].base + pl.a[u];
       seed = u_seed[u];  // read_seed re-seeds every per-read generator (simulate.rs:497-503)
     }
-    const Key key = pcg32_expand(seed);
-    refill_words(key, 0, row, RS);
+    const Key key = CTR ? Key{} : pcg32_expand(seed);
+    if (!CTR) refill_words(key, 0, row, RS);
+    const uint32_t pk0 = (uint32_t)seed, pk1 = (uint32_t)(seed >> 32);  // CTR: the Philox key
     // ---- simulate_errors
     {
       // StdRng(read_seed): the row holds two blocks of the stream, block b at words (b & 1) * 16.  Every 8
@@ -3195,28 +3218,33 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
       // FAST: the source bases come 256 at a time (17 words, shifted to the lane's bit offset once): a lane's loads
       // then touch every 64-byte line of its stretch about twice instead of sixteen times — the lines do not survive in
       // L2 between two loads of a lane (75 GB fetched per 20 Gbases with one 8-byte load per group)
-      uint32_t sw[FAST ? 16 : 1];
+      // (CTR: 64 at a time — four words live instead of sixteen; its workgroups are 256 lanes, eight or more per CU)
+#if !defined(SPLICE_CTR_SRC_WORDS)
+#define SPLICE_CTR_SRC_WORDS 4
+#endif
+      constexpr uint32_t SW = !FAST ? 1u : (CTR ? (uint32_t)SPLICE_CTR_SRC_WORDS : 16u);
+      uint32_t sw[SW];
       for (uint32_t i0 = 0; __any(i0 < n); i0 += 16u) {
         // the 16 source bases that enter the window during this group: positions i0 + K .. i0 + K + 15
         // (at most K + 31 bases past the read, K + 271 with the 256-base chunks: inside the plane's back padding)
         uint32_t s16;
         if (FAST) {
-          if ((i0 & 255u) == 0u && i0 < n) {
+          if ((i0 & (16u * SW - 1u)) == 0u && i0 < n) {
             const int64_t p = (int64_t)(src0 + i0 + K);
             const __attribute__((address_space(1))) uint32_t* q = (const __attribute__((address_space(1))) uint32_t*)(packed + (p >> 4));
             const uint32_t sh = 2u * (uint32_t)(p & 15);
             uint32_t prev = q[0];
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
+            for (int j = 0; j < (int)SW; j++) {
               const uint32_t next = q[j + 1];
               sw[j] = __builtin_amdgcn_alignbit(next, prev, sh);
               prev = next;
             }
           }
-          const uint32_t g = (i0 >> 4) & 15u;  // the same for every lane: one indexed register read
+          const uint32_t g = (i0 >> 4) & (SW - 1u);  // the same for every lane: one indexed register read
           s16 = sw[0];
 #pragma unroll
-          for (uint32_t j = 1; j < 16u; j++) s16 = g == j ? sw[FAST ? j : 0] : s16;
+          for (uint32_t j = 1; j < SW; j++) s16 = g == j ? sw[FAST ? j : 0] : s16;
         } else {
           s16 = i0 < n ? fetch_codes16(packed, (int64_t)(src0 + i0 + K)) : 0u;
         }
@@ -3232,9 +3260,47 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
           if (__all(inside)) {
             const uint32_t win_0 = win, owin_0 = owin, wpos_0 = wpos, subst_0 = n_subst;
             const uint32_t kmask2 = (1u << (2u * K)) - 1u;
-            const char* const cols_bytes = reinterpret_cast<const char*>(C.kmer_cols);
+            const char* const cols_bytes = reinterpret_cast<const char*>(CTR ? C.kmer_cols_ctr : C.kmer_cols);
             const uint32_t stride16 = C.kmer_stride << 4;
             bool rare = false;
+            if (CTR) {
+              // The counter mode's group as a ROLLED loop over its eight step pairs (one Philox block each): nothing but
+              // the window, the output register and one block lives across a pair, so the kernel fits the registers
+              // of eight waves per SIMD — what hides the chain count -> draw -> column load is other waves, not steps of
+              // the same wave in flight.  The 16 output bytes ride in a 128-bit shift register (the step number is not
+              // a compile-time constant here).
+              uint32_t o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u, sbits = s16;
+#pragma nounroll
+              for (uint32_t pp = 0; pp < 8u; pp++) {
+                uint32_t bw[4];
+                philox4x32_10((i0 >> 1) + pp, 2u, pk0, pk1, bw);  // (i0 is a multiple of 16)
+#pragma unroll
+                for (uint32_t h = 0; h < 2u; h++) {
+                  const uint32_t e32 = s_tab[win];
+                  const uint32_t cnt = e32 & 0xffu;
+                  // level 1: A >> 8 < T24  <=>  A < T24 << 8; level 2 only for a k-mer of the model that did not stay
+                  const bool lvl2 = (cnt - 1u < 254u) & (bw[2u * h] >= (e32 & 0xffffff00u));
+                  if (lvl2) {
+                    const uint64_t m = (uint64_t)bw[2u * h + 1u] * cnt;
+                    const Rec16 rec = *reinterpret_cast<const Rec16*>(cols_bytes + (__umul24(win, stride16) + ((uint32_t)(m >> 32) << 4)));
+                    const uint32_t alt = ((uint32_t)m >> 8) < rec.x ? rec.y : rec.z;
+                    rare = rare | ((int32_t)alt < 0);
+                    win = alt & kmask2;
+                  }
+                  rare = rare | (cnt == 255u);
+                  const uint32_t code = win & 3u;
+                  const uint32_t ch = __builtin_amdgcn_perm(0u, 0x54474341u, code | 0x0c0c0c00u);  // "ACGT"[code]
+                  o0 = __builtin_amdgcn_alignbyte(o1, o0, 1u); o1 = __builtin_amdgcn_alignbyte(o2, o1, 1u);
+                  o2 = __builtin_amdgcn_alignbyte(o3, o2, 1u); o3 = (o3 >> 8) | (ch << 24);
+                  n_subst += code != (owin & 3u) ? 1u : 0u;
+                  const uint32_t c2 = (sbits & 3u) << top2;
+                  sbits >>= 2;
+                  win = (win >> 2) | c2;
+                  owin = (owin >> 2) | c2;
+                }
+              }
+              out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3;
+            } else
 #pragma nounroll
             for (uint32_t t8 = 0; t8 < 16u; t8 += 8u) {
 #pragma unroll
@@ -3301,7 +3367,7 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
         if (todo) {
         auto general_step = [&](const uint32_t t) {
           const uint32_t i = i0 + t;
-          if ((t & 7u) == 0u) {
+          if (!CTR && (t & 7u) == 0u) {
             const bool need = i < n && have < (wpos >> 4) + 2u;
             if (__any(need)) {
               if (need) { refill_words(key, have, row + (have & 1u) * 16u * RS, RS); have++; }
@@ -3311,16 +3377,18 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
             // three_bit_encode_kmer fails on anything but ACGTN (encoding.rs:149-176): a '-' skips the k-mer
             if (i + K <= n && !dead && (!HAS_EXC || dm == 0u)) {
               uint32_t first = 0, cnt = 0, zone = 0;
-              const Rec16* recs = C.kmer_recs;
+              uint32_t t24s = 0u;  // CTR: the k-mer's level-1 threshold << 8 (a k-mer with an N has none)
+              const Rec16* recs = CTR ? C.kmer_recs_ctr : C.kmer_recs;
               if ((!HAS_EXC || nm == 0u) && FAST) {
-                cnt = s_cnt8[win];
-                zone = s_zone[cnt];
-                recs = C.kmer_cols;
+                if (CTR) { const uint32_t e32 = s_tab[win]; cnt = e32 & 0xffu; t24s = e32 & 0xffffff00u; }
+                else { cnt = s_cnt8[win]; zone = s_zone[cnt]; }
+                recs = CTR ? C.kmer_cols_ctr : C.kmer_cols;
                 first = win * C.kmer_stride;
                 if (cnt == 255u) cnt = 0xFFFFFFFFu;
               } else if (!HAS_EXC || nm == 0u) {
                 const Rec16 d = C.kmer_direct[win];
                 first = d.x; cnt = d.y; zone = d.z;
+                t24s = d.w << 8;
               } else {
                 uint32_t key3 = 0;  // the model's code of a k-mer with an N
                 for (uint32_t j = 0; j < K; j++)
@@ -3333,15 +3401,29 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
               if (cnt == 0xFFFFFFFFu) {
                 bad_kmer = true; dead = true;  // WeightedAliasIndex::new(..).unwrap() panics
               } else if (cnt != 0u) {
-                uint32_t c;
-                for (;;) {  // uniform_index.sample
-                  const uint64_t m = (uint64_t)next_word() * cnt;
-                  if ((uint32_t)m <= zone) { c = (uint32_t)(m >> 32); break; }
+                uint32_t alt;
+                if (CTR) {
+                  uint32_t gw[4];
+                  philox4x32_10(i >> 1, 2u, pk0, pk1, gw);
+                  const uint32_t A = (i & 1u) ? gw[2] : gw[0], B = (i & 1u) ? gw[3] : gw[1];
+                  if (A < t24s) {
+                    alt = win;  // level 1: the k-mer stays what it is
+                  } else {
+                    const uint64_t m = (uint64_t)B * cnt;
+                    const Rec16 rec = recs[first + (uint32_t)(m >> 32)];
+                    alt = ((uint32_t)m >> 8) < rec.x ? rec.y : rec.z;
+                  }
+                } else {
+                  uint32_t c;
+                  for (;;) {  // uniform_index.sample
+                    const uint64_t m = (uint64_t)next_word() * cnt;
+                    if ((uint32_t)m <= zone) { c = (uint32_t)(m >> 32); break; }
+                  }
+                  const Rec16 rec = recs[first + c];
+                  const float v12 = __uint_as_float((next_word() >> 9) | 0x3F800000u);
+                  const float x = __fadd_rn(__fmul_rn(__fsub_rn(v12, 1.0f), __uint_as_float(rec.w)), 0.0f);
+                  alt = x < __uint_as_float(rec.x) ? rec.y : rec.z;
                 }
-                const Rec16 rec = recs[first + c];
-                const float v12 = __uint_as_float((next_word() >> 9) | 0x3F800000u);
-                const float x = __fadd_rn(__fmul_rn(__fsub_rn(v12, 1.0f), __uint_as_float(rec.w)), 0.0f);
-                const uint32_t alt = x < __uint_as_float(rec.x) ? rec.y : rec.z;
                 if (alt & 0x80000000u) { bad_kmer = true; dead = true; }  // an N = a deletion, 5-7 = decode error
                 else { win = alt; nm = 0u; }
               }

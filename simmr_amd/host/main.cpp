@@ -414,7 +414,9 @@ static int run_main(int argc, char** argv) {
 
   simmr_error_profile pod = eprofile->pod();
   if (args.rng_philox) {  // (extension) the counter mode, for the profiles that draw per base from a parametric law
-    if (pod.kind == SIMMR_CUSTOM) return die("--rng philox is not defined for a custom (empirical) error profile");
+    // (a custom model draws base by base only in the k-mer splice of its long-read path: include/simmr_hip.h)
+    if (pod.kind == SIMMR_CUSTOM && !is_long)
+      return die("--rng philox is not defined for custom-short: its qualities are not drawn base by base and it edits no bases");
     if (pod.kind != SIMMR_PERFECT_SHORT) pod.rng_mode = SIMMR_RNG_PHILOX;  // (perfect-short draws nothing per base)
   }
   const int has_seed = args.seed ? 1 : 0;

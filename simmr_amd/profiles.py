@@ -138,15 +138,18 @@ class CustomShortErrorProfile(ErrorProfile):
     file's bytes; they are handed to the library, which builds the alias tables."""
     kind = _abi.CUSTOM
 
-    def __init__(self, model: bytes):
+    def __init__(self, model: bytes, rng_mode: int = _abi.RNG_REFERENCE):
         import ctypes
         self.model = bytes(model)
         self._buf = ctypes.create_string_buffer(self.model, len(self.model))
+        # RNG_PHILOX: the draws of the k-mer splice (simulate_errors) from Philox counters; long-read models only
+        self.rng_mode = rng_mode
 
     def pod(self):
         import ctypes
         p = ErrorProfilePOD()
         p.kind = self.kind
+        p.rng_mode = self.rng_mode
         p.custom_model = ctypes.cast(self._buf, ctypes.c_void_p).value
         p.custom_model_bytes = len(self.model)
         return p

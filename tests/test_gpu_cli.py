@@ -109,8 +109,11 @@ def test_cli_long_fastq_bytes(workdir, oracle):
     assert out.read_bytes() == bytes(expected)
 
 
-def test_cli_custom_long_with_abundances(workdir, oracle):
-    """BASELINE config 5 in small: a simmrd long-read model, a genome TSV with abundances, the long-read path
+@pytest.mark.parametrize("rng", ["reference", "philox"])
+def test_cli_custom_long_with_abundances(workdir, oracle, rng):
+    """(rng = philox: `--rng philox`, the splice's draws from Philox counters — the file is then the mode's specification,
+    oracle/custom.c: orc_custom_simulate_errors_philox, framed as FASTQ.)
+    BASELINE config 5 in small: a simmrd long-read model, a genome TSV with abundances, the long-read path
     (`custom-long` is an extension of this CLI: the reference's enum has no value that reaches
     CustomShortErrorProfile::simulate_errors, cli.rs:62-70, main.rs:30-33)."""
     from simmr_amd import CustomShortErrorProfile
@@ -124,8 +127,9 @@ def test_cli_custom_long_with_abundances(workdir, oracle):
     fmt = "@{:read_id:} {:genome_id:}|{:sequence_id:}|{:start_position:}|{:end_position:}"
     subprocess.check_call([str(EXE), "--genome-file", str(d / "abund.tsv"), "--output", str(out), "--num-reads", "41",
                            "--seed", "19", "--error-profile", "custom-long", "--custom-profile", str(d / "long_model.bin"),
-                           "--abundance-profile", "custom", "--read-header-format", fmt])
-    prof = CustomShortErrorProfile(blob)
+                           "--abundance-profile", "custom", "--read-header-format", fmt] + (["--rng", "philox"] if rng == "philox" else []))
+    from simmr_amd import _abi
+    prof = CustomShortErrorProfile(blob, _abi.RNG_PHILOX if rng == "philox" else _abi.RNG_REFERENCE)
     required = 2 * 3750  # custom_short.rs:535-538 with the model's means (3750, 0)
     hosts, names_all = [], []
     for contigs, names in genomes:

@@ -297,7 +297,7 @@ def test_philox_mode_exceptions(engine, oracle):
     from tests import _model
     keep = CustomShortErrorProfile(_model.synthetic_short_model(n_positions=40, seed=5))
     cp = keep.pod()
-    cp.rng_mode = _abi.RNG_PHILOX  # empirical PDFs have no counter mode
+    cp.rng_mode = _abi.RNG_PHILOX  # the paired-end path of a custom model has no base-by-base draws: no counter mode
     with pytest.raises(SimmrError) as ei:
         engine.pe_plan(3, cp, 10, 1)
     assert ei.value.code == _abi.EINVAL
@@ -401,14 +401,20 @@ def test_custom_short_rejects_bad_models(engine, genome_multi):
     assert ei.value.code == _abi.ERANGE
 
 
-# custom model on the long-read path: empirical qualities + the k-mer splice of simulate_errors
+# custom model on the long-read path: empirical qualities + the k-mer splice of simulate_errors.
+# rng: the splice's draws from the read's StdRng stream (the reference's bits) or from Philox counters (SIMMR_RNG_PHILOX:
+# the same walk, the same tables, bit-exact against its own restatement orc_custom_simulate_errors_philox)
+RNG_MODES = pytest.mark.parametrize("rng_mode", [_abi.RNG_REFERENCE, _abi.RNG_PHILOX], ids=["reference", "philox"])
+
+
+@RNG_MODES
 @pytest.mark.parametrize("k,seed,n_positions", [(7, 42, 300), (3, 7, 40), (10, 5, 5000), (1, 9, 10)])
-def test_custom_long_bit_exact(engine, oracle, genome_multi, genome_1m, k, seed, n_positions):
+def test_custom_long_bit_exact(engine, oracle, genome_multi, genome_1m, k, seed, n_positions, rng_mode):
     from simmr_amd import CustomShortErrorProfile
     from tests import _model
     blob = _model.synthetic_long_model(kmer_size=k, n_positions=n_positions, seed=seed,
                                        n_kmers=3000 if k >= 6 else 4 ** k)
-    prof = CustomShortErrorProfile(blob)
+    prof = CustomShortErrorProfile(blob, rng_mode)
     assert prof.is_long_read()
     pod = prof.pod()
     engine.stage_genome(4, genome_1m.contigs)
@@ -431,15 +437,16 @@ def test_custom_long_bit_exact(engine, oracle, genome_multi, genome_1m, k, seed,
     assert c[_abi.CNT_QUAL_SUM] == ((d["qual"].astype(np.int64) - 33) % 256).sum()
 
 
+@RNG_MODES
 @pytest.mark.parametrize("k,max_alts", [(7, 21), (6, 32), (7, 40), (5, 255)])
-def test_custom_long_alternate_lists_of_simmrd_size(engine, oracle, genome_1m, k, max_alts):
+def test_custom_long_alternate_lists_of_simmrd_size(engine, oracle, genome_1m, k, max_alts, rng_mode):
     """simmrd keeps up to --max-alt-kmers alternates per k-mer (default 20, a u8): lists of up to 32 go through the
     fixed-stride column table of the fast splice kernel, longer ones through the two-load kernel."""
     from simmr_amd import CustomShortErrorProfile
     from tests import _model
     blob = _model.synthetic_long_model(kmer_size=k, n_positions=50, seed=17 + max_alts, n_kmers=4 ** k, max_alts=max_alts,
                                        lengths=(900, 2500, 100))
-    pod = CustomShortErrorProfile(blob).pod()
+    pod = CustomShortErrorProfile(blob, rng_mode).pod()
     dev = engine.simulate_long_reads([0], [150], pod, 77, read_id_base=0, qual_offset=33)
     ora = _oracle.simulate_long(oracle, [genome_1m], [150], pod, 77, read_id_base=0, qual_offset=33)
     assert_same(dev.to_host(), ora.trimmed(), cols=COLS)
@@ -464,7 +471,8 @@ def test_custom_model_tables_follow_the_model(engine, genome_1m):
     assert np.array_equal(run(a)["seq"], ra["seq"])
 
 
-def test_custom_long_exceptions_and_sharding(engine, oracle):
+@RNG_MODES
+def test_custom_long_exceptions_and_sharding(engine, oracle, rng_mode):
     from simmr_amd import CustomShortErrorProfile
     from tests import _model
     rng = np.random.default_rng(21)
@@ -476,7 +484,7 @@ def test_custom_long_exceptions_and_sharding(engine, oracle):
     engine.stage_genome(3, [seq, short])
     g = _oracle.HostGenome([seq, short])
     pod = CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=4, n_positions=100, seed=2, n_kmers=256,
-                                                             lengths=(300, 2400, 50))).pod()
+                                                             lengths=(300, 2400, 50)), rng_mode).pod()
     whole = _oracle.simulate_long(oracle, [g], [400], pod, 6).trimmed()
     dev = engine.simulate_long_reads([3], [400], pod, 6)
     d = dev.to_host()
@@ -491,14 +499,15 @@ def test_custom_long_exceptions_and_sharding(engine, oracle):
         assert np.array_equal(part["qual"], whole["qual"][base:whole["seq_off"][first + n]])
 
 
+@RNG_MODES
 @pytest.mark.parametrize("uniform_start", [False, True])
-def test_custom_long_per_read_lengths(engine, oracle, genome_multi, genome_1m, uniform_start):
+def test_custom_long_per_read_lengths(engine, oracle, genome_multi, genome_1m, uniform_start, rng_mode):
     """SIMMR_LEN_PER_READ with a custom model: every read draws floor(Normal(read_length_mean, read_length_std))
     from its own StdRng, as the reference does without --seed (custom_short.rs:286-301, simulate.rs:358)."""
     from simmr_amd import CustomShortErrorProfile
     from tests import _model
     prof = CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=6, n_positions=2500, seed=12, n_kmers=4 ** 6,
-                                                               lengths=(800, 5200, 100)))
+                                                               lengths=(800, 5200, 100)), rng_mode)
     pod = prof.pod()
     pod.length_mode = _abi.LEN_PER_READ
     pod.long_start_mode = _abi.START_UNIFORM if uniform_start else _abi.START_REFERENCE
@@ -522,7 +531,8 @@ def test_custom_long_per_read_lengths(engine, oracle, genome_multi, genome_1m, u
     assert np.array_equal(part["qual"], d["qual"][base:int(d["seq_off"][170])])
 
 
-def test_custom_long_reads_shorter_than_a_kmer(engine, oracle):
+@RNG_MODES
+def test_custom_long_reads_shorter_than_a_kmer(engine, oracle, rng_mode):
     """Reads re-cut at the end of a tiny sequence can be shorter than k (even empty): simulate_errors then visits
     no k-mer (custom_short.rs:475-477) and the read is a plain copy."""
     from simmr_amd import CustomShortErrorProfile
@@ -534,7 +544,7 @@ def test_custom_long_reads_shorter_than_a_kmer(engine, oracle):
     g = _oracle.HostGenome([seq])
     blob = _model.synthetic_long_model(kmer_size=7, n_positions=12, seed=3, n_kmers=4 ** 7, read_length_mean=40.0,
                                        read_length_std=2.0)
-    pod = CustomShortErrorProfile(blob).pod()
+    pod = CustomShortErrorProfile(blob, rng_mode).pod()
     for seed in (1, 2, 3):
         dev = engine.simulate_long_reads([3], [300], pod, seed, qual_offset=33).to_host()
         ora = _oracle.simulate_long(oracle, [g], [300], pod, seed, qual_offset=33).trimmed()
@@ -544,12 +554,13 @@ def test_custom_long_reads_shorter_than_a_kmer(engine, oracle):
         assert (lens < 7).any() and (lens >= 7).any()
 
 
-def test_custom_long_error_paths(engine, oracle, genome_multi):
+@RNG_MODES
+def test_custom_long_error_paths(engine, oracle, genome_multi, rng_mode):
     from simmr_amd import CustomShortErrorProfile, SimmrError
     from tests import _model
     # a deletion: the reference panics on its next slice; both sides answer ERANGE
     blob = _model.synthetic_long_model(kmer_size=5, n_positions=20, seed=1, n_kmers=100, deletion=True)
-    pod = CustomShortErrorProfile(blob).pod()
+    pod = CustomShortErrorProfile(blob, rng_mode).pod()
     with pytest.raises(SimmrError) as ei:
         engine.simulate_long_reads([1], [50], pod, 3)
     assert ei.value.code == _abi.ERANGE and "simulate_errors" in ei.value.msg
@@ -570,8 +581,53 @@ def test_custom_long_error_paths(engine, oracle, genome_multi):
     zero = _model.serialize_model([([1.0], [(30, 30)])] * 3, ([1.0], [(700, 700)]), probabilities=probs, kmer_size=1,
                                   read_length_mean=700.0, insert_size_mean=0.0, is_long=True)
     with pytest.raises(SimmrError) as ei:
-        engine.simulate_long_reads([1], [5], CustomShortErrorProfile(zero).pod(), 3)
+        engine.simulate_long_reads([1], [5], CustomShortErrorProfile(zero, rng_mode).pod(), 3)
     assert ei.value.code == _abi.ERANGE
+    # the counter mode of a custom model is the splice's: the paired-end path has no base-by-base draws to offer it
+    with pytest.raises(SimmrError) as ei:
+        engine.pe_plan(1, CustomShortErrorProfile(_model.synthetic_short_model(), _abi.RNG_PHILOX).pod(), 10, 3)
+    assert ei.value.code == _abi.EINVAL and "SIMMR_RNG_PHILOX" in ei.value.msg
+
+
+def test_custom_long_counter_mode_tolerances(engine, genome_1m):
+    """SIMMR_RNG_PHILOX with a custom long-read model: lengths, positions and qualities are the reference mode's bit for
+    bit (the same seeds, the same streams); the splice draws every visited k-mer's alternate from the same alias tables
+    with other bits.  Law: the edited fraction of the bases agrees with the reference mode's within 4 % (relative; ~6e4
+    edits per run), and — on a model whose k-mers are single bases, where a visited base is replaced independently of
+    its neighbours — every alternate's frequency agrees with its weight (chi-square per k-mer, p > 1e-4)."""
+    from simmr_amd import CustomShortErrorProfile
+    from tests import _model
+    blob = _model.synthetic_long_model(kmer_size=6, n_positions=200, seed=31, n_kmers=4 ** 6, lengths=(4000, 9000, 100))
+    runs = {}
+    for rng_mode in (_abi.RNG_REFERENCE, _abi.RNG_PHILOX):
+        engine.counters_reset()
+        d = engine.simulate_long_reads([0], [1500], CustomShortErrorProfile(blob, rng_mode).pod(), 5, qual_offset=33).to_host()
+        c = engine.counters()
+        runs[rng_mode] = (d, c[_abi.CNT_SUBSTITUTIONS] / c[_abi.CNT_ACGT_BASES], c[_abi.CNT_ACGT_BASES])
+    (a, ra, na), (b, rb, nb) = runs[_abi.RNG_REFERENCE], runs[_abi.RNG_PHILOX]
+    for col in ("seq_off", "start", "end", "contig", "read_id", "qual"):
+        assert np.array_equal(a[col], b[col]), col
+    assert na == nb > 5_000_000 and not np.array_equal(a["seq"], b["seq"])
+    assert ra > 0.005 and abs(rb / ra - 1) < 0.04, (ra, rb)
+    # single-base k-mers: P(base c becomes alternate j) = w[c][j] / sum(w[c])
+    w = np.array([[8.0, 1.0, 0.5, 0.5], [0.25, 6.0, 0.25, 1.5], [1.0, 1.0, 5.0, 1.0], [0.1, 0.2, 0.3, 9.4]], dtype=np.float32)
+    probs = [(c, [(j, float(w[c][j])) for j in range(4)]) for c in range(4)]
+    one = _model.serialize_model([([1.0], [(30, 30)])] * 3, ([1.0], [(6000, 6000)]), probabilities=probs, kmer_size=1,
+                                 read_length_mean=6000.0, insert_size_mean=0.0, is_long=True)
+    d = engine.simulate_long_reads([0], [400], CustomShortErrorProfile(one, _abi.RNG_PHILOX).pod(), 9).to_host()
+    ref = np.concatenate([genome_1m.contigs[int(d["contig"][r])][int(d["start"][r]):int(d["end"][r])] for r in range(400)])
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    lut = np.full(256, 255, np.uint8)
+    for ch, v in code.items():
+        lut[ch] = v
+    src, dst = lut[ref], lut[d["seq"]]
+    assert src.size == dst.size > 2_000_000 and src.max() < 4 and dst.max() < 4
+    from scipy.stats import chisquare
+    for c0 in range(4):
+        obs = np.bincount(dst[src == c0], minlength=4).astype(float)
+        pr = w[c0].astype(np.float64)
+        exp = pr / pr.sum() * obs.sum()
+        assert chisquare(obs, exp).pvalue > 1e-4, (c0, obs, exp)
 
 
 def test_error_paths(engine, genome_multi):

@@ -115,7 +115,8 @@ def test_random_multi_genome_plans(engine, oracle):
     assert n_ok == 60
 
 
-def test_random_custom_long_models(engine, oracle):
+@pytest.mark.parametrize("rng_mode", [0, 1], ids=["reference", "philox"])
+def test_random_custom_long_models(engine, oracle, rng_mode):
     """Random long-read models (k-mer size, sparsity of the k-mer table, modelled positions, length law) on random
     genomes with N / '-' runs: qualities and the k-mer splice against the oracle; a refusal must be mutual."""
     from simmr_amd import CustomShortErrorProfile
@@ -129,7 +130,7 @@ def test_random_custom_long_models(engine, oracle):
         lo = int(rng.integers(50, 800)); hi = lo + int(rng.integers(200, 3000))
         blob = _model.synthetic_long_model(kmer_size=k, n_positions=int(rng.integers(1, 1500)), seed=int(rng.integers(0, 1 << 30)),
                                            n_kmers=n_kmers, lengths=(lo, hi, 50), deletion=(it % 8 == 3))
-        prof = CustomShortErrorProfile(blob)
+        prof = CustomShortErrorProfile(blob, rng_mode)  # 1 = SIMMR_RNG_PHILOX: the splice's draws from Philox counters
         pod = prof.pod()
         nc = int(rng.integers(1, 4))
         lens = [int(rng.integers(hi + 500, 30_000)) for _ in range(nc)]
