@@ -404,7 +404,9 @@ def main():
                             "per-lane table reads (address unit)" if args.profile == "custom-short" else
                             "latency of the dependent table load per visited k-mer at 4 waves per SIMD, and ChaCha12 issue"
                             if (custom is not None and args.rng == "reference") else
-                            "the chain count -> draw -> column load of the sequential k-mer walk (one lane per read), and VALU issue"
+                            "latency of the sequential k-mer walk at six waves per SIMD (one lane per read; per base an LDS lookup, "
+                            "the level-1 test, and for one lane in five a column load), with VALU issue (45 instructions per base) "
+                            "at half of the kernel's time"
                             if custom is not None else
                             "VALU issue (ChaCha12 and the per-base state machines of the reference's streams)"
                             if args.rng == "reference" else

@@ -261,9 +261,11 @@ static int enc3(const uint8_t* k, uint64_t n, uint32_t* out) {
 /* The counter mode's draw of a visited k-mer's alternate: the specification (include/simmr_hip.h, enum simmr_rng_mode;
  * the product builds the same tables in simmr_amd/csrc/custom_model.hpp).  The law is the reference's —
  * P(alternate j) = w_j / sum(w) (custom_short.rs:497-503) — split in two levels so that the common outcome, "the k-mer
- * stays what it is", needs no table:
- *   level 1: p_s = P(an alternate equal to the k-mer itself) is cut at T24 = min(floor(2^24 p_s), 2^24 - 1) 2^24ths;
- *   level 2: an alias table (Vose, n columns, thresholds in 2^24ths) over the residual law
+ * stays what it is", needs no table, from ONE 32-bit word X per position:
+ *   level 1: X >> 8 < T24 answers "self"; T24 = 2^24 - 2^e, 2^e the smallest power of two (1 <= e <= 24) of 2^24ths that
+ *            holds 1 - p_s, p_s = P(an alternate equal to the k-mer itself);
+ *   level 2: Z = (X - (T24 << 8)) << (24 - e) is a full word again; m = Z n (64 bits), column c = m >> 32 of an alias table
+ *            (Vose, n columns, thresholds in 2^24ths against (m & 0xffffffff) >> 8) over the residual law
  *            r_j = (p_j - [j is self] (T24 / 2^24) p_j / p_s) / (1 - T24 / 2^24).
  * All in f64, sums in list order.  A k-mer with an N has no "self" (its alternates with an N are errors, not draws). */
 static uint32_t ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t n, uint32_t self_code, int has_self,
@@ -272,10 +274,12 @@ static uint32_t ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t 
   for (uint32_t j = 0; j < n; j++) W += (double)w[j];
   double ps = 0.0;
   if (has_self) for (uint32_t j = 0; j < n; j++) if (alt[j] == self_code) ps += (double)w[j] / W;
-  double t = floor(ps * 16777216.0);
-  if (t > 16777215.0) t = 16777215.0;
-  if (!(t >= 0.0)) t = 0.0;
-  const uint32_t T24 = (uint32_t)t;
+  /* level 2 takes 2^e of the 2^24 level-1 values, the smallest power of two that holds 1 - p_s (1 <= e <= 24): a draw
+   * that lands there is rescaled to a full word by a shift */
+  const double need = (1.0 - ps) * 16777216.0;
+  uint32_t e = 1;
+  while (e < 24u && (double)(1u << e) < need) e++;
+  const uint32_t T24 = 16777216u - (1u << e);
   const double lvl1 = (double)T24 / 16777216.0, rest = 1.0 - lvl1;
   double* odds = (double*)malloc(sizeof(double) * (n ? n : 1));
   for (uint32_t j = 0; j < n; j++) {
@@ -308,10 +312,9 @@ static uint32_t ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t 
 }
 
 /* `philox` != 0: SIMMR_RNG_PHILOX for a custom long-read model — the walk is the reference's; the alternate of the k-mer
- * visited at position i is drawn from words A = 2 (i & 1) and B = 2 (i & 1) + 1 of the Philox4x32-10 block with key =
- * the read's seed and counter (i >> 1, 2, 'simm', 'r\0\0\3'): level 1  A >> 8 < T24 -> the k-mer itself;  otherwise level 2
- * m = B * n (64 bits), column c = m >> 32, fraction f = (m & 0xffffffff) >> 8, alternate f < thr[c] ? c : alias[c].
- * Tolerance parity: the law of every draw is the reference's, the bits are not. */
+ * visited at position i is drawn from ONE word, X = word i & 3 of the Philox4x32-10 block with key = the read's seed and
+ * counter (i >> 2, 2, 'simm', 'r\0\0\3'), through the two levels of ctr_splice_tables.  Tolerance parity: the law of every
+ * draw is the reference's, the bits are not. */
 static int64_t simulate_errors_walk(const orc_model* m, const uint8_t* seq, uint64_t len, uint64_t seed, uint8_t* out, int philox) {
   orc_rng r; orc_rng_seed_from_u64(&r, seed);
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -332,10 +335,10 @@ static int64_t simulate_errors_walk(const orc_model* m, const uint8_t* seq, uint
       const uint32_t n = (uint32_t)m->prob_n[e];
       float wsum;
       if (alias_f32_check(m->prob_w[e], n, &wsum)) return -2;  /* the same lists are unusable in both modes */
-      const uint32_t ctr[4] = {(uint32_t)(i >> 1), 2u, 0x73696D6Du, 0x72000003u};
+      const uint32_t ctr[4] = {(uint32_t)(i >> 2), 2u, 0x73696D6Du, 0x72000003u};
       uint32_t w4[4];
       orc_philox4x32_10(ctr, key, w4);
-      const uint32_t A = w4[2 * (i & 1)], B = w4[2 * (i & 1) + 1];
+      const uint32_t X = w4[i & 3];
       int has_n = 0;
       for (uint64_t j = 0; j < k; j++) has_n |= ((code >> (3 * j)) & 7u) == 4u;
       uint32_t* thr = (uint32_t*)malloc(4 * n);
@@ -345,10 +348,13 @@ static int64_t simulate_errors_walk(const orc_model* m, const uint8_t* seq, uint
       for (uint32_t j = 0; j < n; j++) codes[j] = m->prob_alt[e][j] & kmask;
       const uint32_t T24 = ctr_splice_tables(codes, m->prob_w[e], n, code, !has_n, thr, al);
       free(codes);
-      if ((A >> 8) < T24) {
+      if ((X >> 8) < T24) {
         alt = code;
       } else {
-        const uint64_t mm = (uint64_t)B * n;
+        uint32_t eb = 0;  /* the level-2 region holds 2^eb level-1 values: 2^24 - T24 */
+        while ((1u << eb) < 16777216u - T24) eb++;
+        const uint32_t Z = (X - (T24 << 8)) << (24u - eb);
+        const uint64_t mm = (uint64_t)Z * n;
         const uint32_t c = (uint32_t)(mm >> 32), f = (uint32_t)mm >> 8;
         alt = m->prob_alt[e][f < thr[c] ? c : al[c]];
       }

@@ -192,10 +192,12 @@ struct KmerTables {
 
 // The counter mode's draw of a visited k-mer's alternate (include/simmr_hip.h, enum simmr_rng_mode; restated in
 // the test tree's CPU specification).  The law is the reference's — P(alternate j) = w_j / sum(w) — split in two levels so
-// that the common outcome, "the k-mer stays what it is", needs no table access:
-//   level 1: P(self) = p_s is cut at T24 = min(floor(2^24 p_s), 2^24 - 1) 2^24ths; a 24-bit draw below T24 answers "self";
-//   level 2 (the rest, 1 - T24 / 2^24 of the draws): an alias table (Vose, n columns, thresholds in 2^24ths) over the
-//   residual law r_j = (p_j - [j is self] (T24 / 2^24) p_j / p_s) / (1 - T24 / 2^24).
+// that the common outcome, "the k-mer stays what it is", needs no table access, from ONE 32-bit word X per position:
+//   level 1: X >> 8 < T24 answers "self", T24 = 2^24 - 2^e with 2^e the smallest power of two (1 <= e <= 24) of 2^24ths
+//            that holds 1 - P(self);
+//   level 2 (X >> 8 >= T24): Z = (X - (T24 << 8)) << (24 - e), a full word again, picks column (Z n) >> 32 of an alias table
+//            (Vose, n columns, thresholds in 2^24ths against ((Z n) & 0xffffffff) >> 8) over the residual law
+//            r_j = (p_j - [j is self] (T24 / 2^24) p_j / p_s) / (1 - T24 / 2^24).
 // All in f64, sums in list order; `has_self` false for k-mers with an N (their alternates with an N are errors, not draws).
 inline uint32_t ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t n, uint32_t self_code, bool has_self,
                                   uint32_t* thr, uint32_t* alias) {
@@ -203,10 +205,12 @@ inline uint32_t ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t 
   for (uint32_t j = 0; j < n; j++) W += (double)w[j];
   double ps = 0.0;
   if (has_self) for (uint32_t j = 0; j < n; j++) if (alt[j] == self_code) ps += (double)w[j] / W;
-  double t = floor(ps * 16777216.0);
-  if (t > 16777215.0) t = 16777215.0;
-  if (!(t >= 0.0)) t = 0.0;
-  const uint32_t T24 = (uint32_t)t;
+  /* level 2 takes 2^e of the 2^24 level-1 values, the smallest power of two that holds 1 - p_s (1 <= e <= 24): a draw
+   * that lands there is rescaled to a full word by a shift */
+  const double need = (1.0 - ps) * 16777216.0;
+  uint32_t e = 1;
+  while (e < 24u && (double)(1u << e) < need) e++;
+  const uint32_t T24 = 16777216u - (1u << e);
   const double lvl1 = (double)T24 / 16777216.0, rest = 1.0 - lvl1;
   std::vector<double> odds(n);
   for (uint32_t j = 0; j < n; j++) {

@@ -3115,11 +3115,12 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
 // of a wave in consecutive banks whatever word each is at) + the Uniform(0, n) zones + the counts.
 //
 // CTR: SIMMR_RNG_PHILOX with a custom long-read model (include/simmr_hip.h; restated on the CPU by the test tree:
-// orc_custom_simulate_errors_philox).  The walk is the same; a visited k-mer's alternate is drawn from two words of
-// Philox4x32-10 keyed by the read's seed — position i takes words A = 2 (i & 1) and B = 2 (i & 1) + 1 of the block with
-// counter (i >> 1, 2, 'simm', 'r\0\0\3') — in TWO LEVELS (custom_model.hpp: ctr_splice_tables): A >> 8 below the
-// k-mer's threshold T24 answers "the k-mer stays what it is" without any table access; only the rest (the model's error
-// rate: a tenth of the visited k-mers) goes to an alias column, chosen and resolved by B.  That is the point of the mode:
+// orc_custom_simulate_errors_philox).  The walk is the same; a visited k-mer's alternate is drawn from ONE word of
+// Philox4x32-10 keyed by the read's seed — position i takes word i & 3 of the block with counter
+// (i >> 2, 2, 'simm', 'r\0\0\3') — in TWO LEVELS (custom_model.hpp: ctr_splice_tables): X >> 8 below the k-mer's
+// threshold T24 answers "the k-mer stays what it is" without any table access; only the rest (the model's error rate: a
+// tenth of the visited k-mers) goes to an alias column, chosen and resolved by the same word rescaled (T24 leaves a
+// power of two of values above it, so the rescaling is a shift).  That is the point of the mode:
 // the reference's draw needs its column for EVERY visited k-mer, sixty-four different cache lines per wave-step, and the
 // reference-mode kernel is bound by exactly that (the same kernel with Philox words but the reference's one-level draw
 // took the same 86 ms per 20 Gbases; with one lane in ten loading, 43: profiles/r4/ab_splice_ctr_*.log).  Nothing of a
@@ -3128,10 +3129,13 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
 constexpr uint32_t SPLICE_FAST_LANES = 1024u;
 __host__ __device__ inline uint32_t splice_fast_lds_bytes(uint32_t k) { return 32u * SPLICE_FAST_LANES * 4u + 256u * 4u + (1u << (2u * k)); }
 __host__ __device__ inline uint32_t splice_ctr_lds_bytes(uint32_t k) { return 4u << (2u * k); }
-constexpr uint32_t SPLICE_CTR_LANES_MAX = 768u;  // two workgroups of 768 beside each other when the table takes 64 KB (k = 7)
+#if !defined(SPLICE_CTR_LANES)
+#define SPLICE_CTR_LANES 768
+#endif
+constexpr uint32_t SPLICE_CTR_LANES_MAX = SPLICE_CTR_LANES;  // two workgroups beside each other when the table takes 64 KB (k = 7)
 template <bool HAS_EXC, bool FAST, bool CTR = false>
 #if !defined(SPLICE_CTR_WAVES)
-#define SPLICE_CTR_WAVES 1  /* waves per SIMD asked of the compiler for the counter mode's instantiations (1: whatever it finds) */
+#define SPLICE_CTR_WAVES 6  /* waves per SIMD asked of the compiler for the counter mode's instantiations: two workgroups of 768 lanes per CU */
 #endif
 __global__ void __launch_bounds__(CTR ? SPLICE_CTR_LANES_MAX : (FAST ? 1024 : 256), CTR ? SPLICE_CTR_WAVES : 1)
 k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint64_t n_units,
@@ -3151,6 +3155,14 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
   const uint32_t* const s_zone = splice_lds + (CTR ? 0u : 32u * SPLICE_FAST_LANES);
   const uint8_t* const s_cnt8 = reinterpret_cast<const uint8_t*>(s_zone + (CTR ? 0u : 256u));
   const uint32_t* const s_tab = splice_lds;  // CTR: T24 << 8 | count
+  __shared__ uint32_t s_asc[CTR ? 256 : 1];  // CTR: four 2-bit codes -> four ASCII bytes
+  if (CTR) {
+    const uint32_t acgt = 0x54474341u;  // "ACGT"
+    for (uint32_t t = threadIdx.x; t < 256u; t += NT)
+      s_asc[t] = ((acgt >> (8 * (t & 3u))) & 0xffu) | (((acgt >> (8 * ((t >> 2) & 3u))) & 0xffu) << 8) |
+                 (((acgt >> (8 * ((t >> 4) & 3u))) & 0xffu) << 16) | (((acgt >> (8 * (t >> 6))) & 0xffu) << 24);
+    if (!FAST) __syncthreads();
+  }
   if (FAST && CTR) {
     const uint32_t n_w = 1u << (2u * K);
     for (uint32_t w = threadIdx.x; w < n_w; w += NT) splice_lds[w] = C.kmer_tab32[w];
@@ -3264,42 +3276,49 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
             const uint32_t stride16 = C.kmer_stride << 4;
             bool rare = false;
             if (CTR) {
-              // The counter mode's group as a ROLLED loop over its eight step pairs (one Philox block each): nothing but
-              // the window, the output register and one block lives across a pair, so the kernel fits the registers
-              // of eight waves per SIMD — what hides the chain count -> draw -> column load is other waves, not steps of
-              // the same wave in flight.  The 16 output bytes ride in a 128-bit shift register (the step number is not
-              // a compile-time constant here).
-              uint32_t o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u, sbits = s16;
+              // The counter mode's group as a ROLLED loop over its four Philox blocks (one word per step): nothing but the
+              // window, two code registers and one block lives across a block's steps, so the kernel fits the registers of
+              // six waves per SIMD.  The 16 output bases are gathered as 2-bit codes (v_alignbit shifts a step's code in)
+              // and become ASCII once per group through the LDS table; the substitutions are counted once per group from the
+              // codes of the output and of the original.
+              uint32_t oc = 0u, orig = 0u, sbits = s16;
+              uint32_t rarev = 0u;  // bit 31: something the straight line cannot do was met
 #pragma nounroll
-              for (uint32_t pp = 0; pp < 8u; pp++) {
+              for (uint32_t qd = 0; qd < 4u; qd++) {
                 uint32_t bw[4];
-                philox4x32_10((i0 >> 1) + pp, 2u, pk0, pk1, bw);  // (i0 is a multiple of 16)
+                philox4x32_10((i0 >> 2) + qd, 2u, pk0, pk1, bw);  // (i0 is a multiple of 16)
 #pragma unroll
-                for (uint32_t h = 0; h < 2u; h++) {
+                for (uint32_t h = 0; h < 4u; h++) {
+                  const uint32_t X = bw[h];
                   const uint32_t e32 = s_tab[win];
                   const uint32_t cnt = e32 & 0xffu;
-                  // level 1: A >> 8 < T24  <=>  A < T24 << 8; level 2 only for a k-mer of the model that did not stay
-                  const bool lvl2 = (cnt - 1u < 254u) & (bw[2u * h] >= (e32 & 0xffffff00u));
-                  if (lvl2) {
-                    const uint64_t m = (uint64_t)bw[2u * h + 1u] * cnt;
-                    const Rec16 rec = *reinterpret_cast<const Rec16*>(cols_bytes + (__umul24(win, stride16) + ((uint32_t)(m >> 32) << 4)));
-                    const uint32_t alt = ((uint32_t)m >> 8) < rec.x ? rec.y : rec.z;
-                    rare = rare | ((int32_t)alt < 0);
-                    win = alt & kmask2;
-                  }
-                  rare = rare | (cnt == 255u);
-                  const uint32_t code = win & 3u;
-                  const uint32_t ch = __builtin_amdgcn_perm(0u, 0x54474341u, code | 0x0c0c0c00u);  // "ACGT"[code]
-                  o0 = __builtin_amdgcn_alignbyte(o1, o0, 1u); o1 = __builtin_amdgcn_alignbyte(o2, o1, 1u);
-                  o2 = __builtin_amdgcn_alignbyte(o3, o2, 1u); o3 = (o3 >> 8) | (ch << 24);
-                  n_subst += code != (owin & 3u) ? 1u : 0u;
+                  const uint32_t tx = e32 & 0xffffff00u;  // T24 << 8
+                  // level 1: X >> 8 < T24  <=>  X < T24 << 8; level 2 only for a k-mer of the model that did not stay
+                  const bool lvl2 = (cnt - 1u < 254u) & (X >= tx);
+                  // level 2: the 2^(e + 8) values from T24 << 8 up, shifted to a full word (24 - e = the leading zeros of
+                  // ~(T24 << 8 | 0xff), whose set bits are bits 8 .. e + 7; e >= 1)
+                  const uint32_t Z = (X - tx) << __builtin_clz(~(e32 | 0xffu));
+                  // No branch: every lane loads — the lanes that stay at level 1 all the same record (one line for the
+                  // whole wave), the others their column — so that the load is in flight while the block's other steps'
+                  // arithmetic runs; nine wave-steps in ten have a lane at level 2 anyway.
+                  const uint64_t m = (uint64_t)Z * cnt;
+                  const uint32_t off = lvl2 ? __umul24(win, stride16) + ((uint32_t)(m >> 32) << 4) : 0u;
+                  const Rec16 rec = *reinterpret_cast<const Rec16*>(cols_bytes + off);  // (a nontemporal load here: twice the time)
+                  const uint32_t alt = ((uint32_t)m >> 8) < rec.x ? rec.y : rec.z;
+                  rarev |= lvl2 ? alt : (cnt == 255u ? 0x80000000u : 0u);
+                  win = lvl2 ? (alt & kmask2) : win;
+                  oc = __builtin_amdgcn_alignbit(win, oc, 2);      // (the low base of the window enters at the top)
+                  orig = __builtin_amdgcn_alignbit(owin, orig, 2);
                   const uint32_t c2 = (sbits & 3u) << top2;
                   sbits >>= 2;
                   win = (win >> 2) | c2;
                   owin = (owin >> 2) | c2;
                 }
               }
-              out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3;
+              out[0] = s_asc[oc & 0xffu]; out[1] = s_asc[(oc >> 8) & 0xffu]; out[2] = s_asc[(oc >> 16) & 0xffu]; out[3] = s_asc[oc >> 24];
+              const uint32_t dx = oc ^ orig;
+              n_subst += (uint32_t)__builtin_popcount((dx | (dx >> 1)) & 0x55555555u);
+              rare = rare | ((int32_t)rarev < 0);
             } else
 #pragma nounroll
             for (uint32_t t8 = 0; t8 < 16u; t8 += 8u) {
@@ -3404,12 +3423,13 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
                 uint32_t alt;
                 if (CTR) {
                   uint32_t gw[4];
-                  philox4x32_10(i >> 1, 2u, pk0, pk1, gw);
-                  const uint32_t A = (i & 1u) ? gw[2] : gw[0], B = (i & 1u) ? gw[3] : gw[1];
-                  if (A < t24s) {
+                  philox4x32_10(i >> 2, 2u, pk0, pk1, gw);
+                  const uint32_t X = (i & 2u) ? ((i & 1u) ? gw[3] : gw[2]) : ((i & 1u) ? gw[1] : gw[0]);
+                  if (X < t24s) {
                     alt = win;  // level 1: the k-mer stays what it is
                   } else {
-                    const uint64_t m = (uint64_t)B * cnt;
+                    const uint32_t Z = (X - t24s) << __builtin_clz(~(t24s | 0xffu));
+                    const uint64_t m = (uint64_t)Z * cnt;
                     const Rec16 rec = recs[first + (uint32_t)(m >> 32)];
                     alt = ((uint32_t)m >> 8) < rec.x ? rec.y : rec.z;
                   }

@@ -50,7 +50,8 @@ def main():
     for name, key, workload in (("pmc_default.txt", "k_emit_philox_slot16", "bench.py default (minimal-short 150 bp PE, 100 Mbp, 100 M reads, counter mode, 16-byte read slots)"),
                                 ("pmc_compact.txt", "k_emit_philox", "bench.py --layout compact (the same run with byte streams without gaps)"),
                                 ("pmc_perfect.txt", "k_emit_perfect_pe", "bench.py --profile perfect-short"),
-                                ("pmc_custom_long.txt", "k_custom_long_splice", "bench.py --profile custom-long --reads 1000000"),
+                                ("pmc_custom_long.txt", "k_custom_long_splice_ctr", "bench.py --profile custom-long --reads 1000000 (counter mode of the splice)"),
+                                ("pmc_custom_long_reference.txt", "k_custom_long_splice", "bench.py --profile custom-long --rng reference --reads 1000000"),
                                 ("pmc_through_fastq.txt", "k_emit_philox_text", "bench.py --through-fastq: the TEXT form of the counter-mode kernel (simmr_emit_fastq), its launches only")):
         f = src / name
         if f.exists():

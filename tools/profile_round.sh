@@ -13,6 +13,7 @@ stats() {  # name, bench args...
 stats bench_default
 stats bench_perfect_short --profile perfect-short
 stats bench_custom_long --profile custom-long --reads 1000000
+stats bench_custom_long_reference --profile custom-long --rng reference --reads 1000000
 stats bench_custom_short --profile custom-short --reads 20000000
 stats bench_minimal_long --profile minimal-long --reads 10000000
 stats bench_through_fastq --through-fastq --no-other-mode
@@ -20,7 +21,8 @@ S="FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES;SQ_WA
 tools/pmc_cmd.sh "prof_$tag/pmc_default" "k_emit_philox<false, false, true, false" "$S" -- python3 bench.py --no-cpu-baseline --no-other-mode --steps 1 --warmup 0 > "$out/pmc_default.txt"
 tools/pmc_cmd.sh "prof_$tag/pmc_compact" "k_emit_philox<false, false, true, false" "FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES;SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY" -- python3 bench.py --no-cpu-baseline --no-other-mode --layout compact --steps 1 --warmup 0 > "$out/pmc_compact.txt"
 tools/pmc_cmd.sh "prof_$tag/pmc_perfect" k_emit_perfect_pe "FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_WAVES" -- python3 bench.py --no-cpu-baseline --profile perfect-short --steps 1 --warmup 0 > "$out/pmc_perfect.txt"
-tools/pmc_cmd.sh "prof_$tag/pmc_custom_long" k_custom_long_splice "FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES;SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" -- python3 bench.py --no-cpu-baseline --profile custom-long --reads 1000000 --steps 1 --warmup 0 > "$out/pmc_custom_long.txt"
+tools/pmc_cmd.sh "prof_$tag/pmc_custom_long" k_custom_long_splice "FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES;SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" -- python3 bench.py --no-cpu-baseline --no-other-mode --profile custom-long --reads 1000000 --steps 1 --warmup 0 > "$out/pmc_custom_long.txt"
+tools/pmc_cmd.sh "prof_$tag/pmc_custom_long_reference" k_custom_long_splice "FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES;SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" -- python3 bench.py --no-cpu-baseline --no-other-mode --profile custom-long --rng reference --reads 1000000 --steps 1 --warmup 0 > "$out/pmc_custom_long_reference.txt"
 # (the TEXT form only: <HAS_EXC, COPY_ONLY, CACHED, TEXT, ...> = <false, false, true, true, ...>; the command's one column launch is left out)
 tools/pmc_cmd.sh "prof_$tag/pmc_through_fastq" "k_emit_philox<false, false, true, true" "FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES;SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY" -- python3 bench.py --no-cpu-baseline --no-other-mode --through-fastq --steps 1 --warmup 0 > "$out/pmc_through_fastq.txt"
 rm -rf "$out"/bench_*/ "$out"/pmc_*/p*/  # keep the summaries, drop the raw traces
