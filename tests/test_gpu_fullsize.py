@@ -135,8 +135,11 @@ def test_c1_perfect_short_full_roundtrip(big):
         assert bool((seq[a + 1:b:2] == rc).all())
 
 
-def test_c5_custom_long_properties(big):
-    """BASELINE configs[4] in the large: a custom (simmrd-shaped) long-read model, per-read lengths, 500 k reads
+@pytest.mark.parametrize("rng_mode", [0, 1], ids=["reference", "philox"])
+def test_c5_custom_long_properties(big, rng_mode):
+    """(rng_mode 1 = SIMMR_RNG_PHILOX: the splice's draws from Philox counters; the properties are the same, and the
+    edited fraction stays in the band the reference mode's falls in.)
+    BASELINE configs[4] in the large: a custom (simmrd-shaped) long-read model, per-read lengths, 500 k reads
     (10 Gbases), checked on the device through size-independent properties: determinism, sharded == whole, the
     constant quality tail, substitutions only where the counters say, alphabet."""
     import torch
@@ -144,7 +147,7 @@ def test_c5_custom_long_properties(big):
     eng = big
     n_pos = 1000
     prof = CustomShortErrorProfile(model_io.synthetic_long_model(kmer_size=7, n_positions=n_pos, seed=1, n_kmers=4 ** 7,
-                                                                  read_length_mean=20000.0, read_length_std=4000.0))
+                                                                  read_length_mean=20000.0, read_length_std=4000.0), rng_mode)
     pod = prof.pod()
     pod.length_mode = _abi.LEN_PER_READ
     pod.long_start_mode = _abi.START_UNIFORM
@@ -181,6 +184,8 @@ def test_c5_custom_long_properties(big):
             mism += int((seq[a:b] != refb[s0:s0 + (b - a)]).sum().item())
         assert 0.05 < mism / int(off[2000]) < 0.15
     assert 0.05 < c[_abi.CNT_SUBSTITUTIONS] / c[_abi.CNT_ACGT_BASES] < 0.15
+    # both modes draw from the same law: 0.0970 edited bases per base with this model (10 Gbases: the two agree to 1e-4)
+    assert abs(c[_abi.CNT_SUBSTITUTIONS] / c[_abi.CNT_ACGT_BASES] - 0.0970) < 0.0005
     # determinism and sharding: checksums of a shard's byte range
     cs_whole = checksum_range(whole.seq, int(off[123_456]), int(off[223_456]))
     cq_whole = checksum_range(whole.qual, int(off[123_456]), int(off[223_456]))
