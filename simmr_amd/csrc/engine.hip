@@ -87,6 +87,7 @@ struct simmr_engine {
   bool plan_coarse = false; // pairs for the counter-mode kernel: u_off64 (first byte of every 64th pair) instead of u_off
   DevBuf w_bytes, u_off64, fq_off64;
   uint32_t splice_lds_set[2] = {0, 0};  // dynamic-LDS limit already set on this device for k_custom_long_splice<exc, fast>
+  uint32_t splice_ctr_lds_set[2] = {0, 0};  // the same for the counter mode's instantiations <exc, fast, CTR>
   bool fq_coarse = false;  // the direct FASTQ plan in force has fq_off64 (first byte of every 64th record) instead of fq_off
   bool plan_paired = false;
   bool plan_multi = false;    // paired-end plan over several genomes (u_genome per pair)
@@ -1577,6 +1578,10 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          : (exc ? k_custom_long_splice<true, false, true> : k_custom_long_splice<false, false, true>);
         const uint32_t lds = fast ? splice_ctr_lds_bytes(e->prof.custom.kmer_size) : 0u;
         const uint32_t lanes = lds > 16384u ? SPLICE_CTR_LANES_MAX : 256u;
+        if (lds > 32768u && lds > e->splice_ctr_lds_set[exc ? 1 : 0]) {  // (64 KB of table + the kernel's static LDS: over the default limit)
+          HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          e->splice_ctr_lds_set[exc ? 1 : 0] = lds;
+        }
         // (many more workgroups than are resident: reads come longest first, and the tail of the launch is short ones)
         const uint32_t cgrid = (uint32_t)std::min<uint64_t>((n_reads + lanes - 1) / lanes, (uint64_t)e->n_cu * 64 * e->custom_long_mult);
         hipLaunchKernelGGL(kern, dim3(cgrid), dim3(lanes), lds, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), n_units, order,

@@ -136,3 +136,58 @@ def test_long_path_with_a_custom_model(oracle):
     per = _oracle.simulate_long(oracle, [g], [40], pod, 11).trimmed()
     lens = np.diff(per["seq_off"].astype(np.int64))
     assert len(set(lens.tolist())) > 10 and 500 < lens.mean() < 1000  # reads on the 1200 nt sequence are re-cut at its end
+
+
+def test_counter_mode_splice_specification(oracle):
+    """SIMMR_RNG_PHILOX with a custom long-read model (include/simmr_hip.h; oracle/custom.c: ctr_splice_tables,
+    orc_custom_simulate_errors_philox) — the specification the HIP kernel is compared with bit for bit, checked here for
+    what it promises: (1) with one alternate per k-mer no draw matters, so both modes give the reference walk's bytes;
+    (2) lengths, positions and qualities are the reference mode's; (3) on a model of single-base k-mers, where a visited
+    base is replaced independently of its neighbours, every alternate's frequency follows its weight (chi-square), for
+    dominant, balanced and self-less lists alike; (4) a shard of a run equals that range of the whole run."""
+    from scipy.stats import chisquare
+    from simmr_amd import CustomShortErrorProfile, _abi
+    from tests import _synth
+    lut = np.full(256, 255, np.uint8)
+    for ch, v in {65: 0, 67: 1, 71: 2, 84: 3}.items():
+        lut[ch] = v
+    contigs = _synth.synthetic_contigs([400_000], 8)
+    g = _oracle.HostGenome(contigs)
+    # (1) deterministic lists
+    k = 3
+    probs = [(sum(((i >> (2 * j)) & 3) << (3 * j) for j in range(k)), [(sum((((i * 7 + 3) >> (2 * j)) & 3) << (3 * j) for j in range(k)), 1.5)])
+             for i in range(0, 64, 3)]
+    q3 = [([1.0], [(30, 30)])] * 3
+    det = _model.serialize_model(q3, ([1.0], [(700, 700)]), probabilities=probs, kmer_size=k, read_length_mean=700.0,
+                                 insert_size_mean=0.0, is_long=True)
+    a = _oracle.simulate_long(oracle, [g], [50], CustomShortErrorProfile(det, _abi.RNG_REFERENCE).pod(), 3).trimmed()
+    b = _oracle.simulate_long(oracle, [g], [50], CustomShortErrorProfile(det, _abi.RNG_PHILOX).pod(), 3).trimmed()
+    for col in ("seq", "qual", "seq_off", "start", "end"):
+        assert np.array_equal(a[col], b[col]), col
+    # (3) the law, on lists with a dominant self, a balanced list, a list without self, a list of one
+    w = [[8.0, 1.0, 0.5, 0.5], [1.0, 1.0, 1.0, 1.0], [0.0, 3.0, 0.0, 4.0], None]  # (G's list has no G: (C, 3), (A, 0), (T, 4))
+    probs = [(0, [(j, w[0][j]) for j in range(4)]), (1, [(j, w[1][j]) for j in range(4)]), (2, [(j, w[2][j]) for j in (1, 0, 3)]),
+             (3, [(3, 0.25)])]
+    one = _model.serialize_model(q3, ([1.0], [(6000, 6000)]), probabilities=probs, kmer_size=1, read_length_mean=6000.0,
+                                 insert_size_mean=0.0, is_long=True)
+    ref_pod, ctr_pod = CustomShortErrorProfile(one, _abi.RNG_REFERENCE).pod(), CustomShortErrorProfile(one, _abi.RNG_PHILOX).pod()
+    ra = _oracle.simulate_long(oracle, [g], [120], ref_pod, 9).trimmed()
+    rb = _oracle.simulate_long(oracle, [g], [120], ctr_pod, 9).trimmed()
+    for col in ("qual", "seq_off", "start", "end", "contig", "read_id"):  # (2)
+        assert np.array_equal(ra[col], rb[col]), col
+    assert not np.array_equal(ra["seq"], rb["seq"])
+    src = lut[np.concatenate([contigs[0][int(rb["start"][r]):int(rb["end"][r])] for r in range(120)])]
+    for out in (ra, rb):
+        dst = lut[out["seq"]]
+        assert src.size == dst.size > 600_000
+        for c0 in range(3):
+            obs = np.bincount(dst[src == c0], minlength=4).astype(float)
+            pr = np.array(w[c0], dtype=np.float64)
+            keep = pr > 0
+            assert obs[~keep].sum() == 0
+            assert chisquare(obs[keep], pr[keep] / pr.sum() * obs.sum()).pvalue > 1e-4, (c0, obs)
+        assert (dst[src == 3] == 3).all()
+    # (4) a shard of the counter-mode run
+    part = _oracle.simulate_long(oracle, [g], [120], ctr_pod, 9, first=37, count=40).trimmed()
+    lo, hi = int(rb["seq_off"][37]), int(rb["seq_off"][77])
+    assert np.array_equal(part["seq"], rb["seq"][lo:hi]) and np.array_equal(part["qual"], rb["qual"][lo:hi])
