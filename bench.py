@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--rng", default="philox", choices=["reference", "philox"],
                     help="philox: Philox4x32-10 counter mode for the per-base draws (north_star's design, tolerance "
                          "parity); reference: the reference's own ChaCha12 streams (bit-exact, slower)")
+    ap.add_argument("--plan", default="philox", choices=["reference", "philox"],
+                    help="with --rng philox, where the PLAN's draws (contig, seeds, lengths, positions) come from: philox = Philox "
+                         "counters too (SIMMR_RNG_PHILOX_FULL: minimal-short and minimal-long; the default), reference = the "
+                         "reference's ChaCha12 streams (SIMMR_RNG_PHILOX: same positions and lengths as the reference run)")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the untimed side measurements (the other rng mode, the FASTQ text)")
     ap.add_argument("--through-fastq", action="store_true",
                     help="one step = plan + FASTQ sizing + emit straight into FASTQ text resident in HBM (simmr_fastq_plan_direct / "
@@ -138,12 +142,15 @@ def main():
         prof = (MinimalShortErrorProfile() if args.profile == "minimal-short" else PerfectShortErrorProfile()).pod()
     if args.rng == "philox" and args.profile != "perfect-short":
         prof.rng_mode = _abi.RNG_PHILOX
+        if args.plan == "philox" and args.profile in ("minimal-short", "minimal-long"):
+            prof.rng_mode = _abi.RNG_PHILOX_FULL
+    plan_full = prof.rng_mode == _abi.RNG_PHILOX_FULL
 
     # default layout: the 16-byte read slots where the emit kernel offers them (counter mode, minimal profiles), else compact
     if args.layout is None:
-        args.layout = "slot16" if (prof.rng_mode == _abi.RNG_PHILOX and custom is None and args.profile != "perfect-short") else "compact"
+        args.layout = "slot16" if (prof.rng_mode != _abi.RNG_REFERENCE and custom is None and args.profile != "perfect-short") else "compact"
     slot16 = args.layout == "slot16"
-    if slot16 and (prof.rng_mode != _abi.RNG_PHILOX or custom is not None):
+    if slot16 and (prof.rng_mode == _abi.RNG_REFERENCE or custom is not None):
         raise SystemExit("--layout slot16 is the counter mode's layout (minimal-short / minimal-long with --rng philox)")
     eng.set_read_slots(16 if slot16 else 0)
 
@@ -165,19 +172,29 @@ def main():
     def plan():
         if long_mode:  # shard = range of global read indices
             return eng.long_plan([0], [total_reads], prof, args.seed, first, 2 * pairs_per_gpu)
-        if "pos" not in shard_start:
-            shard_start["pos"] = seek_outer_stream(eng, pieces, (0, 1, first), args.seed) if world > 1 else (0, 0)
+        if "pos" not in shard_start:  # (SIMMR_RNG_PHILOX_FULL: a pair's draws are a function of its index, no stream to seek in)
+            shard_start["pos"] = seek_outer_stream(eng, pieces, (0, 1, first), args.seed) if (world > 1 and prof.rng_mode != _abi.RNG_PHILOX_FULL) else (0, 0)
         return eng.pe_plan(0, prof, total_reads, args.seed, first, pairs_per_gpu, shard_start["pos"])
 
     # sizes are a deterministic function of (seed, shard): plan once to allocate
     info = plan()
     # (one pair of buffers serves both layouts of the side measurements: sized for the larger, the slots)
-    slot_capable = prof.rng_mode == _abi.RNG_PHILOX and custom is None and args.profile != "perfect-short"
+    slot_capable = prof.rng_mode != _abi.RNG_REFERENCE and custom is None and args.profile != "perfect-short"
     cap_bases = info.total_bases
     if slot_capable and not slot16 and world == 1 and not args.no_other_mode:
         eng.set_read_slots(16)
         cap_bases = max(cap_bases, plan().total_bases)
         eng.set_read_slots(0)
+        info = plan()
+    if world == 1 and not args.no_other_mode and args.rng == "philox" and args.profile in ("minimal-short", "minimal-long"):
+        # (the `other_plan` side measurement draws other lengths: size the buffers for the larger of the two runs)
+        keep_mode = prof.rng_mode
+        prof.rng_mode = _abi.RNG_PHILOX if plan_full else _abi.RNG_PHILOX_FULL
+        for sb in ((16, 0) if slot_capable else (16 if slot16 else 0,)):
+            eng.set_read_slots(sb)
+            cap_bases = max(cap_bases, plan().total_bases)
+        prof.rng_mode = keep_mode
+        eng.set_read_slots(16 if slot16 else 0)
         info = plan()
     out = Reads.allocate(info.n_reads, cap_bases, eng.device, qual_offset=33, slot_bytes=info.slot_bytes)
     out.total_bases = int(info.total_bases)
@@ -256,7 +273,7 @@ def main():
     other = None
     if world == 1 and not args.no_other_mode and args.profile != "perfect-short":
         keep_mode, keep_c = prof.rng_mode, counters_dev.clone()
-        prof.rng_mode = _abi.RNG_REFERENCE if args.rng == "philox" else _abi.RNG_PHILOX
+        prof.rng_mode = _abi.RNG_REFERENCE if args.rng == "philox" else (_abi.RNG_PHILOX_FULL if plan_full else _abi.RNG_PHILOX)
         if slot16:  # (the reference's streams are walked by kernels that write the compact layout)
             eng.set_read_slots(0)
             out.slot_bytes = 0
@@ -300,6 +317,29 @@ def main():
         eng.set_read_slots(16 if slot16 else 0)
         out.slot_bytes = 16 if slot16 else 0
         step(False)  # (the columns of the timed layout again: the read lengths below come from them)
+        counters_dev.copy_(keep_c)
+
+    # untimed side measurement of the other plan (N = 1): the same step with the plan drawn from the reference's streams
+    # (SIMMR_RNG_PHILOX: what `value` was measured with before the full counter mode existed) — or from counters
+    other_plan = None
+    if world == 1 and not args.no_other_mode and args.rng == "philox" and args.profile in ("minimal-short", "minimal-long") \
+            and not args.through_fastq:
+        keep_mode, keep_c = prof.rng_mode, counters_dev.clone()
+        prof.rng_mode = _abi.RNG_PHILOX if plan_full else _abi.RNG_PHILOX_FULL
+        step(False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step(False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 3
+        other_plan = {"plan": ("the reference's ChaCha12 streams (SIMMR_RNG_PHILOX: positions, lengths and seeds of the reference run)"
+                               if plan_full else "Philox counters (SIMMR_RNG_PHILOX_FULL)"),
+                      "value": info.n_reads / dt, "unit": "reads/s", "ms_per_step": dt * 1e3, "plan_ms": eng.last_plan_ms(),
+                      "kernel_ms": eng.last_emit_kernel_ms(), "steps": 3,
+                      "note": "three steps after one warm-up step, same shard, outside the timed region"}
+        prof.rng_mode = keep_mode
+        step(False)  # (the columns of the timed mode again: the read lengths below come from them)
         counters_dev.copy_(keep_c)
 
     # untimed side measurement: the same step through FASTQ text (N = 1, the default command only)
@@ -378,7 +418,9 @@ def main():
                             + f", 1 genome ({args.genome_bases} bp synthetic SplitMix64 seed 2), "
                             f"{2 * pairs_per_gpu} reads per GPU per step, seed {args.seed}",
                 "rng": ("reference StdRng streams (ChaCha12), bit-exact mode" if args.rng == "reference" else
-                        "Philox4x32-10 counter mode for per-base draws (tolerance parity)"),
+                        "Philox4x32-10 counter mode for every draw of the path — contig, seeds, lengths, positions and the per-base "
+                        "draws (SIMMR_RNG_PHILOX_FULL, include/simmr_hip.h; tolerance parity)" if plan_full else
+                        "Philox4x32-10 counter mode for per-base draws, plan from the reference's streams (tolerance parity)"),
                 "layout": ("slot16: every read in a 16-byte-aligned slot of seq / qual (SIMMR_SLOT16, include/simmr_hip.h), "
                            f"{2 * int(info.total_bases)} stream bytes per step" if slot16 else
                            f"compact: seq / qual byte streams without gaps, {2 * int(info.total_bases)} stream bytes per step"),
@@ -439,6 +481,8 @@ def main():
             result["other_rng_mode"] = other
         if other_layout is not None:
             result["other_layout"] = other_layout
+        if other_plan is not None:
+            result["other_plan"] = other_plan
         if through is not None:
             result["through_fastq"] = through
         if args.through_fastq:

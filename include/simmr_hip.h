@@ -90,9 +90,26 @@ enum simmr_profile_kind {
  *     n-column alias table over the residual law (thresholds in 2^24ths), fraction (m & 0xffffffff) >> 8.
  *     (oracle/custom.c: ctr_splice_tables / orc_custom_simulate_errors_philox; the paired-end path of a custom model
  *     has no base-by-base draws and refuses the mode.)
- *   Positions, lengths and seeds still come from the reference's streams.  Statistical tolerance only (BASELINE.json north_star): the law is the reference's
- *   (minimal_short.rs:83-140), the bits are not. */
-enum simmr_rng_mode { SIMMR_RNG_REFERENCE = 0, SIMMR_RNG_PHILOX = 1 };
+ *   Positions, lengths and seeds still come from the reference's streams.  Statistical tolerance only (BASELINE.json
+ *   north_star): the law is the reference's (minimal_short.rs:83-140), the bits are not.
+ * PHILOX_FULL: PHILOX, and the draws of the PLAN from Philox counters as well — what north_star describes ("random
+ *   start-position draw, length draw, per-base draws: counter-based"), and what makes a shard's plan a function of its
+ *   pair indices alone (no stream to walk or to seek in: the plan path costs a quarter).  Specification, version 1:
+ *     every generator the reference seeds on the way to a read — StdRng::seed_from_u64(s) for the lengths
+ *     (minimal_short.rs:33-67), the start position and the two mate-2 seeds (simulate.rs:227-270), a long read's own
+ *     generator — is the word stream W(s): word w = word w & 3 of the Philox4x32-10 block with key = s and counter
+ *     (w >> 2, 3, 0x73696D6D, 0x72000003), consumed in the reference's order by the reference's algorithms (gen_range with
+ *     its rejection zone, the ziggurat, Gamma, Option<u64>);
+ *     the genome's outer stream (simulate.rs:172-186, one generator walked pair by pair) becomes one block per pair: pair p
+ *     of the genome's run takes the block with key = the run's seed and counter (p & 0xffffffff, 4 | (p >> 32) << 8,
+ *     0x73696D6D, 0x72000003) = (w0, w1, w2, w3): contig = ((w0 | w1 << 32) * num_seqs) >> 64, pe_seed = w2 | w3 << 32
+ *     (as in the reference, every genome of a run sees the same seed);
+ *     the per-base draws are PHILOX's, keyed by the seeds this plan makes.
+ *   Minimal-short, and minimal-long / perfect-long with SIMMR_LEN_PER_READ (the one constant length of a seeded reference
+ *   run, simulate.rs:358, is a property of its stream); not the custom profiles.  Restated in oracle/ (rand08.c: the
+ *   generator's second word source; simulate.c: orc_pe_outer_ctr), compared bit for bit; law tests in
+ *   tests/test_gpu_parity.py::test_philox_full_*. */
+enum simmr_rng_mode { SIMMR_RNG_REFERENCE = 0, SIMMR_RNG_PHILOX = 1, SIMMR_RNG_PHILOX_FULL = 2 };
 
 /* Long-read length policy (Appendix A Q5 of SURVEY.md).
  * REFERENCE: with a seed, get_random_read_length(seed) (simulate.rs:358) is

@@ -44,7 +44,12 @@ typedef struct orc_rng {
   uint32_t results[64]; /* rand_chacha 0.3.1 buffers 4 blocks per refill     */
   uint32_t index;       /* next unread word, 64 = empty                      */
   uint64_t words_used;  /* oracle-only bookkeeping: words consumed so far    */
+  uint32_t ctr;         /* 1: SIMMR_RNG_PHILOX_FULL's word stream W(seed) instead of ChaCha12 (key[0..1] = seed) */
 } orc_rng;
+/* Which word source orc_rng_seed_from_u64 gives the generators it makes ON THIS THREAD: 0 = the reference's (PCG32
+ * expansion + ChaCha12), 1 = SIMMR_RNG_PHILOX_FULL's W(seed): word w = word w & 3 of the Philox4x32-10 block with key =
+ * seed and counter (w >> 2, 3, 'simm', 'r\0\0\3').  The plan functions of simulate.c switch it on around their draws. */
+void orc_set_stream_kind(int kind);
 
 void orc_chacha_block(const uint32_t key[8], uint64_t counter, uint32_t rounds, uint32_t out[16]);
 void orc_pcg32_expand(uint64_t state, uint32_t key_out[8]);
@@ -118,6 +123,8 @@ typedef struct orc_genome {
 /* simulate_pe_reads_from_genome's outer loop (simulate.rs:172-184): fills
  * contig_idx[i], pe_seed[i] for pairs [first, first+count).  *slots = u64
  * draws consumed up to the end of the last returned pair. */
+/* SIMMR_RNG_PHILOX_FULL: the outer draws of pairs [first, first + count) of a genome's run, one Philox block per pair */
+int orc_pe_outer_ctr(uint64_t n_contigs, uint64_t seed, uint64_t first, uint64_t count, uint32_t* contig_idx, uint64_t* pe_seed);
 int orc_pe_outer(uint64_t n_contigs, uint64_t seed, uint64_t first, uint64_t count,
                  uint32_t* contig_idx, uint64_t* pe_seed, uint64_t* slots);
 

@@ -56,7 +56,12 @@ void orc_pcg32_expand(uint64_t state, uint32_t key_out[8]) {
   }
 }
 
+static _Thread_local int g_stream_kind = 0;
+void orc_set_stream_kind(int kind) { g_stream_kind = kind; }
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);  /* philox.c */
+
 void orc_rng_from_seed(orc_rng* r, const uint8_t seed[32]) {
+  r->ctr = 0;
   for (int i = 0; i < 8; i++)
     r->key[i] = (uint32_t)seed[4 * i] | (uint32_t)seed[4 * i + 1] << 8 |
                 (uint32_t)seed[4 * i + 2] << 16 | (uint32_t)seed[4 * i + 3] << 24;
@@ -66,6 +71,9 @@ void orc_rng_from_seed(orc_rng* r, const uint8_t seed[32]) {
 }
 
 void orc_rng_seed_from_u64(orc_rng* r, uint64_t state) {
+  r->ctr = g_stream_kind ? 1u : 0u;
+  if (r->ctr) { memset(r->key, 0, sizeof r->key); r->key[0] = (uint32_t)state; r->key[1] = (uint32_t)(state >> 32); }
+  else
   orc_pcg32_expand(state, r->key);
   r->counter = 0;
   r->index = 64;
@@ -74,6 +82,12 @@ void orc_rng_seed_from_u64(orc_rng* r, uint64_t state) {
 
 /* BlockRng::generate_and_set: refill 4 consecutive blocks. */
 static void refill(orc_rng* r, uint32_t index) {
+  if (r->ctr) {  /* the next 64 words of W(seed): sixteen Philox blocks (r->counter counts 16-word units as for ChaCha) */
+    for (uint32_t b = 0; b < 16; b++) {
+      const uint32_t c[4] = {(uint32_t)(4 * r->counter + b), 3u, 0x73696D6Du, 0x72000003u};
+      orc_philox4x32_10(c, r->key, r->results + 4 * b);
+    }
+  } else
   for (int b = 0; b < 4; b++) orc_chacha_block(r->key, r->counter + b, 12, r->results + 16 * b);
   r->counter += 4;
   r->index = index;

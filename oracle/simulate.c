@@ -342,8 +342,33 @@ int orc_pe_outer(uint64_t n_contigs, uint64_t seed, uint64_t first, uint64_t cou
   return 0;
 }
 
+/* SIMMR_RNG_PHILOX_FULL (include/simmr_hip.h): the outer stream as one Philox block per pair — pair i of the genome's run
+ * takes the block with key = seed and counter (i & 0xffffffff, 4 | (i >> 32) << 8, 'simm', 'r\0\0\3') = (w0, w1, w2, w3):
+ * contig = ((w0 | w1 << 32) * n_contigs) >> 64, pe_seed = w2 | w3 << 32. */
+int orc_pe_outer_ctr(uint64_t n_contigs, uint64_t seed, uint64_t first, uint64_t count, uint32_t* contig_idx, uint64_t* pe_seed) {
+  if (n_contigs == 0) FAIL(SIMMR_EGENOME, "genome has no sequences");
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (uint64_t i = first; i < first + count; i++) {
+    const uint32_t ctr[4] = {(uint32_t)i, 4u | ((uint32_t)(i >> 32) << 8), 0x73696D6Du, 0x72000003u};
+    uint32_t w[4];
+    orc_philox4x32_10(ctr, key, w);
+    const unsigned __int128 m = (unsigned __int128)((uint64_t)w[0] | ((uint64_t)w[1] << 32)) * n_contigs;
+    contig_idx[i - first] = (uint32_t)(uint64_t)(m >> 64);
+    pe_seed[i - first] = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+  }
+  return 0;
+}
+
 /* simulate.rs:211-258 and the two Option<u64> draws at :266,:270 */
+static int pe_plan_pair_draws(const simmr_error_profile* p, uint64_t size, uint64_t pe_seed, orc_pe_plan* pl);
 int orc_pe_plan_pair(const simmr_error_profile* p, uint64_t size, uint64_t pe_seed, orc_pe_plan* pl) {
+  /* SIMMR_RNG_PHILOX_FULL: every generator made below is W(its seed) instead of StdRng */
+  orc_set_stream_kind(p->rng_mode == SIMMR_RNG_PHILOX_FULL);
+  const int rc = pe_plan_pair_draws(p, size, pe_seed, pl);
+  orc_set_stream_kind(0);
+  return rc;
+}
+static int pe_plan_pair_draws(const simmr_error_profile* p, uint64_t size, uint64_t pe_seed, orc_pe_plan* pl) {
   uint16_t L16, I16, req16;
   int rc;
   if ((rc = orc_profile_get_read_length(p, pe_seed, &L16))) return rc;  /* :211 */
@@ -400,8 +425,8 @@ static int pe_emit_pair(const orc_genome* g, const simmr_error_profile* p, uint3
   uint8_t* tmp = (uint8_t*)malloc(L ? L : 1);
   if (!tmp) FAIL(SIMMR_ENOMEM, "oom");
   int rc;
-  if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_MINIMAL_SHORT) {
-    /* counter mode (philox.c): one key per read = its Phred seed */
+  if (p->rng_mode != SIMMR_RNG_REFERENCE && p->kind == SIMMR_MINIMAL_SHORT) {
+    /* counter modes (philox.c): one key per read = its Phred seed */
     orc_philox_read(p, seq + pl->fwd_start, L, pe_seed, o->qual + o1, o->seq + o1);
     orc_philox_read(p, seq + pl->rev_end, L, pl->qseed2, o->qual + o2, tmp);
     orc_reverse_complement(tmp, L, o->seq + o2);
@@ -436,6 +461,8 @@ int orc_simulate_pe_reads_from_genome(const orc_genome* g, const simmr_error_pro
                                       uint64_t count, uint32_t read_id_base,
                                       const simmr_reads_out* out, uint64_t* total_bases,
                                       int threads) {
+  if (p->rng_mode == SIMMR_RNG_PHILOX_FULL && p->kind != SIMMR_MINIMAL_SHORT)
+    FAIL(SIMMR_EINVAL, "SIMMR_RNG_PHILOX_FULL on the paired-end path: minimal-short only");
   uint64_t n_pairs = genome_reads / 2; /* simulate.rs:179 */
   if (first > n_pairs) first = n_pairs;
   if (count > n_pairs - first) count = n_pairs - first;
@@ -444,7 +471,8 @@ int orc_simulate_pe_reads_from_genome(const orc_genome* g, const simmr_error_pro
   uint64_t* seeds = (uint64_t*)malloc(sizeof(uint64_t) * (count ? count : 1));
   orc_pe_plan* plans = (orc_pe_plan*)malloc(sizeof(orc_pe_plan) * (count ? count : 1));
   if (!cidx || !seeds || !plans) { free(cidx); free(seeds); free(plans); FAIL(SIMMR_ENOMEM, "oom"); }
-  int rc = orc_pe_outer(g->n_contigs, seed, first, count, cidx, seeds, NULL);
+  int rc = p->rng_mode == SIMMR_RNG_PHILOX_FULL ? orc_pe_outer_ctr(g->n_contigs, seed, first, count, cidx, seeds)
+                                                : orc_pe_outer(g->n_contigs, seed, first, count, cidx, seeds, NULL);
   int err = 0;
   if (!rc) {
 #pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1) if (threads > 1)
@@ -537,6 +565,8 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
   if (out->reads_capacity < count) FAIL(SIMMR_ERANGE, "reads_capacity too small");
   int per_read = (!has_seed) || p->length_mode == SIMMR_LEN_PER_READ;
   if (p->kind == SIMMR_CUSTOM && !orc_profile_is_long_read(p)) FAIL(SIMMR_EINVAL, "a short-read custom model on the long-read path");
+  if (p->rng_mode == SIMMR_RNG_PHILOX_FULL && (p->kind == SIMMR_CUSTOM || !per_read))
+    FAIL(SIMMR_EINVAL, "SIMMR_RNG_PHILOX_FULL: minimal-long / perfect-long with per-read lengths only");
   long_unit* units = (long_unit*)calloc(count ? count : 1, sizeof(long_unit));
   if (!units) FAIL(SIMMR_ENOMEM, "oom");
   int rc = 0;
@@ -587,7 +617,9 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
       for (uint64_t k = 0; k < genome_reads[g]; k++, gi++) {
         if (gi >= first + count) break;
         if (gi < first) continue;
+        orc_set_stream_kind(p->rng_mode == SIMMR_RNG_PHILOX_FULL);  /* the read's own generator: W(seed) in the full counter mode */
         orc_rng r; orc_rng_seed_from_u64(&r, orc_per_read_seed(seed, gi));
+        orc_set_stream_kind(0);
         long_unit* u = &units[gi - first];
         for (int tries = 0;; tries++) {
           uint32_t L;
@@ -622,8 +654,10 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
 #pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1) if (threads > 1)
     for (int64_t k = 0; k < (int64_t)count; k++) {
       long_unit* u = &units[k];
+      orc_set_stream_kind(p->rng_mode == SIMMR_RNG_PHILOX_FULL);
       int r2 = long_window(genomes[u->genome].size[u->contig], u->read_length, u->read_seed,
                            p->long_start_mode == SIMMR_START_UNIFORM, &u->start, &u->end);
+      orc_set_stream_kind(0);
       if (r2) {
 #pragma omp critical
         { if (!err) err = r2; }
@@ -648,7 +682,7 @@ int orc_simulate_long_reads(const orc_genome* genomes, uint32_t n_genomes,
       if (g_faithful_cost) pay_reference_clones(G, u->contig, u->read_length);
       if (u->end > G->len[u->contig]) { r2 = SIMMR_ERANGE; }
       /* :497 quality over end-start; :500 simulate_errors = copy; :503 mutations */
-      if (!r2 && p->rng_mode == SIMMR_RNG_PHILOX && (p->kind == SIMMR_MINIMAL_LONG || p->kind == SIMMR_PERFECT_LONG)) {
+      if (!r2 && p->rng_mode != SIMMR_RNG_REFERENCE && (p->kind == SIMMR_MINIMAL_LONG || p->kind == SIMMR_PERFECT_LONG)) {
         orc_philox_read(p, G->seq[u->contig] + u->start, n, u->read_seed, out->qual + o1, out->seq + o1);
       } else if (!r2 && p->kind == SIMMR_CUSTOM) {
         /* :497 quality; :500 simulate_errors (the k-mer splice); :503 simulate_point_mutations = copy */

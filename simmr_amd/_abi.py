@@ -20,7 +20,7 @@ OK, EINVAL, ENOMEM, ENODEV, ERANGE, ESTATE, EGENOME, ENOTSUP = 0, -22, -12, -19,
 PERFECT_SHORT, MINIMAL_SHORT, PERFECT_LONG, MINIMAL_LONG, CUSTOM = range(5)
 COMM_ID_BYTES = 128
 # enum simmr_rng_mode
-RNG_REFERENCE, RNG_PHILOX = 0, 1
+RNG_REFERENCE, RNG_PHILOX, RNG_PHILOX_FULL = 0, 1, 2
 # enum simmr_length_mode
 LEN_REFERENCE, LEN_PER_READ = 0, 1
 # enum simmr_long_start_mode

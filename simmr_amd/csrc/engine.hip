@@ -406,10 +406,14 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
 int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, ProfileDev* out) {
   if (!p) return e->fail(SIMMR_EINVAL, "profile is NULL");
   if (p->kind > SIMMR_CUSTOM) return e->fail(SIMMR_EINVAL, "unknown profile kind %u", p->kind);
-  if (p->rng_mode > SIMMR_RNG_PHILOX) return e->fail(SIMMR_EINVAL, "unknown rng_mode %u", p->rng_mode);
+  if (p->rng_mode > SIMMR_RNG_PHILOX_FULL) return e->fail(SIMMR_EINVAL, "unknown rng_mode %u", p->rng_mode);
+  // the full counter mode (the plan's draws from Philox counters too): the parametric profiles that draw per base
+  if (p->rng_mode == SIMMR_RNG_PHILOX_FULL && (p->kind == SIMMR_CUSTOM || p->kind == SIMMR_PERFECT_SHORT))
+    return e->fail(SIMMR_EINVAL, "SIMMR_RNG_PHILOX_FULL covers minimal-short, minimal-long and perfect-long (a custom model's lengths "
+                                 "and qualities, and perfect-short as a whole, are the reference's streams)");
   // a custom model has one place where draws are made base by base: the k-mer splice of its long-read path
   // (simulate_errors, custom_short.rs:455-516; the qualities use the same few words at every position)
-  if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind == SIMMR_CUSTOM && !want_long)
+  if (p->rng_mode != SIMMR_RNG_REFERENCE && p->kind == SIMMR_CUSTOM && !want_long)
     return e->fail(SIMMR_EINVAL, "SIMMR_RNG_PHILOX covers the profiles that draw base by base: minimal-short, minimal-long, "
                                  "perfect-long and the k-mer splice of a custom long-read model");
   if (p->kind == SIMMR_CUSTOM) {
@@ -451,7 +455,7 @@ int make_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, 
         (!(p->read_length_std >= 0.0) || !(p->insert_size_std >= 0.0)))
       return e->fail(SIMMR_EINVAL, "negative standard deviation");
   }
-  if (p->rng_mode == SIMMR_RNG_PHILOX && p->kind != SIMMR_PERFECT_SHORT) {
+  if (p->rng_mode != SIMMR_RNG_REFERENCE && p->kind != SIMMR_PERFECT_SHORT) {
     // The two tables of the counter mode.  The joint law over the 1024
     // outcomes o = q | s << 8, w(q,0) = P(q)(1 - p_q), w(q,s) = P(q) p_q / 3 (P(q) = the profile's Phred law,
     // p_q = the probability of the reference's 24-bit test gen::<f32>() > accuracy(q), minimal_short.rs:83-140),
@@ -738,7 +742,7 @@ int read_err_word(simmr_engine* e, uint32_t* w) {
 // are a preference: the counter-mode item kernel (k_emit_philox) writes them; a plan whose emit kernel does not gets the
 // compact layout and says so in simmr_plan_info.slot_bytes, which is what the caller sizes and labels its buffers from.
 int plan_slot_round(simmr_engine* e, const ProfileDev& prof, uint32_t* round) {
-  const bool offered = !(prof.kind == SIMMR_K_CUSTOM || prof.kind == SIMMR_K_PERFECT_SHORT || prof.rng_mode != SIMMR_RNG_PHILOX);
+  const bool offered = !(prof.kind == SIMMR_K_CUSTOM || prof.kind == SIMMR_K_PERFECT_SHORT || prof.rng_mode == SIMMR_RNG_REFERENCE);
   *round = (e->read_slots == SIMMR_SLOT16 && offered) ? 15u : 0u;
   return SIMMR_OK;
 }
@@ -753,14 +757,15 @@ int plan_slot_round(simmr_engine* e, const ProfileDev& prof, uint32_t* round) {
 // profiles/r3/plan_register_form_kernels.txt)
 int launch_plan_pe(simmr_engine* e, const ProfileDev& prof, uint32_t genome, uint64_t count, const uint32_t* u_genome,
                    const PlanArrays& pw, unsigned long long* tiles, uint32_t slot_round, unsigned long long* wave_bytes) {
-  hipLaunchKernelGGL(k_plan_pe, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
+  auto plan_kern = prof.rng_mode == SIMMR_RNG_PHILOX_FULL ? k_plan_pe<true> : k_plan_pe<false>;
+  hipLaunchKernelGGL(plan_kern, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                      e->d_genomes.as<GenomeDev>(), genome, count, e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(), u_genome, pw,
                      e->d_tables.as<Tables>(), e->d_err.as<uint32_t>(), tiles, slot_round, wave_bytes);
   return SIMMR_OK;
 }
 
 bool plan_is_coarse(simmr_engine* e, const ProfileDev& prof) {
-  return prof.rng_mode == SIMMR_RNG_PHILOX && prof.kind != SIMMR_K_CUSTOM && prof.kind != SIMMR_K_PERFECT_SHORT && e->philox_form != 2;
+  return prof.rng_mode != SIMMR_RNG_REFERENCE && prof.kind != SIMMR_K_CUSTOM && prof.kind != SIMMR_K_PERFECT_SHORT && e->philox_form != 2;
 }
 
 int check_out(simmr_engine* e, const simmr_reads_out* out, uint64_t n_reads, uint64_t total) {
@@ -1292,12 +1297,20 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   const bool coarse = plan_is_coarse(e, prof);
   if (count > 0) {
     // the stream is entered at pair start_unit (slot start_slot): units are counted from there
-    rc = run_outer(e, seed, g.contigs.size(), start_slot, first - start_unit + count, first - start_unit, count,
-                   e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(), &end_slot);
+    if (prof.rng_mode == SIMMR_RNG_PHILOX_FULL) {
+      // one Philox block per pair (k_outer_ctr): nothing to walk, nothing to seek in (start_slot / start_unit have no meaning)
+      hipLaunchKernelGGL(k_outer_ctr, dim3(grid_for(count, 256)), dim3(256), 0, e->stream, (const MultiGenome*)nullptr, 0u,
+                         e->d_genomes.as<GenomeDev>(), (uint32_t)g.contigs.size(), seed, first, count, (uint32_t*)nullptr,
+                         e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>());
+      rc = SIMMR_OK;
+    } else {
+      rc = run_outer(e, seed, g.contigs.size(), start_slot, first - start_unit + count, first - start_unit, count,
+                     e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(), &end_slot);
+    }
     if (rc) return rc;
     PlanArrays pw = plan_arrays(e, seeds2);
     // the mutation seed of mate 2 is only read by the kernels that walk the reference's mutation stream
-    if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode == SIMMR_RNG_PHILOX) pw.ms2 = nullptr;
+    if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode != SIMMR_RNG_REFERENCE) pw.ms2 = nullptr;
     // the plan kernel adds each pair's bytes to its tile of the offset scan (sort_by_length uses the same scratch first)
     presummed = prof.kind != SIMMR_K_PERFECT_SHORT && !coarse &&
                 !(prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0);
@@ -1415,17 +1428,24 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
   uint64_t end_slot = 0, total = 0;
   bool presummed = false;
   const bool coarse = plan_is_coarse(e, prof);
+  const bool full = prof.rng_mode == SIMMR_RNG_PHILOX_FULL;
   for (const Cls& c : classes) {  // run_outer synchronises, so `mg` has been uploaded when it returns
+    if (full) break;  // (no outer lists: every pair's block is made where the pair is planned)
     if ((rc = run_outer(e, seed, c.range, 0, c.need, 0, c.need, e->m_contig.as<uint32_t>() + c.off,
                         e->m_seed.as<uint64_t>() + c.off, &end_slot)))
       return rc;
   }
   if (count > 0) {
+    if (full)
+      hipLaunchKernelGGL(k_outer_ctr, dim3(grid_for(count, 256)), dim3(256), 0, e->stream, e->m_genomes.as<MultiGenome>(), n_genomes,
+                         e->d_genomes.as<GenomeDev>(), 0u, seed, first, count, e->u_genome.as<uint32_t>(),
+                         e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>());
+    else
     hipLaunchKernelGGL(k_multi_units, dim3(grid_for(count, 256)), dim3(256), 0, e->stream, e->m_genomes.as<MultiGenome>(),
                        n_genomes, first, count, e->m_contig.as<uint32_t>(), e->m_seed.as<uint64_t>(),
                        e->u_genome.as<uint32_t>(), e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>());
     PlanArrays pw = plan_arrays(e, seeds2);
-    if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode == SIMMR_RNG_PHILOX) pw.ms2 = nullptr;
+    if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode != SIMMR_RNG_REFERENCE) pw.ms2 = nullptr;
     presummed = prof.kind != SIMMR_K_PERFECT_SHORT && !coarse && !(prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE);
     unsigned long long* tiles = presummed ? tile_sums_begin(e, count) : nullptr;
     if (presummed && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
@@ -1486,7 +1506,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
   const uint32_t* u_genome = (paired && !e->plan_multi) ? nullptr : e->u_genome.as<uint32_t>();
   // the Philox and perfect-short emit kernels write the metadata columns and the plan counters themselves
   const bool fused = n_units > 0 && (e->prof.kind == SIMMR_K_PERFECT_SHORT ||
-                                     (e->prof.kind != SIMMR_K_CUSTOM && e->prof.rng_mode == SIMMR_RNG_PHILOX));
+                                     (e->prof.kind != SIMMR_K_CUSTOM && e->prof.rng_mode != SIMMR_RNG_REFERENCE));
   if (!fused)
     hipLaunchKernelGGL(k_write_meta, dim3(grid_for(n_units + 1, 256)), dim3(256), 0, e->stream,
                        paired ? 1u : 0u, n_units, e->plan_first, read_id_base, e->plan_genome, pl,
@@ -1502,7 +1522,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->plan_genome, u_genome, e->plan_any_exc ? 1u : 0u, n_units, e->prof.read_length, pl,
                          e->u_contig.as<uint32_t>(), out->seq,
                          out->qual, 60u + out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters);
-    } else if (e->prof.rng_mode == SIMMR_RNG_PHILOX && e->prof.kind != SIMMR_K_CUSTOM) {  // (a custom model's counter mode: below)
+    } else if (e->prof.rng_mode != SIMMR_RNG_REFERENCE && e->prof.kind != SIMMR_K_CUSTOM) {  // (a custom model's counter mode: below)
       bool exc = false;
       if (paired) exc = e->plan_any_exc;
       else for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);
@@ -1570,7 +1590,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->d_err.as<uint32_t>());
       bool fast = e->prof.custom.kmer_stride != 0;
       if (e->splice_variant == 1) fast = false;  // the two-load kernel (A/B timing)
-      if (e->prof.rng_mode == SIMMR_RNG_PHILOX) {
+      if (e->prof.rng_mode != SIMMR_RNG_REFERENCE) {
         // the counter mode of the splice (kernels.hip section 9c, CTR): the LDS holds one word per k-mer (4^k words);
         // with k = 7 (64 KB) two workgroups of 768 lanes share a CU — six waves per SIMD, what the kernel's registers allow —
         // with smaller tables 256-lane workgroups do
@@ -1706,6 +1726,9 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   uint64_t first = std::min(shard.first, total_reads);
   uint64_t count = std::min(shard.count, total_reads - first);
   const bool per_read = !has_seed || profile->length_mode == SIMMR_LEN_PER_READ;
+  if (prof.rng_mode == SIMMR_RNG_PHILOX_FULL && !per_read)
+    return e->fail(SIMMR_EINVAL, "SIMMR_RNG_PHILOX_FULL plans long reads with SIMMR_LEN_PER_READ only (the one constant length of a "
+                                 "seeded reference run, simulate.rs:358, is a property of the reference's stream)");
   if (!has_seed) seed = os_entropy_u64();
   if ((rc = ensure_plan_arrays(e, count, false, true))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_a, e->stream));
@@ -1785,7 +1808,8 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
                          count, L0, prof.long_start_uniform, e->u_contig.as<uint32_t>(), e->u_genome.as<uint32_t>(),
                          e->u_seed.as<uint64_t>(), plan_arrays(e, false), e->d_err.as<uint32_t>());
     } else {
-      hipLaunchKernelGGL(k_plan_long_per_read, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0,
+      auto plan_kern = prof.rng_mode == SIMMR_RNG_PHILOX_FULL ? k_plan_long_per_read<true> : k_plan_long_per_read<false>;
+      hipLaunchKernelGGL(plan_kern, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0,
                          e->stream, prof, e->d_genomes.as<GenomeDev>(), e->d_runs.as<LongGenomeRun>(),
                          (uint32_t)runs.size(), seed, first, count, e->u_contig.as<uint32_t>(),
                          e->u_genome.as<uint32_t>(), e->u_seed.as<uint64_t>(), plan_arrays(e, false),
@@ -2071,7 +2095,7 @@ static FqPlan fq_plan_view(simmr_engine* e) {
 // form for perfect-short (no draws at all: the planned bases, a constant quality line; perfect_short.rs:24-44)
 static bool fq_direct_kernel(const simmr_engine* e) {
   if (e->prof.kind == SIMMR_K_PERFECT_SHORT) return true;
-  return e->prof.kind != SIMMR_K_CUSTOM && e->prof.rng_mode == SIMMR_RNG_PHILOX;
+  return e->prof.kind != SIMMR_K_CUSTOM && e->prof.rng_mode != SIMMR_RNG_REFERENCE;
 }
 
 int simmr_fastq_plan_direct(simmr_engine* e, const char* header_format, const simmr_fastq_names* names,

@@ -460,7 +460,8 @@ k_outer_emit(OuterParams P, uint64_t first_block, uint64_t n_blocks, uint32_t fi
 // 2b. Custom (empirical) PDFs: CustomPDF::sample (custom_short.rs:108-151) =
 //     WeightedAliasIndex<f64>::sample, then Uniform<u32>::sample of the chosen bin.
 // ===========================================================================
-SIMMR_DEV uint32_t pdf_sample_lane(LaneRng& rng, const CustomDev& C, const PdfDev pdf, bool* bad) {
+template <typename Rng>
+SIMMR_DEV uint32_t pdf_sample_lane(Rng& rng, const CustomDev& C, const PdfDev pdf, bool* bad) {
   uint32_t c;
   for (;;) {  // uniform_index.sample
     const uint64_t m = (uint64_t)rng.next_u32() * pdf.n;
@@ -558,6 +559,32 @@ struct MultiGenome {
   uint32_t pad;
 };
 
+// SIMMR_RNG_PHILOX_FULL: the outer draws (simulate.rs:172-186) as one Philox block per pair — no stream, no scan.  Pair p
+// of its genome's run takes the block with key = the run's seed and counter (p & 0xffffffff, 4 | (p >> 32) << 8, ..):
+// contig = ((w0 | w1 << 32) * num_seqs) >> 64, pe_seed = w2 | w3 << 32.  mg == null: one genome (n_contigs), pairs
+// first .. first + n_units; else the plan over several genomes (k_multi_units' search).
+extern "C" __global__ void __launch_bounds__(256)
+k_outer_ctr(const MultiGenome* __restrict__ mg, uint32_t n_genomes, const GenomeDev* __restrict__ genomes, uint32_t n_contigs0,
+            uint64_t seed, uint64_t first, uint64_t n_units, uint32_t* __restrict__ u_genome,
+            uint32_t* __restrict__ u_contig, uint64_t* __restrict__ u_seed) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_units) return;
+  uint64_t p = first + k;
+  uint64_t nc = n_contigs0;
+  if (mg) {
+    uint32_t lo = 0, hi = n_genomes;  // last genome with base <= the global pair index
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (mg[mid].base <= p) lo = mid; else hi = mid; }
+    const MultiGenome g = mg[lo];
+    p -= g.base;
+    u_genome[k] = g.slot;
+    nc = genomes[g.slot].n_contigs;
+  }
+  uint32_t w[4];
+  philox4x32_10((uint32_t)p, 4u | ((uint32_t)(p >> 32) << 8), (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  u_contig[k] = (uint32_t)__umul64hi((uint64_t)w[0] | ((uint64_t)w[1] << 32), nc);
+  u_seed[k] = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+}
+
 extern "C" __global__ void __launch_bounds__(256)
 k_multi_units(const MultiGenome* __restrict__ mg, uint32_t n_genomes, uint64_t first, uint64_t n_units,
               const uint32_t* __restrict__ cls_contig, const uint64_t* __restrict__ cls_seed,
@@ -574,6 +601,7 @@ k_multi_units(const MultiGenome* __restrict__ mg, uint32_t n_genomes, uint64_t f
   u_seed[k] = cls_seed[g.cls_off + p];
 }
 
+template <bool CTR>
 SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t k,
                                   const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
                                   const uint32_t* __restrict__ u_genome, const PlanArrays& pl, const Tables* __restrict__ T,
@@ -581,7 +609,9 @@ SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __res
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8 /* per thread */
 
-extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
+// CTR: SIMMR_RNG_PHILOX_FULL — the pair's generators are the word streams W(seed) (rng_device.hpp: LaneRngT<true>)
+template <bool CTR>
+__global__ void __launch_bounds__(PLAN_THREADS)
 k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t n_units,
           const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
           const uint32_t* __restrict__ u_genome, PlanArrays pl, const Tables* __restrict__ T,
@@ -589,7 +619,7 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
           unsigned long long* __restrict__ wave_bytes) {
   __shared__ uint32_t rows[PLAN_THREADS * 17];
   uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
-  const uint32_t planned = k < n_units ? k_plan_pe_unit(prof, genomes, genome, k, u_contig, u_seed, u_genome, pl, T, err, rows) : 0u;
+  const uint32_t planned = k < n_units ? k_plan_pe_unit<CTR>(prof, genomes, genome, k, u_contig, u_seed, u_genome, pl, T, err, rows) : 0u;
   // The bytes this workgroup's pairs will write, added to the sum of their tile of the offset scan (SCAN_THREADS *
   // SCAN_ITEMS units: a multiple of this workgroup's 256), so that the scan needs no pass of its own to reduce them.
   // Or (wave_bytes: the plans the counter-mode emit kernel serves) the bytes of every 64 pairs by themselves: that kernel
@@ -607,6 +637,7 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
 }
 
 // one pair (the body of k_plan_pe); returns its read length L, 0 for a pair that cannot be planned
+template <bool CTR>
 SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t k,
                                   const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
                                   const uint32_t* __restrict__ u_genome, const PlanArrays& pl, const Tables* __restrict__ T,
@@ -614,8 +645,8 @@ SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __res
   const GenomeDev G = genomes[u_genome ? u_genome[k] : genome];  // u_genome: several genomes in one plan
   const uint64_t size = G.contigs[u_contig[k]].size;
   const uint64_t pe_seed = u_seed[k];
-  LaneRng rng;
-  rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);
+  LaneRngT<CTR> rng;
+  rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);  // (CTR: W(pe_seed), rng_device.hpp)
   uint64_t L = prof.read_length, I = prof.insert_size;
   if (prof.kind == SIMMR_K_MINIMAL_SHORT) {
     // minimal_short.rs:33-42 and :58-67: both re-seed with pe_seed, so both see
@@ -654,7 +685,7 @@ SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __res
   if (rng.gen_bool()) qs = rng.next_u64(); else { qs = entropy_substitute(pe_seed, 1); flags |= SIMMR_FLAG_QSEED_SUBST; }
   if (rng.gen_bool()) ms = rng.next_u64(); else { ms = entropy_substitute(pe_seed, 2); flags |= SIMMR_FLAG_MSEED_SUBST; }
   if (prof.kind == SIMMR_K_PERFECT_SHORT) flags &= (uint8_t)~(SIMMR_FLAG_QSEED_SUBST | SIMMR_FLAG_MSEED_SUBST);
-  if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode == SIMMR_RNG_PHILOX) flags &= (uint8_t)~SIMMR_FLAG_MSEED_SUBST;  // drawn but never used
+  if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode != SIMMR_RNG_REFERENCE) flags &= (uint8_t)~SIMMR_FLAG_MSEED_SUBST;  // drawn but never used
   // Rust would panic on an out-of-range slice; never silently read out of bounds.
   const uint64_t len = G.contigs[u_contig[k]].len;
   if (fs + L > len || re + L > len) { atomicOr(err, SIMMR_ERRBIT_SLICE); L = 0; }
@@ -711,7 +742,8 @@ k_plan_long_ref(const GenomeDev* __restrict__ genomes, const LongGenomeRun* __re
 
 // long reads, per-read mode (include/simmr_hip.h SIMMR_LEN_PER_READ): length,
 // contig and read seed all come from StdRng(per_read_seed(seed, read index)).
-extern "C" __global__ void __launch_bounds__(PLAN_THREADS)
+template <bool CTR>  // (CTR: SIMMR_RNG_PHILOX_FULL, as in k_plan_pe)
+__global__ void __launch_bounds__(PLAN_THREADS)
 k_plan_long_per_read(ProfileDev prof, const GenomeDev* __restrict__ genomes,
                      const LongGenomeRun* __restrict__ runs, uint32_t n_runs, uint64_t seed,
                      uint64_t first_unit, uint64_t n_units, uint32_t* __restrict__ u_contig,
@@ -723,7 +755,7 @@ k_plan_long_per_read(ProfileDev prof, const GenomeDev* __restrict__ genomes,
   const uint64_t gi = first_unit + k;
   const LongGenomeRun run = runs[find_run(runs, n_runs, gi)];
   const GenomeDev G = genomes[run.genome];
-  LaneRng rng;
+  LaneRngT<CTR> rng;
   rng.seed_from_u64(per_read_seed(seed, gi), rows + threadIdx.x * 17);
   uint32_t L = 0, contig = 0;
   uint64_t read_seed = 0;
@@ -2033,24 +2065,7 @@ k_emit_lanes(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t ge
 // ===========================================================================
 #include "fastq_format.hpp"  // (inside namespace simmr) header formatting, for the TEXT form of k_emit_philox
 
-SIMMR_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
-
-SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4]) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-  uint32_t c2 = 0x73696D6Du, c3 = 0x72000003u;
-#if defined(SIMMR_ABLATE_PHILOX)
-  out[0] = c0 * M0 + k0; out[1] = (c0 ^ c1) * M1 + k1; out[2] = out[0] ^ c2 ^ (k1 + W0); out[3] = out[1] ^ c3 ^ (k0 + W1);
-  return;
-#endif
-#pragma unroll
-  for (int r = 0; r < 10; r++) {
-    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;  // one v_mad_u64_u32 each
-    const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
-    c0 = xor3(h1, c1, k0); c1 = l1; c2 = xor3(h0, c3, k1); c3 = l0;
-    k0 += W0; k1 += W1;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
+// (xor3, philox4x32_10: rng_device.hpp — the plan kernels of SIMMR_RNG_PHILOX_FULL draw from it too)
 
 #define PHILOX_UNITS 128u
 #define PHILOX_READS 256u  /* 128 pairs x 2 mates */

@@ -104,41 +104,76 @@ struct Tables {
 
 #define SIMMR_ZIG_R 3.654152885361008796
 
+// Philox4x32-10 (Random123 constants; rocRAND's rocrand_philox4x32_10 with subsequence 'simm' | 'r\0\0\3' << 32): the
+// block with key (k0, k1) and counter (c0, c1, 'simm', 'r\0\0\3').  Two v_mad_u64_u32 and two v_bitop3_b32 per round.
+SIMMR_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+SIMMR_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  uint32_t c2 = 0x73696D6Du, c3 = 0x72000003u;
+#if defined(SIMMR_ABLATE_PHILOX)
+  out[0] = c0 * M0 + k0; out[1] = (c0 ^ c1) * M1 + k1; out[2] = out[0] ^ c2 ^ (k1 + W0); out[3] = out[1] ^ c3 ^ (k0 + W1);
+  return;
+#endif
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;  // one v_mad_u64_u32 each
+    const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
+    c0 = xor3(h1, c1, k0); c1 = l1; c2 = xor3(h0, c3, k1); c3 = l0;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
 // ---------------------------------------------------------------------------
 // LaneRng: BlockRng<ChaCha12Core> semantics for ONE lane, one block buffered in
 // a lane-private LDS row (17-word pitch -> conflict free).  Words are consumed
 // strictly consecutively, exactly like rand_core's BlockRng (the reference's
 // 4-block refill is only buffering).
-struct LaneRng {
+template <bool CTR>
+struct LaneRngT {
   Key key;
   uint64_t next_block;  // counter of the block that will be generated next
   uint32_t idx;         // next unread word in buf, 16 = empty
   uint32_t* buf;        // 16 words of LDS owned by this lane
   uint32_t words_used;
+  // CTR — SIMMR_RNG_PHILOX_FULL (include/simmr_hip.h): the same consumer over the word stream W(s) — word w = word w & 3
+  // of the Philox block with key = s and counter (w >> 2, 3, ..) — buffered eight words (two blocks) at a time: a
+  // pair's plan takes eight.  cap = words per refill (16 for ChaCha12); k0 / k1 = the key.  (A compile-time switch: with
+  // both word sources in one kernel the plan kernels lost a third of their waves to the registers of the one not in use.)
+  static constexpr uint32_t cap = CTR ? 8u : 16u;
+  uint32_t k0, k1;
 
   SIMMR_DEV void seed_from_u64(uint64_t s, uint32_t* lds_row) {
-    key = pcg32_expand(s);
+    if (CTR) { k0 = (uint32_t)s; k1 = (uint32_t)(s >> 32); } else { key = pcg32_expand(s); }
     next_block = 0;
-    idx = 16;
+    idx = cap;
     buf = lds_row;
     words_used = 0;
   }
   // same seed again (the reference re-creates StdRng::seed_from_u64(seed) for every
   // profile call): keep the key, and block 0 if it is still the buffered one
   SIMMR_DEV void restart() {
-    if (next_block == 1) { idx = 0; } else { next_block = 0; idx = 16; }
+    if (next_block == 1) { idx = 0; } else { next_block = 0; idx = cap; }
     words_used = 0;
   }
   SIMMR_DEV void refill() {
-    uint32_t o[16];
-    chacha12_block(key, next_block, o);
+    if (CTR) {  // (next_block counts refills: Philox blocks 2 next_block and 2 next_block + 1)
+      uint32_t o[8];
+      philox4x32_10(2u * (uint32_t)next_block, 3u, k0, k1, o);
+      philox4x32_10(2u * (uint32_t)next_block + 1u, 3u, k0, k1, o + 4);
 #pragma unroll
-    for (int i = 0; i < 16; i++) buf[i] = o[i];
+      for (int i = 0; i < 8; i++) buf[i] = o[i];
+    } else {
+      uint32_t o[16];
+      chacha12_block(key, next_block, o);
+#pragma unroll
+      for (int i = 0; i < 16; i++) buf[i] = o[i];
+    }
     next_block++;
     idx = 0;
   }
   SIMMR_DEV uint32_t next_u32() {
-    if (idx >= 16) refill();
+    if (idx >= cap) refill();
     words_used++;
     return buf[idx++];
   }
@@ -208,6 +243,7 @@ struct LaneRng {
     }
   }
 };
+using LaneRng = LaneRngT<false>;  // the reference's streams
 
 // saturating float -> integer `as` casts of Rust (NaN -> 0)
 SIMMR_DEV uint32_t sat_u8_f32(float f) {

@@ -387,7 +387,7 @@ std::string usage() {
          "  --seed <N>                    Random seed\n"
          "  --size-adjusted               Adjust by genome size\n"
          "  --contiguous                  Treat separate sequences in a genome as one contiguous sequence\n"
-         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths  --uniform-start  --host-fastq  --host-normalize  --device-chunk-reads <N>  --rng <reference|philox>\n";
+         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths  --uniform-start  --host-fastq  --host-normalize  --device-chunk-reads <N>  --rng <reference|philox|philox-full>\n";
 }
 
 static bool parse_u64(const std::string& s, uint64_t max, uint64_t* out) {
@@ -458,9 +458,10 @@ bool parse_cli_args(int argc, const char* const* argv, CliArgs* a, std::string* 
     else if (arg == "--per-read-lengths") a->per_read_lengths = true;
     else if (arg == "--rng") {
       if (!need(&v)) return false;
-      if (v == "philox") a->rng_philox = true;
-      else if (v == "reference") a->rng_philox = false;
-      else { *err = "invalid value for --rng (reference, philox)"; return false; }
+      if (v == "philox") { a->rng_philox = true; a->rng_philox_full = false; }
+      else if (v == "philox-full") { a->rng_philox = true; a->rng_philox_full = true; }
+      else if (v == "reference") { a->rng_philox = false; a->rng_philox_full = false; }
+      else { *err = "invalid value for --rng (reference, philox, philox-full)"; return false; }
     }
     else if (arg == "--uniform-start") a->uniform_start = true;
     else { *err = "Found argument '" + arg + "' which wasn't expected"; return false; }

@@ -418,6 +418,11 @@ static int run_main(int argc, char** argv) {
     if (pod.kind == SIMMR_CUSTOM && !is_long)
       return die("--rng philox is not defined for custom-short: its qualities are not drawn base by base and it edits no bases");
     if (pod.kind != SIMMR_PERFECT_SHORT) pod.rng_mode = SIMMR_RNG_PHILOX;  // (perfect-short draws nothing per base)
+    if (args.rng_philox_full) {  // the plan from counters too (the library says which profiles it serves)
+      if (pod.kind == SIMMR_PERFECT_SHORT || pod.kind == SIMMR_CUSTOM)
+        return die("--rng philox-full covers minimal-short, minimal-long and perfect-long");
+      pod.rng_mode = SIMMR_RNG_PHILOX_FULL;
+    }
   }
   const int has_seed = args.seed ? 1 : 0;
   const uint64_t seed = args.seed.value_or(0);

@@ -199,6 +199,8 @@ struct CliArgs {  // cli.rs:93-220, same flags and defaults
   bool per_read_lengths = false;                 // --per-read-lengths (SIMMR_LEN_PER_READ)
   bool rng_philox = false;  // --rng philox: the counter mode for the per-base draws (SIMMR_RNG_PHILOX; statistical parity,
                             // BASELINE.json north_star).  Default `reference`: the reference's own streams, byte-identical output
+  bool rng_philox_full = false;  // --rng philox-full: the plan's draws from Philox counters too (SIMMR_RNG_PHILOX_FULL): minimal-short,
+                                 // and minimal-long / perfect-long with --per-read-lengths
 };
 // returns false and fills err on a usage error (clap would exit(2)); help=true for --help
 bool parse_cli_args(int argc, const char* const* argv, CliArgs* out, std::string* err, bool* help);

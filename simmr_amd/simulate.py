@@ -21,6 +21,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+from . import _abi
 from ._abi import U64_MAX
 from .profiles import AbundanceProfile, ErrorProfile
 
@@ -157,7 +158,8 @@ def simulate_pe_reads(backend, num_reads: int, genomes: Sequence[GenomeRef], err
     pod = error_profile.pod()
     # Only the first genome of a rank's range can start in the middle of that genome's outer stream.
     start = {}
-    if world > 1 and seed is not None and hasattr(backend, "outer_summarize"):
+    # (RNG_PHILOX_FULL: a pair's outer draws are a function of its index — there is no stream to seek in)
+    if world > 1 and seed is not None and hasattr(backend, "outer_summarize") and pod.rng_mode != _abi.RNG_PHILOX_FULL:
         pieces = []
         for j in range(world):
             mid = [(gi, sh) for gi, sh in enumerate(pe_shards(reads_per_genome, j, world))

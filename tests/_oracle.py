@@ -14,7 +14,7 @@ LIB = ROOT / "oracle" / "liboracle.so"
 
 class Rng(C.Structure):
     _fields_ = [("key", C.c_uint32 * 8), ("counter", C.c_uint64), ("results", C.c_uint32 * 64),
-                ("index", C.c_uint32), ("words_used", C.c_uint64)]
+                ("index", C.c_uint32), ("words_used", C.c_uint64), ("ctr", C.c_uint32)]
 
 
 class Genome(C.Structure):

@@ -277,31 +277,33 @@ def test_cli_a_genome_without_a_pair_is_skipped(workdir, oracle):
 
 
 @pytest.mark.parametrize("profile,cls", [("minimal-short", MinimalShortErrorProfile), ("minimal-long", MinimalLongErrorProfile)])
-def test_cli_rng_philox(workdir, oracle, profile, cls):
+@pytest.mark.parametrize("mode", ["philox", "philox-full"])
+def test_cli_rng_philox(workdir, oracle, profile, cls, mode):
     """--rng philox (extension flag): the counter mode through the CLI.  The text straight from the plan (the TEXT form of
     the counter-mode kernel) and the --host-fastq path (columns in 16-byte read slots, closed up on the host by
     DeviceOut::to_host) write the same file, and that file is the mode's specification (oracle/philox.c) framed as
     fastq.rs:32-121 frames it.  Without the flag the reference's own streams are walked (the other CLI tests)."""
     from simmr_amd import _abi
+    rng_mode = _abi.RNG_PHILOX_FULL if mode == "philox-full" else _abi.RNG_PHILOX  # (philox-full: the plan from counters too)
     d, genomes = workdir
     long_mode = profile.endswith("long")
     n = "40" if long_mode else "4001"
     extra = ["--per-read-lengths", "--gamma", "3000,2500"] if long_mode else []
     outs = []
     for tag, flags in (("dev", []), ("host", ["--host-fastq"]), ("chunk", ["--device-chunk-reads", "33"])):
-        out = d / f"philox_{profile}_{tag}.fq"
+        out = d / f"{mode}_{profile}_{tag}.fq"
         subprocess.check_call([str(EXE), "--genome", str(d / "g1.fna"), "--output", str(out), "--num-reads", n, "--seed", "42",
-                               "--error-profile", profile, "--rng", "philox", "--read-header-format",
+                               "--error-profile", profile, "--rng", mode, "--read-header-format",
                                "@{:read_id:}/{:pair:} {:sequence_id:} {:start_position:}-{:end_position:} {:reverse_complement:}"] + extra + flags)
         outs.append(out.read_bytes())
     assert len(outs[0]) > 50_000 and outs[0] == outs[1] == outs[2]
     contigs, names = genomes[1]
     g = _oracle.HostGenome(contigs)
     if long_mode:
-        pod = cls(gamma_mean=3000.0, gamma_std=2500.0, length_mode=_abi.LEN_PER_READ, rng_mode=_abi.RNG_PHILOX).pod()
+        pod = cls(gamma_mean=3000.0, gamma_std=2500.0, length_mode=_abi.LEN_PER_READ, rng_mode=rng_mode).pod()
         o = _oracle.simulate_long(oracle, [g], [40], pod, 42, qual_offset=33)
     else:
-        o = _oracle.simulate_pe(oracle, g, cls(rng_mode=_abi.RNG_PHILOX).pod(), 4001, 42, qual_offset=33)
+        o = _oracle.simulate_pe(oracle, g, cls(rng_mode=rng_mode).pod(), 4001, 42, qual_offset=33)
     exp = fastq_of(o.trimmed(), o.n_reads, names, "x", not long_mode,
                    fmt="@{:read_id:}/{:pair:} {:sequence_id:} {:start_position:}-{:end_position:} {:reverse_complement:}")
     assert outs[0] == exp

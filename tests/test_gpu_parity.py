@@ -345,6 +345,98 @@ def test_philox_mode_tolerances(engine, genome_1m):
         assert chi2 < 13.8, (a, row)  # chi-square, 2 dof, p > 0.001
 
 
+# ---- SIMMR_RNG_PHILOX_FULL: the plan's draws from Philox counters too (include/simmr_hip.h) ----
+def test_philox_full_matches_its_specification(engine, oracle, genome_multi, genome_1m):
+    """Bit for bit the CPU restatement of the mode (oracle/rand08.c: the generator's second word source; simulate.c:
+    orc_pe_outer_ctr): contigs, seeds, lengths, windows, mate-2 seeds, qualities and bases — whole runs, shards of them,
+    several genomes in one plan, long reads with per-read lengths."""
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX_FULL).pod()
+    for gidx, g, reads, seed in ((1, genome_multi, 3001, 5), (0, genome_1m, 8000, 42)):
+        dev = engine.simulate_pe_reads_from_genome(gidx, prof, reads, seed, qual_offset=33)
+        ora = _oracle.simulate_pe(oracle, g, prof, reads, seed, qual_offset=33)
+        assert_same(dev.to_host(), ora.trimmed())
+    # a shard is a function of its pair indices alone: no position in a stream to hand over
+    whole = _oracle.simulate_pe(oracle, genome_multi, prof, 5000, 77, read_id_base=3).trimmed()
+    for first, count in ((0, 10), (1234, 700), (2499, 1), (2400, 5000)):
+        part = engine.simulate_pe_reads_from_genome(1, prof, 5000, 77, first=first, count=count, read_id_base=3).to_host()
+        n = min(count, 2500 - first)
+        a, b = int(whole["seq_off"][2 * first]), int(whole["seq_off"][2 * (first + n)])
+        assert np.array_equal(part["seq"], whole["seq"][a:b]) and np.array_equal(part["qual"], whole["qual"][a:b])
+        for col in ("start", "end", "contig", "read_id", "flags"):
+            assert np.array_equal(part[col], whole[col][2 * first:2 * (first + n)]), col
+    # edge shapes (the three window cases of simulate.rs:241-258, tiny reads, long inserts)
+    for L, I, q in ((20, 20, 30), (7, 3, 10), (150, 600, 45), (333, 100, 2)):
+        pe = MinimalShortErrorProfile(read_length=L, insert_size=I, mean_phred_score=q, rng_mode=_abi.RNG_PHILOX_FULL).pod()
+        dev = engine.simulate_pe_reads_from_genome(1, pe, 2501, 13, first=100, count=900, read_id_base=7)
+        ora = _oracle.simulate_pe(oracle, genome_multi, pe, 2501, 13, first=100, count=900, read_id_base=7, max_len=4096)
+        assert_same(dev.to_host(), ora.trimmed())
+    # several genomes in one plan (simmr_pe_plan_multi): the per-genome runs of the specification, concatenated
+    engine.stage_genome(4, genome_1m.contigs)
+    reads = [1200, 0, 801]
+    d = engine.simulate_pe_reads_multi([1, 4, 0], reads, prof, 9, qual_offset=33).to_host()
+    parts, base = [], 0
+    for g, n in zip((genome_multi, genome_1m, genome_1m), reads):
+        parts.append(_oracle.simulate_pe(oracle, g, prof, n, 9, read_id_base=base, qual_offset=33).trimmed())
+        base += n // 2
+    assert np.array_equal(d["seq"], np.concatenate([p["seq"] for p in parts]))
+    assert np.array_equal(d["qual"], np.concatenate([p["qual"] for p in parts]))
+    for col in ("start", "end", "contig", "read_id", "flags"):
+        assert np.array_equal(d[col], np.concatenate([p[col] for p in parts])), col
+    # long reads with per-read lengths, both Phred laws
+    for cls, kw in ((MinimalLongErrorProfile, dict(mean_phred_score=20)), (PerfectLongErrorProfile, {})):
+        lp = cls(gamma_mean=3000.0, gamma_std=2500.0, length_mode=_abi.LEN_PER_READ, rng_mode=_abi.RNG_PHILOX_FULL, **kw).pod()
+        dev = engine.simulate_long_reads([1, 0], [120, 75], lp, 3, first=11, count=150)
+        ora = _oracle.simulate_long(oracle, [genome_multi, genome_1m], [120, 75], lp, 3, first=11, count=150)
+        dd, oo = dev.to_host(), ora.trimmed()
+        oo["genome"] = np.array([1, 0], dtype=np.uint32)[oo["genome"]]
+        assert_same(dd, oo, cols=COLS + ("genome",))
+
+
+def test_philox_full_refusals(engine, genome_multi):
+    from simmr_amd import CustomShortErrorProfile, SimmrError
+    from tests import _model
+    for pod, plan in ((PerfectShortErrorProfile().pod(), "pe"), (CustomShortErrorProfile(_model.synthetic_short_model()).pod(), "pe"),
+                      (CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=5, n_kmers=100)).pod(), "long"),
+                      (MinimalLongErrorProfile().pod(), "long")):  # (the last: the reference's one constant length)
+        pod.rng_mode = _abi.RNG_PHILOX_FULL
+        with pytest.raises(SimmrError) as ei:
+            engine.pe_plan(1, pod, 100, 1) if plan == "pe" else engine.long_plan([1], [10], pod, 1)
+        assert ei.value.code == _abi.EINVAL and "SIMMR_RNG_PHILOX" in ei.value.msg, ei.value.msg
+
+
+def test_philox_full_tolerances(engine, genome_1m, genome_multi):
+    """The laws of the plan's draws (the per-base laws are SIMMR_RNG_PHILOX's, test_philox_mode_tolerances): read length
+    floor(N(150, 15)), insert from the same z (minimal_short.rs:33-67), the first mate's start uniform on
+    [0, size - required), contigs uniform whatever their size (simulate.rs:181), half of the mate-2 seeds drawn and half
+    substituted (Option<u64>, simulate.rs:266), and the run's substitution rate and Phred mean."""
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX_FULL).pod()
+    engine.counters_reset()
+    d = engine.simulate_pe_reads_from_genome(0, prof, 1_000_000, 2024).to_host()
+    c = engine.counters()
+    assert abs(c[_abi.CNT_SUBSTITUTIONS] / c[_abi.CNT_ACGT_BASES] / 0.013404 - 1) < 0.02
+    assert abs(c[_abi.CNT_QUAL_SUM] / c[_abi.CNT_BASES] - 29.5) < 0.05
+    lens = np.diff(d["seq_off"].astype(np.int64))[0::2]
+    n = lens.size
+    assert n == 500_000 and abs(lens.mean() - 149.5) < 0.1 and abs(lens.std() - 15.0) < 0.1  # floor() takes half a base
+    # start of mate 1 ~ U[0, size - required): mean, variance and a coarse histogram
+    size, required = 1_000_000, 450
+    st = d["start"][0::2].astype(np.float64) / (size - required)
+    assert abs(st.mean() - 0.5) < 4 * np.sqrt(1 / 12 / n) and abs(st.var() - 1 / 12) < 0.001
+    hist = np.bincount((st * 20).astype(int), minlength=20)
+    assert (np.abs(hist - n / 20) < 5 * np.sqrt(n / 20)).all()
+    # mate-2 seeds: Some / None with probability 1/2 each
+    subst = ((d["flags"][1::2] & _abi.FLAG_QSEED_SUBST) != 0).mean()
+    assert abs(subst - 0.5) < 5 * np.sqrt(0.25 / n)
+    # contigs of a genome are drawn uniformly, not by size
+    dm = engine.simulate_pe_reads_from_genome(1, prof, 200_000, 5).to_host()
+    cnt = np.bincount(dm["contig"][0::2], minlength=len(genome_multi.contigs))
+    assert (np.abs(cnt - 100_000 / cnt.size) < 5 * np.sqrt(100_000 / cnt.size)).all()
+    # and the two counter modes are different runs of the same law
+    d1 = engine.simulate_pe_reads_from_genome(0, MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX).pod(), 1_000_000, 2024).to_host()
+    l1 = np.diff(d1["seq_off"].astype(np.int64))[0::2]
+    assert not np.array_equal(d1["start"], d["start"]) and abs(l1.mean() - lens.mean()) < 0.15
+
+
 # custom-short (empirical PDFs): bincode model -> alias tables on both sides
 @pytest.mark.parametrize("n_positions,seed", [(120, 42), (60, 7)])
 def test_custom_short_bit_exact(engine, oracle, genome_multi, n_positions, seed):

@@ -185,4 +185,6 @@ def test_header_states_the_shipped_philox_specification():
     assert "one output word per base" not in text and "base index / 4" not in text
     # the same constants in the specification's restatement and in the kernel
     assert "0x73696D6D" in (ROOT / "oracle" / "philox.c").read_text().upper().replace("0X", "0x")
-    assert "0x73696D6Du" in (ROOT / "simmr_amd" / "csrc" / "kernels.hip").read_text()
+    assert "0x73696D6Du" in (ROOT / "simmr_amd" / "csrc" / "rng_device.hpp").read_text()  # (philox4x32_10, used by kernels.hip)
+    for needle in ("SIMMR_RNG_PHILOX_FULL", "(w >> 2, 3, 0x73696D6D, 0x72000003)", "4 | (p >> 32) << 8"):  # the full counter mode
+        assert needle in text, needle

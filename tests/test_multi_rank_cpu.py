@@ -200,6 +200,24 @@ def test_two_ranks_equal_one_rank():
     assert got[0][4] == 0 and got[1][4] == 1
 
 
+def test_full_counter_mode_needs_no_seek():
+    """SIMMR_RNG_PHILOX_FULL: a pair's outer draws are a function of its index, so a rank that starts in the middle of a
+    genome plans its shard without the summaries / all-gather of the reference's stream (simulate.py skips the seek: no
+    process group exists here, a collective would raise) — and the shards of 1, 2, 3 and 5 ranks are the whole run."""
+    from simmr_amd import _abi
+    be = OracleBackend()
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX_FULL)
+    whole = simulate_pe_reads(be, PE_READS, _refs(), prof, UniformAbundanceProfile(), 42, 0, 1)
+    for world in (2, 3, 5):
+        per_rank = [simulate_pe_reads(be, PE_READS, _refs(), prof, UniformAbundanceProfile(), 42, rk, world) for rk in range(world)]
+        for g, (*_, r) in enumerate(whole):
+            w = r.trimmed()
+            parts = [per_rank[rk][g][4].trimmed() for rk in range(world) if per_rank[rk][g][4] is not None]
+            for col in ("start", "end", "contig", "read_id", "flags", "seq", "qual"):
+                assert np.array_equal(np.concatenate([p[col] for p in parts]), w[col]), (world, g, col)
+    assert getattr(be, "seeks", 0) == 0
+
+
 # ---- eight ranks, a stream a billion slots long ---------------------------------------------------------------
 class PeriodicStream:
     """An outer stream whose accept bits repeat with period P (a stand-in for StdRng: nothing can replay 1e9 real

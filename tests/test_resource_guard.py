@@ -46,10 +46,13 @@ def test_counter_mode_item_kernel_every_instantiation(kernels):
 
 
 def test_other_bench_kernels(kernels):
-    for name, occ, scratch in (("k_emit_perfect_pe<", 7, 0), ("k_plan_pe$", 6, 0), ("k_outer_classify", 8, 0),
+    for name, occ, scratch in (("k_emit_perfect_pe<", 7, 0), ("k_plan_pe<", 6, 0), ("k_outer_ctr", 8, 0), ("k_outer_classify", 8, 0),
                                ("k_outer_scan", 8, 0), ("k_outer_emit", 8, 0), ("k_fastq_size_plan", 8, 0),
                                ("k_emit_lanes<", 4, 32),               # bit-exact mode: 32 bytes per lane, documented
-                               ("k_custom_long_splice<", 4, 0),        # the k-mer splice: four waves per SIMD around its LDS tables
+                               (r"k_custom_long_splice<(true|false), (true|false), false>", 4, 0),  # the k-mer splice on the reference's streams: four waves per SIMD around its LDS rows
+                               # its counter mode: six waves per SIMD (two workgroups of 768 lanes around the 64 KB table); the
+                               # cap costs the fixed-stride forms 16 / 36 bytes of spills around the group loop, none in the step loop
+                               (r"k_custom_long_splice<(true|false), (true|false), true>", 6, 36),
                                ("k_plan_long_per_read", 5, 0), ("k_fastq_write", 6, 0)):
         ks = _named(kernels, name)
         assert ks, name
