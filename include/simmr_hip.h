@@ -162,7 +162,7 @@ typedef struct simmr_plan_info {
   uint64_t n_reads;      /* 2*n_units for PE, n_units for long                */
   uint64_t total_bases;  /* bytes needed in seq[] and in qual[]               */
   uint64_t seed_used;    /* the seed (given, or drawn from OS entropy)        */
-  uint64_t outer_slots;  /* u64 draws consumed from the outer StdRng stream   */
+  uint64_t outer_slots;  /* u64 draws consumed from the outer StdRng stream (0 with SIMMR_RNG_PHILOX_FULL: there is none) */
   uint32_t const_read_length; /* long/REFERENCE: the run-wide length, else 0  */
   uint32_t slot_bytes;   /* 0: compact streams; 16: SIMMR_SLOT16 (simmr_engine_set_read_slots) */
 } simmr_plan_info;
@@ -306,7 +306,8 @@ int simmr_pe_plan(simmr_engine* e, uint32_t genome_idx, const simmr_error_profil
  * Ranks summarize disjoint ranges, exchange the 4 numbers (the path's only other
  * collective, 32 bytes per rank) and compose them; simmr_pe_plan_at then starts
  * at a known position: pair `start_unit` begins at slot `start_slot`
- * (start_unit <= shard.first; start_slot = start_unit = 0 is simmr_pe_plan). */
+ * (start_unit <= shard.first; start_slot = start_unit = 0 is simmr_pe_plan).  With SIMMR_RNG_PHILOX_FULL there is no stream:
+ * the two positions are ignored and the call is simmr_pe_plan. */
 typedef struct simmr_outer_summary {
   uint64_t units[2];      /* pairs completed in the range, by state at slot_first */
   uint32_t end_state[2];  /* state after the range */

@@ -42,7 +42,7 @@ def big(engine):
     return engine
 
 
-@pytest.mark.parametrize("rng_mode", [_abi.RNG_PHILOX, _abi.RNG_REFERENCE])
+@pytest.mark.parametrize("rng_mode", [_abi.RNG_PHILOX_FULL, _abi.RNG_PHILOX, _abi.RNG_REFERENCE], ids=["philox-full", "philox", "reference"])
 def test_c2_full_size_properties(big, rng_mode):
     import torch
     eng = big

@@ -26,7 +26,7 @@ def genome_multi(engine):
     return _oracle.HostGenome(contigs)
 
 
-@pytest.mark.parametrize("rng_mode", [_abi.RNG_REFERENCE, _abi.RNG_PHILOX])
+@pytest.mark.parametrize("rng_mode", [_abi.RNG_REFERENCE, _abi.RNG_PHILOX, _abi.RNG_PHILOX_FULL], ids=["reference", "philox", "philox-full"])
 def test_c4_thousand_genomes_rank_shards(engine, oracle, rng_mode):
     """1000 genomes (one sequence of 30 kbp each, SplitMix64(1000 + g)), uniform abundance, 2 M reads: rank r of 8
     takes pairs [r N / 8, (r + 1) N / 8) of the global pair index through ONE plan over all genomes."""
