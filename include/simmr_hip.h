@@ -101,7 +101,7 @@ enum simmr_profile_kind {
  *     (w >> 2, 3, 0x73696D6D, 0x72000003), consumed in the reference's order by the reference's algorithms (gen_range with
  *     its rejection zone, the ziggurat, Gamma, Option<u64>);
  *     the genome's outer stream (simulate.rs:172-186, one generator walked pair by pair) becomes one block per pair: pair p
- *     of the genome's run takes the block with key = the run's seed and counter (p & 0xffffffff, 4 | (p >> 32) << 8,
+ *     of the genome's run (p < 2^56) takes the block with key = the run's seed and counter (p & 0xffffffff, 4 | (p >> 32) << 8,
  *     0x73696D6D, 0x72000003) = (w0, w1, w2, w3): contig = ((w0 | w1 << 32) * num_seqs) >> 64, pe_seed = w2 | w3 << 32
  *     (as in the reference, every genome of a run sees the same seed);
  *     the per-base draws are PHILOX's, keyed by the seeds this plan makes.
