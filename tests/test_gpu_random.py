@@ -36,7 +36,7 @@ def test_random_configurations_match_the_oracle(engine, oracle, sweep_seed):
             if kind == 0:
                 prof = PerfectShortErrorProfile(L, I).pod()
             else:
-                prof = MinimalShortErrorProfile(read_length=L, insert_size=I, mean_phred_score=mq, rng_mode=int(rng.integers(0, 2))).pod()
+                prof = MinimalShortErrorProfile(read_length=L, insert_size=I, mean_phred_score=mq, rng_mode=int(rng.integers(0, 3))).pod()  # reference / philox / philox-full
             reads = int(rng.integers(0, 1500)); first = int(rng.integers(0, reads // 2 + 2)); count = int(rng.integers(0, 800))
             if 2 * L + I >= min(lens):
                 continue
@@ -45,7 +45,7 @@ def test_random_configurations_match_the_oracle(engine, oracle, sweep_seed):
         else:
             gm = float(rng.integers(300, 4000)); gs = gm * float(rng.uniform(0.3, 0.9))
             cls = MinimalLongErrorProfile
-            rm = int(rng.integers(0, 2))
+            rm = int(rng.integers(0, 3))  # (philox-full with the reference's one constant length: refused on both sides)
             prof = cls(gamma_mean=gm, gamma_std=gs, length_mode=int(rng.integers(0, 2)), rng_mode=rm, uniform_start=bool(rng.integers(0, 2)), mean_phred_score=int(rng.integers(0, 60))).pod()
             if kind == 3:
                 prof.kind = _abi.PERFECT_LONG
@@ -92,7 +92,8 @@ def test_random_multi_genome_plans(engine, oracle):
         reads = [int(rng.integers(0, 900)) for _ in order]
         L, I = int(rng.integers(5, 200)), int(rng.integers(0, 300))
         prof = [PerfectShortErrorProfile(L, I), MinimalShortErrorProfile(read_length=L, insert_size=I),
-                MinimalShortErrorProfile(read_length=L, insert_size=I, rng_mode=_abi.RNG_PHILOX)][int(rng.integers(0, 3))].pod()
+                MinimalShortErrorProfile(read_length=L, insert_size=I, rng_mode=_abi.RNG_PHILOX),
+                MinimalShortErrorProfile(read_length=L, insert_size=I, rng_mode=_abi.RNG_PHILOX_FULL)][int(rng.integers(0, 4))].pod()
         seed = int(rng.integers(0, 1 << 60))
         parts, base = [], 0
         for gi, n in zip(order, reads):
