@@ -70,6 +70,11 @@ def main():
                     help="with --rng philox, where the PLAN's draws (contig, seeds, lengths, positions) come from: philox = Philox "
                          "counters too (SIMMR_RNG_PHILOX_FULL: minimal-short and minimal-long; the default), reference = the "
                          "reference's ChaCha12 streams (SIMMR_RNG_PHILOX: same positions and lengths as the reference run)")
+    ap.add_argument("--plan-overlap", action="store_true",
+                    help="the engine plans on a stream of its own into a second set of plan buffers (simmr_engine_set_plan_overlap): "
+                         "the plan of step k + 1 then runs beside the emit of step k.  Off by default — the emit kernel's time, "
+                         "which `roofline` is about, is then that of the kernel alone; the default line times ten steps with it "
+                         "as `with_plan_overlap`")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the untimed side measurements (the other rng mode, the FASTQ text)")
     ap.add_argument("--through-fastq", action="store_true",
                     help="one step = plan + FASTQ sizing + emit straight into FASTQ text resident in HBM (simmr_fastq_plan_direct / "
@@ -153,6 +158,7 @@ def main():
     if slot16 and (prof.rng_mode == _abi.RNG_REFERENCE or custom is not None):
         raise SystemExit("--layout slot16 is the counter mode's layout (minimal-short / minimal-long with --rng philox)")
     eng.set_read_slots(16 if slot16 else 0)
+    eng.set_plan_overlap(args.plan_overlap)
 
     pairs_per_gpu = args.reads // 2
     total_reads = 2 * pairs_per_gpu * world  # the whole job
@@ -221,8 +227,7 @@ def main():
                 c = counters_dev.cpu()
                 dist.all_reduce(c)
                 counters_dev.copy_(c)
-        if record:
-            emit_ms.append(eng.last_emit_kernel_ms())
+        if record:  # (the emit kernel's time is read once after the timed steps: asking after every emit would wait for it)
             plan_ms.append(eng.last_plan_ms())
             fq["plan_ms"].append(eng.last_fastq_plan_ms())
 
@@ -243,8 +248,8 @@ def main():
                 c = counters_dev.cpu()
                 dist.all_reduce(c)
                 counters_dev.copy_(c)
-        if record:
-            emit_ms.append(eng.last_emit_kernel_ms())
+        if record:  # (the emit kernel's time is read once after the timed steps: asking after every emit would wait for it
+            #  and keep the plan of the next step from running beside it)
             plan_ms.append(eng.last_plan_ms())
 
     def fence():
@@ -264,6 +269,8 @@ def main():
         the_step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    # HIP events around every emit launch of the timed steps, on the engine's stream (the last 64 are kept)
+    emit_ms.append(eng.emit_kernel_ms_mean(min(args.steps, 64)))
     el = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -340,6 +347,29 @@ def main():
                       "note": "three steps after one warm-up step, same shard, outside the timed region"}
         prof.rng_mode = keep_mode
         step(False)  # (the columns of the timed mode again: the read lengths below come from them)
+        counters_dev.copy_(keep_c)
+
+    # untimed side measurement (N = 1): the same steps with the plan of step k + 1 beside the emit of step k
+    with_overlap = None
+    if world == 1 and not args.no_other_mode and not args.plan_overlap and not args.through_fastq:
+        keep_c = counters_dev.clone()
+        eng.set_plan_overlap(True)
+        for _ in range(2):
+            step(False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            step(False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 10
+        with_overlap = {"what": "simmr_engine_set_plan_overlap(e, 1): plan calls on the engine's own stream into a second set of plan "
+                                "buffers — the plan of step k + 1 runs while the emit of step k is on the device",
+                        "value": info.n_reads / dt, "unit": "reads/s", "ms_per_step": dt * 1e3,
+                        "kernel_ms": eng.emit_kernel_ms_mean(10), "steps": 10,
+                        "note": "ten steps after two warm-up steps, same shard, outside the timed region; the emit kernel shares the "
+                                "device with the plan kernels here, so its time is not the kernel's own"}
+        eng.set_plan_overlap(False)
+        step(False)
         counters_dev.copy_(keep_c)
 
     # untimed side measurement: the same step through FASTQ text (N = 1, the default command only)
@@ -424,6 +454,9 @@ def main():
                 "layout": ("slot16: every read in a 16-byte-aligned slot of seq / qual (SIMMR_SLOT16, include/simmr_hip.h), "
                            f"{2 * int(info.total_bases)} stream bytes per step" if slot16 else
                            f"compact: seq / qual byte streams without gaps, {2 * int(info.total_bases)} stream bytes per step"),
+                "plan_overlap": ("off" if not args.plan_overlap else
+                                 "on: the plan of step k + 1 runs on the engine's plan stream beside the emit of step k "
+                                 "(simmr_engine_set_plan_overlap; every step still plans and emits its own shard)"),
                 "reads_per_gpu": 2 * pairs_per_gpu,
                 "sharding": ("global read-index range per GPU" if long_mode else "pair-index range per GPU"),
                 # what carried the collectives of this run, and how many ranks it saw
@@ -483,6 +516,8 @@ def main():
             result["other_layout"] = other_layout
         if other_plan is not None:
             result["other_plan"] = other_plan
+        if with_overlap is not None:
+            result["with_plan_overlap"] = with_overlap
         if through is not None:
             result["through_fastq"] = through
         if args.through_fastq:

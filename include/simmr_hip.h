@@ -249,6 +249,15 @@ int simmr_engine_set_stream(simmr_engine* e, void* hip_stream);
  * got).  Anything else: SIMMR_EINVAL.  The plan in force keeps the layout it was made with. */
 int simmr_engine_set_read_slots(simmr_engine* e, uint32_t slot_bytes);
 
+/* The plan of the next shard beside the emit of this one.  A run that is generated shard by shard (the reference keeps a
+ * whole run in RAM, main.rs:180-206; here `for range: plan, emit, drain`) calls plan k + 1 while the emit of shard k is
+ * still on the device; with on != 0 the plan calls run on a stream of the engine's own and write a second set of the
+ * buffers an emit reads, so the two overlap — the plan kernels are bound by latency, the emit kernels by instruction
+ * issue — instead of queueing behind one another.  The caller's stream (simmr_engine_set_stream) is made to wait for the
+ * plan before the call returns, so everything the caller enqueues afterwards sees it: no call sequence changes.  Costs a
+ * second set of plan columns (25 bytes per pair / long read).  Off by default; switching synchronises the device. */
+int simmr_engine_set_plan_overlap(simmr_engine* e, int on);
+
 /* ---- reference staging -------------------------------------------------- */
 /* Replaces the in-RAM `Genome { sequence: Vec<Seq> }` (genome.rs:17-41): the
  * normalised ASCII contigs are packed once into HBM as a flat 2-bit array
@@ -381,6 +390,10 @@ int simmr_counters_reset(simmr_engine* e);
 /* HIP-event time (ms) of the dominant emit kernel of the last *_emit call,
  * measured on the engine's stream. Synchronises the stream. */
 int simmr_last_emit_kernel_ms(simmr_engine* e, float* ms);
+/* The mean of the last `last_n` emits' times (at most 64 are kept), after ONE synchronisation of the engine's stream —
+ * for a loop that must not wait for every emit (simmr_engine_set_plan_overlap: asking after each emit would serialise
+ * the plan of the next shard behind it). */
+int simmr_emit_kernel_ms_mean(simmr_engine* e, uint32_t last_n, float* ms);
 /* HIP-event time (ms) of the last *_plan call's device work. */
 int simmr_last_plan_ms(simmr_engine* e, float* ms);
 

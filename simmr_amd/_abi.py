@@ -118,6 +118,7 @@ SYMBOLS = {
     "simmr_last_error": (C.c_char_p, [C.c_void_p]),
     "simmr_engine_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "simmr_engine_set_read_slots": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "simmr_engine_set_plan_overlap": (C.c_int, [C.c_void_p, C.c_int]),
     "simmr_stage_genome": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_void_p),
                                      _P(C.c_uint64), _P(C.c_uint64)]),
     "simmr_stage_fasta": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_void_p), _P(C.c_uint64), C.c_int,
@@ -144,6 +145,7 @@ SYMBOLS = {
     "simmr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "simmr_allreduce_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "simmr_last_emit_kernel_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
+    "simmr_emit_kernel_ms_mean": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
     "simmr_last_plan_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "simmr_entropy_substitute": (C.c_uint64, [C.c_uint64, C.c_uint32]),
     "simmr_fastq_plan": (C.c_int, [C.c_void_p, C.c_char_p, _P(FastqNames), _P(ReadsOut), C.c_uint64, C.c_int,

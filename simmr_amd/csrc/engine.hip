@@ -75,6 +75,11 @@ struct simmr_engine {
   DevBuf d_genomes;  // GenomeDev[genomes.size()]
   DevBuf d_tables, d_counters, d_err, d_scalars;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  // The event pairs of the last emits (ev_c / ev_d = the pair of the emit in progress): simmr_emit_kernel_ms_mean averages them
+  // with ONE synchronisation, where asking after every emit (simmr_last_emit_kernel_ms) would wait for each.
+  static constexpr int EMIT_RING = 64;
+  hipEvent_t ring_c[EMIT_RING] = {}, ring_d[EMIT_RING] = {};
+  uint64_t n_emits = 0;
   float last_emit_ms = 0.f, last_plan_ms = 0.f, last_fastq_plan_ms = 0.f;
 
   // current plan
@@ -96,6 +101,17 @@ struct simmr_engine {
   DevBuf u_contig, u_genome, u_seed, u_len, u_a, u_b, u_qs2, u_ms2, u_flags, u_off;
   DevBuf scan_tmp, u_order, len_hist;
   bool plan_sorted = false;
+  // simmr_engine_set_plan_overlap: the plan calls run on a stream of their own and write a SECOND set of the buffers an
+  // emit reads (plan columns, offsets, order, error word, counter-mode tables), so that the plan of the next shard runs
+  // while the emit of this one is still on the device — one is bound by latency, the other by VALU issue.  plan_sets_swap
+  // exchanges the two sets; mark[s] = the work on the caller's stream that read set s when set s was last given up.
+  bool overlap = false;
+  hipStream_t plan_stream = nullptr;
+  hipEvent_t ev_plan_done = nullptr, ev_mark[2] = {nullptr, nullptr};
+  bool mark_valid[2] = {false, false};
+  int cur_set = 0;
+  DevBuf s_w_bytes, s_u_off64, s_m_genomes, s_u_contig, s_u_genome, s_u_seed, s_u_len, s_u_a, s_u_b, s_u_qs2, s_u_ms2, s_u_flags,
+      s_u_off, s_u_order, s_d_err, s_d_runs, s_d_usable, s_ph_table;
   int emit_variant = 0;  // 0 = lane-per-read kernel for short reads; 1 = wave-per-unit kernel (SIMMR_VARIANTS builds only)
   // measurement knobs, read ONCE when the engine is made (a stray variable cannot change a running engine's launches)
   int philox_form = 1;          // SIMMR_PHILOX_FORM: 1 = the item kernel (default), 2 = the tile kernel where it applies (emit_tile.hip; measured slower: profiles/r3/tile_form_*)
@@ -295,6 +311,43 @@ uint64_t model_hash(const void* p, uint64_t n) {
   return h;
 }
 
+// ---- the plan of the next shard beside the emit of this one (simmr_engine_set_plan_overlap) ----
+static void plan_sets_swap(simmr_engine* e) {
+  std::swap(e->w_bytes, e->s_w_bytes); std::swap(e->u_off64, e->s_u_off64); std::swap(e->m_genomes, e->s_m_genomes);
+  std::swap(e->u_contig, e->s_u_contig); std::swap(e->u_genome, e->s_u_genome); std::swap(e->u_seed, e->s_u_seed);
+  std::swap(e->u_len, e->s_u_len); std::swap(e->u_a, e->s_u_a); std::swap(e->u_b, e->s_u_b); std::swap(e->u_qs2, e->s_u_qs2);
+  std::swap(e->u_ms2, e->s_u_ms2); std::swap(e->u_flags, e->s_u_flags); std::swap(e->u_off, e->s_u_off);
+  std::swap(e->u_order, e->s_u_order); std::swap(e->d_err, e->s_d_err); std::swap(e->d_runs, e->s_d_runs);
+  std::swap(e->d_usable, e->s_d_usable); std::swap(e->ph_table, e->s_ph_table);
+  e->cur_set ^= 1;
+}
+// One per plan call.  With the overlap on: marks what the caller's stream has been given so far (all of it may read the
+// set in force), takes the other set, lets the plan stream wait for whatever read THAT set when it was given up, and
+// makes the plan stream the engine's stream for the duration of the call; on the way out — whichever way — the caller's
+// stream is put back and made to wait for the plan.
+struct PlanScope {
+  simmr_engine* e;
+  hipStream_t main = nullptr;
+  bool on = false;
+  explicit PlanScope(simmr_engine* eng) : e(eng) {
+    if (!e->overlap || !e->plan_stream) return;
+    main = e->stream;
+    if (hipEventRecord(e->ev_mark[e->cur_set], main) != hipSuccess) return;
+    e->mark_valid[e->cur_set] = true;
+    plan_sets_swap(e);
+    if (e->mark_valid[e->cur_set]) (void)hipStreamWaitEvent(e->plan_stream, e->ev_mark[e->cur_set], 0);
+    if (!e->d_err.p && (!e->d_err.ensure(64) || hipMemset(e->d_err.p, 0, 64) != hipSuccess)) { /* the plan's own checks report it */ }
+    e->stream = e->plan_stream;
+    on = true;
+  }
+  ~PlanScope() {
+    if (!on) return;
+    (void)hipEventRecord(e->ev_plan_done, e->plan_stream);
+    e->stream = main;
+    (void)hipStreamWaitEvent(main, e->ev_plan_done, 0);
+  }
+};
+
 int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want_long, ProfileDev* out) {
   if (!p->custom_model || p->custom_model_bytes == 0) return e->fail(SIMMR_EINVAL, "custom profile without a model");
   // A job plans many shards with one model: parsing it, building the alias and k-mer tables and uploading them
@@ -313,6 +366,8 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
     return SIMMR_OK;
   }
   e->custom_cached = false;
+  // (the tables below are rewritten: with the plan overlap on, an emit of the previous model may still be reading them)
+  if (e->overlap) (void)hipDeviceSynchronize();
   ModelHost m;
   std::string err;
   if (!parse_model((const uint8_t*)p->custom_model, p->custom_model_bytes, &m, &err)) return e->fail(SIMMR_EINVAL, "%s", err.c_str());
@@ -768,6 +823,22 @@ bool plan_is_coarse(simmr_engine* e, const ProfileDev& prof) {
   return prof.rng_mode != SIMMR_RNG_REFERENCE && prof.kind != SIMMR_K_CUSTOM && prof.kind != SIMMR_K_PERFECT_SHORT && e->philox_form != 2;
 }
 
+// the event pair of the emit about to be launched (a ring of EMIT_RING pairs, made on first use)
+hipError_t next_emit_events(simmr_engine* e) {
+  const int i = (int)(e->n_emits % simmr_engine::EMIT_RING);
+  if (!e->ring_c[i]) {
+    if (e->n_emits == 0) { e->ring_c[0] = e->ev_c; e->ring_d[0] = e->ev_d; }
+    else {
+      hipError_t s = hipEventCreate(&e->ring_c[i]);
+      if (s != hipSuccess) return s;
+      if ((s = hipEventCreate(&e->ring_d[i])) != hipSuccess) return s;
+    }
+  }
+  e->ev_c = e->ring_c[i]; e->ev_d = e->ring_d[i];
+  e->n_emits++;
+  return hipSuccess;
+}
+
 int check_out(simmr_engine* e, const simmr_reads_out* out, uint64_t n_reads, uint64_t total) {
   if (!out) return e->fail(SIMMR_EINVAL, "out is NULL");
   if (!out->seq_off) return e->fail(SIMMR_EINVAL, "out->seq_off is NULL");
@@ -1008,6 +1079,14 @@ void simmr_engine_destroy(simmr_engine* e) {
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
   comm_release(e);
+  (void)hipDeviceSynchronize();
+  if (e->plan_stream) (void)hipStreamDestroy(e->plan_stream);
+  if (e->ev_plan_done) (void)hipEventDestroy(e->ev_plan_done);
+  for (int i = 0; i < 2; i++) if (e->ev_mark[i]) (void)hipEventDestroy(e->ev_mark[i]);
+  for (DevBuf* b : {&e->s_w_bytes, &e->s_u_off64, &e->s_m_genomes, &e->s_u_contig, &e->s_u_genome, &e->s_u_seed, &e->s_u_len, &e->s_u_a,
+                    &e->s_u_b, &e->s_u_qs2, &e->s_u_ms2, &e->s_u_flags, &e->s_u_off, &e->s_u_order, &e->s_d_err, &e->s_d_runs,
+                    &e->s_d_usable, &e->s_ph_table})
+    b->release();
   for (auto& g : e->genomes) { g.packed.release(); g.mask.release(); g.d_contigs.release(); }
   DevBuf* bufs[] = {&e->d_genomes, &e->d_tables, &e->d_counters, &e->d_err, &e->d_scalars, &e->u_contig,
                     &e->u_genome, &e->u_seed, &e->u_len, &e->u_a, &e->u_b, &e->u_qs2,
@@ -1018,8 +1097,11 @@ void simmr_engine_destroy(simmr_engine* e) {
   for (DevBuf* b : bufs) b->release();
   if (e->ev_a) (void)hipEventDestroy(e->ev_a);
   if (e->ev_b) (void)hipEventDestroy(e->ev_b);
-  if (e->ev_c) (void)hipEventDestroy(e->ev_c);
-  if (e->ev_d) (void)hipEventDestroy(e->ev_d);
+  if (e->n_emits == 0) { e->ring_c[0] = e->ev_c; e->ring_d[0] = e->ev_d; }
+  for (int i = 0; i < simmr_engine::EMIT_RING; i++) {
+    if (e->ring_c[i]) (void)hipEventDestroy(e->ring_c[i]);
+    if (e->ring_d[i]) (void)hipEventDestroy(e->ring_d[i]);
+  }
   delete e;
 }
 
@@ -1033,6 +1115,20 @@ int simmr_engine_set_read_slots(simmr_engine* e, uint32_t slot_bytes) {
 int simmr_engine_set_stream(simmr_engine* e, void* hip_stream) {
   if (!e) return SIMMR_EINVAL;
   e->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return SIMMR_OK;
+}
+
+int simmr_engine_set_plan_overlap(simmr_engine* e, int on) {
+  if (!e) return SIMMR_EINVAL;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipDeviceSynchronize());  // (nothing of either set is in flight across the switch)
+  if (on && !e->plan_stream) {
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->plan_stream, hipStreamNonBlocking));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_plan_done, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_mark[i], hipEventDisableTiming));
+  }
+  e->overlap = on != 0;
+  e->mark_valid[0] = e->mark_valid[1] = false;
   return SIMMR_OK;
 }
 
@@ -1268,6 +1364,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   e->plan_kind = PLAN_NONE;
   e->fq_direct = false;  // (a direct FASTQ plan belongs to the plan it was made for)
   HIP_TRY(e, hipSetDevice(e->device));
+  PlanScope plan_scope(e);  // (simmr_engine_set_plan_overlap: the other buffer set, the plan stream)
   int rc = check_genome(e, genome_idx);
   if (rc) return rc;
   ProfileDev prof;
@@ -1375,6 +1472,7 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
   e->fq_direct = false;  // (a direct FASTQ plan belongs to the plan it was made for)
   if (n_genomes == 0 || !genome_idx || !genome_reads) return e->fail(SIMMR_EINVAL, "simmr_pe_plan_multi: no genomes");
   HIP_TRY(e, hipSetDevice(e->device));
+  PlanScope plan_scope(e);  // (simmr_engine_set_plan_overlap: the other buffer set, the plan stream)
   int rc;
   ProfileDev prof;
   if ((rc = make_profile(e, profile, false, &prof))) return rc;
@@ -1512,6 +1610,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                        paired ? 1u : 0u, n_units, e->plan_first, read_id_base, e->plan_genome, pl,
                        e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome, out_cols(out));
   unsigned long long* counters = e->d_counters.as<unsigned long long>();
+  HIP_TRY(e, next_emit_events(e));
   HIP_TRY(e, hipEventRecord(e->ev_c, e->stream));
   if (n_units > 0) {
     if (e->prof.kind == SIMMR_K_PERFECT_SHORT) {
@@ -1712,6 +1811,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   e->plan_kind = PLAN_NONE;
   e->fq_direct = false;  // (a direct FASTQ plan belongs to the plan it was made for)
   HIP_TRY(e, hipSetDevice(e->device));
+  PlanScope plan_scope(e);  // (simmr_engine_set_plan_overlap: the other buffer set, the plan stream)
   if (!genome_idx || !genome_reads || n_genomes == 0) return e->fail(SIMMR_EINVAL, "no genomes");
   int rc;
   ProfileDev prof;
@@ -2067,6 +2167,7 @@ int simmr_fastq_emit(simmr_engine* e, const simmr_reads_out* reads, uint8_t* dst
   const uint32_t hdr_lds = 4 * FQ_BATCH * e->fq_hpitch;  // up to 68 KB with 255-byte headers: above the default limit
   if (hdr_lds > 48 * 1024)
     HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fastq_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hdr_lds));
+  HIP_TRY(e, next_emit_events(e));
   HIP_TRY(e, hipEventRecord(e->ev_c, e->stream));
   hipLaunchKernelGGL(k_fastq_write, dim3(grid), dim3(256), hdr_lds, e->stream, e->fq_tpl_dev.as<FqTemplate>(), tb, rd,
                      e->fq_reads, e->fq_paired ? 1u : 0u, e->fq_lit_bytes, e->fq_hpitch, e->fq_off.as<uint64_t>(), dst);
@@ -2196,6 +2297,7 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
   PlanArrays pl = plan_arrays(e, seeds2);
   const uint32_t* u_genome = (paired && !e->plan_multi) ? nullptr : e->u_genome.as<uint32_t>();
   unsigned long long* counters = e->d_counters.as<unsigned long long>();
+  HIP_TRY(e, next_emit_events(e));
   HIP_TRY(e, hipEventRecord(e->ev_c, e->stream));
   {
     const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
@@ -2258,6 +2360,24 @@ int simmr_last_emit_kernel_ms(simmr_engine* e, float* ms) {
   if (rc) return rc;
   HIP_TRY(e, hipEventElapsedTime(&e->last_emit_ms, e->ev_c, e->ev_d));
   *ms = e->last_emit_ms;
+  return SIMMR_OK;
+}
+
+int simmr_emit_kernel_ms_mean(simmr_engine* e, uint32_t last_n, float* ms) {
+  if (!e || !ms || last_n == 0) return SIMMR_EINVAL;
+  int rc = sync_check(e, "emit");
+  if (rc) return rc;
+  const uint64_t have = std::min<uint64_t>(e->n_emits, (uint64_t)simmr_engine::EMIT_RING);
+  const uint64_t n = std::min<uint64_t>(last_n, have);
+  if (n == 0) return e->fail(SIMMR_ESTATE, "no emit yet");
+  double sum = 0.0;
+  for (uint64_t k = 0; k < n; k++) {
+    const int i = (int)((e->n_emits - 1 - k) % simmr_engine::EMIT_RING);
+    float t = 0.f;
+    HIP_TRY(e, hipEventElapsedTime(&t, e->ring_c[i], e->ring_d[i]));
+    sum += t;
+  }
+  *ms = (float)(sum / (double)n);
   return SIMMR_OK;
 }
 

@@ -152,6 +152,11 @@ class Engine:
         """Layout of the reads that plans made from now on emit: 0 compact, 16 = SIMMR_SLOT16 (simmr_engine_set_read_slots)."""
         self._check(self.lib.simmr_engine_set_read_slots(self._h, int(slot_bytes)))
 
+    def set_plan_overlap(self, on: bool):
+        """The plan of the next shard beside the emit of this one (simmr_engine_set_plan_overlap): plan calls on a stream
+        of the engine's own, into a second set of the plan buffers."""
+        self._check(self.lib.simmr_engine_set_plan_overlap(self._h, 1 if on else 0))
+
     # -- staging ------------------------------------------------------------
     def stage_genome(self, genome_idx: int, contigs: Sequence, sizes: Optional[Sequence[int]] = None):
         """contigs: normalised ASCII sequences (bytes or uint8 arrays), Seq.seq
@@ -365,6 +370,12 @@ class Engine:
     def last_emit_kernel_ms(self) -> float:
         ms = C.c_float()
         self._check(self.lib.simmr_last_emit_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def emit_kernel_ms_mean(self, last_n: int) -> float:
+        """Mean HIP-event time of the last `last_n` emits (one synchronisation; simmr_emit_kernel_ms_mean)."""
+        ms = C.c_float()
+        self._check(self.lib.simmr_emit_kernel_ms_mean(self._h, int(last_n), C.byref(ms)))
         return ms.value
 
     def last_plan_ms(self) -> float:

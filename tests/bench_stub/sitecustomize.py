@@ -99,6 +99,12 @@ def _install():
         def last_plan_ms(self):
             return self.ms[0]
 
+        def emit_kernel_ms_mean(self, last_n):
+            return self.ms[1]
+
+        def set_plan_overlap(self, on):
+            pass
+
         def close(self):
             pass
 

@@ -389,3 +389,73 @@ def test_results_do_not_depend_on_the_grid(engine, monkeypatch, knobs):
         assert np.array_equal(got[0][1], got[1][1])
     finally:
         other.close()
+
+
+def test_plan_overlap_gives_the_same_reads(oracle):
+    """simmr_engine_set_plan_overlap: plan calls on the engine's own stream into a second set of plan buffers, so that plan
+    k + 1 runs while emit k is still on the device.  Shards of one run are planned and emitted back to back without a
+    synchronisation in between — paired-end in all three rng modes, several genomes in one plan, long reads, a custom
+    long-read model — and every shard must be what the same calls give without the overlap (= the oracle's)."""
+    import torch
+    from simmr_amd import CustomShortErrorProfile, MinimalLongErrorProfile
+    from simmr_amd.engine import Engine, Reads
+    from tests import _model
+    eng = Engine(0)
+    try:
+        lens = [60_000, 45_000, 52_000]
+        eng.stage_synthetic(0, lens, 5)
+        eng.stage_synthetic(1, [70_000], 6)
+        g0 = _oracle.HostGenome(_synth.synthetic_contigs(lens, 5))
+        g1 = _oracle.HostGenome(_synth.synthetic_contigs([70_000], 6))
+        eng.set_plan_overlap(True)
+        reads, seed = 40_000, 77
+        for mode in (_abi.RNG_PHILOX_FULL, _abi.RNG_PHILOX, _abi.RNG_REFERENCE):
+            prof = MinimalShortErrorProfile(rng_mode=mode).pod()
+            whole = _oracle.simulate_pe(oracle, g0, prof, reads, seed, qual_offset=33).trimmed()
+            outs = []
+            for k in range(8):  # eight shards of 2500 pairs, nothing waited for between them
+                info = eng.pe_plan(0, prof, reads, seed, 2500 * k, 2500)
+                out = Reads.allocate(info.n_reads, info.total_bases, eng.device, qual_offset=33, slot_bytes=info.slot_bytes)
+                out.total_bases = int(info.total_bases)
+                eng.pe_emit(0, out)  # (ids: pair 0 of the genome is id 0; the plan knows its first pair)
+                outs.append(out)
+            torch.cuda.synchronize()
+            got = [o.to_host() for o in outs]
+            assert np.array_equal(np.concatenate([d["seq"] for d in got]), whole["seq"]), mode
+            assert np.array_equal(np.concatenate([d["qual"] for d in got]), whole["qual"]), mode
+            for col in ("start", "end", "contig", "read_id", "flags"):
+                assert np.array_equal(np.concatenate([d[col] for d in got]), whole[col]), (mode, col)
+        # several genomes in one plan, alternating with single-genome plans of another profile
+        prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX_FULL).pod()
+        prof2 = MinimalShortErrorProfile(read_length=80, insert_size=120, mean_phred_score=20, rng_mode=_abi.RNG_PHILOX_FULL).pod()
+        a = eng.simulate_pe_reads_multi([0, 1], [9000, 7000], prof, 5, qual_offset=33)
+        b = eng.simulate_pe_reads_from_genome(1, prof2, 6000, 9, qual_offset=33)
+        c = eng.simulate_pe_reads_multi([1, 0], [3000, 5000], prof, 6, qual_offset=33)
+        torch.cuda.synchronize()
+        ob = _oracle.simulate_pe(oracle, g1, prof2, 6000, 9, qual_offset=33).trimmed()
+        assert np.array_equal(b.to_host()["seq"], ob["seq"]) and np.array_equal(b.to_host()["qual"], ob["qual"])
+        for dev, order, rd, sd in ((a, (g0, g1), (9000, 7000), 5), (c, (g1, g0), (3000, 5000), 6)):
+            parts, base = [], 0
+            for g, n in zip(order, rd):
+                parts.append(_oracle.simulate_pe(oracle, g, prof, n, sd, read_id_base=base, qual_offset=33).trimmed())
+                base += n // 2
+            d = dev.to_host()
+            assert np.array_equal(d["seq"], np.concatenate([p["seq"] for p in parts]))
+            assert np.array_equal(d["qual"], np.concatenate([p["qual"] for p in parts]))
+        # long reads, and a custom long-read model (its emit kernels use the error word of their buffer set)
+        lp = MinimalLongErrorProfile(gamma_mean=3000.0, gamma_std=2500.0, length_mode=_abi.LEN_PER_READ, rng_mode=_abi.RNG_PHILOX_FULL).pod()
+        cp = CustomShortErrorProfile(_model.synthetic_long_model(kmer_size=6, n_positions=100, seed=4, n_kmers=4 ** 6, lengths=(800, 3000, 100)),
+                                     _abi.RNG_PHILOX).pod()
+        runs = [eng.simulate_long_reads([0, 1], [150, 90], p, 3, first=f, count=60, qual_offset=33) for p in (lp, cp) for f in (0, 60, 120, 180)]
+        torch.cuda.synchronize()
+        i = 0
+        for p in (lp, cp):
+            for f in (0, 60, 120, 180):
+                o = _oracle.simulate_long(oracle, [g0, g1], [150, 90], p, 3, first=f, count=60, qual_offset=33).trimmed()
+                d = runs[i].to_host(); i += 1
+                assert np.array_equal(d["seq"], o["seq"]) and np.array_equal(d["qual"], o["qual"]), (f,)
+        eng.set_plan_overlap(False)
+        d = eng.simulate_pe_reads_from_genome(1, prof2, 6000, 9, qual_offset=33).to_host()
+        assert np.array_equal(d["seq"], ob["seq"])
+    finally:
+        eng.close()
