@@ -810,12 +810,14 @@ int plan_slot_round(simmr_engine* e, const ProfileDev& prof, uint32_t* round) {
 // the whole suite and no faster, 1.22 + 1.31 ms against 1.39: the kernel's thousand instructions per pair are PCG32 and
 // ChaCha12 either way, and the left-over pairs cost 5000 apiece once no neighbour shares their path.
 // profiles/r3/plan_register_form_kernels.txt)
+// `oc`: SIMMR_RNG_PHILOX_FULL — the pairs' outer draws are made by the plan kernel itself (kernels.hip: outer_ctr_pair)
 int launch_plan_pe(simmr_engine* e, const ProfileDev& prof, uint32_t genome, uint64_t count, const uint32_t* u_genome,
-                   const PlanArrays& pw, unsigned long long* tiles, uint32_t slot_round, unsigned long long* wave_bytes) {
+                   const PlanArrays& pw, unsigned long long* tiles, uint32_t slot_round, unsigned long long* wave_bytes,
+                   const OuterCtrArgs& oc = OuterCtrArgs{}) {
   auto plan_kern = prof.rng_mode == SIMMR_RNG_PHILOX_FULL ? k_plan_pe<true> : k_plan_pe<false>;
   hipLaunchKernelGGL(plan_kern, dim3(grid_for(count, PLAN_THREADS)), dim3(PLAN_THREADS), 0, e->stream, prof,
                      e->d_genomes.as<GenomeDev>(), genome, count, e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>(), u_genome, pw,
-                     e->d_tables.as<Tables>(), e->d_err.as<uint32_t>(), tiles, slot_round, wave_bytes);
+                     e->d_tables.as<Tables>(), e->d_err.as<uint32_t>(), tiles, slot_round, wave_bytes, oc);
   return SIMMR_OK;
 }
 
@@ -1395,10 +1397,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   if (count > 0) {
     // the stream is entered at pair start_unit (slot start_slot): units are counted from there
     if (prof.rng_mode == SIMMR_RNG_PHILOX_FULL) {
-      // one Philox block per pair (k_outer_ctr): nothing to walk, nothing to seek in (start_slot / start_unit have no meaning)
-      hipLaunchKernelGGL(k_outer_ctr, dim3(grid_for(count, 256)), dim3(256), 0, e->stream, (const MultiGenome*)nullptr, 0u,
-                         e->d_genomes.as<GenomeDev>(), (uint32_t)g.contigs.size(), seed, first, count, (uint32_t*)nullptr,
-                         e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>());
+      // one Philox block per pair, made by the plan kernel: nothing to walk, nothing to seek in (start_slot / start_unit have no meaning)
       rc = SIMMR_OK;
     } else {
       rc = run_outer(e, seed, g.contigs.size(), start_slot, first - start_unit + count, first - start_unit, count,
@@ -1414,8 +1413,9 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     unsigned long long* tiles = presummed ? tile_sums_begin(e, count) : nullptr;
     if (presummed && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
     if (coarse && !e->w_bytes.ensure(((count + 63) / 64) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
+    const OuterCtrArgs oc{nullptr, 0u, (uint32_t)g.contigs.size(), seed, first, nullptr, e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>()};
     if ((rc = launch_plan_pe(e, prof, genome_idx, count, (const uint32_t*)nullptr, pw, tiles, slot_round,
-                             coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr)))
+                             coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr, oc)))
       return rc;
   }
   e->plan_sorted = false;
@@ -1534,11 +1534,7 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
       return rc;
   }
   if (count > 0) {
-    if (full)
-      hipLaunchKernelGGL(k_outer_ctr, dim3(grid_for(count, 256)), dim3(256), 0, e->stream, e->m_genomes.as<MultiGenome>(), n_genomes,
-                         e->d_genomes.as<GenomeDev>(), 0u, seed, first, count, e->u_genome.as<uint32_t>(),
-                         e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>());
-    else
+    if (!full)  // (the full counter mode: the plan kernel finds each pair's genome and makes its outer draws)
     hipLaunchKernelGGL(k_multi_units, dim3(grid_for(count, 256)), dim3(256), 0, e->stream, e->m_genomes.as<MultiGenome>(),
                        n_genomes, first, count, e->m_contig.as<uint32_t>(), e->m_seed.as<uint64_t>(),
                        e->u_genome.as<uint32_t>(), e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>());
@@ -1548,8 +1544,10 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
     unsigned long long* tiles = presummed ? tile_sums_begin(e, count) : nullptr;
     if (presummed && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
     if (coarse && !e->w_bytes.ensure(((count + 63) / 64) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
+    const OuterCtrArgs oc{e->m_genomes.as<MultiGenome>(), n_genomes, 0u, seed, first, e->u_genome.as<uint32_t>(),
+                          e->u_contig.as<uint32_t>(), e->u_seed.as<uint64_t>()};
     if ((rc = launch_plan_pe(e, prof, 0u, count, (const uint32_t*)e->u_genome.as<uint32_t>(), pw, tiles, slot_round,
-                             coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr)))
+                             coarse ? e->w_bytes.as<unsigned long long>() : (unsigned long long*)nullptr, oc)))
       return rc;
   }
   e->plan_sorted = false;

@@ -559,30 +559,39 @@ struct MultiGenome {
   uint32_t pad;
 };
 
-// SIMMR_RNG_PHILOX_FULL: the outer draws (simulate.rs:172-186) as one Philox block per pair — no stream, no scan.  Pair p
-// of its genome's run takes the block with key = the run's seed and counter (p & 0xffffffff, 4 | (p >> 32) << 8, ..):
-// contig = ((w0 | w1 << 32) * num_seqs) >> 64, pe_seed = w2 | w3 << 32.  mg == null: one genome (n_contigs), pairs
-// first .. first + n_units; else the plan over several genomes (k_multi_units' search).
-extern "C" __global__ void __launch_bounds__(256)
-k_outer_ctr(const MultiGenome* __restrict__ mg, uint32_t n_genomes, const GenomeDev* __restrict__ genomes, uint32_t n_contigs0,
-            uint64_t seed, uint64_t first, uint64_t n_units, uint32_t* __restrict__ u_genome,
-            uint32_t* __restrict__ u_contig, uint64_t* __restrict__ u_seed) {
-  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= n_units) return;
-  uint64_t p = first + k;
-  uint64_t nc = n_contigs0;
-  if (mg) {
-    uint32_t lo = 0, hi = n_genomes;  // last genome with base <= the global pair index
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (mg[mid].base <= p) lo = mid; else hi = mid; }
-    const MultiGenome g = mg[lo];
+// SIMMR_RNG_PHILOX_FULL: the outer draws (simulate.rs:172-186) as one Philox block per pair — no stream, no scan, no kernel
+// of their own: k_plan_pe<true> makes them where it plans the pair.  Pair p of its genome's run takes the block with key =
+// the run's seed and counter (p & 0xffffffff, 4 | (p >> 32) << 8, ..): contig = ((w0 | w1 << 32) * num_seqs) >> 64,
+// pe_seed = w2 | w3 << 32.  mg == null: one genome (n_contigs0), pairs first .. ; else the plan over several genomes
+// (k_multi_units' search).  The three columns are written for the emit kernels, which read them as in every other mode.
+struct OuterCtrArgs {
+  const MultiGenome* mg;
+  uint32_t n_genomes, n_contigs0;
+  uint64_t seed, first;
+  uint32_t* u_genome_w;
+  uint32_t* u_contig_w;
+  uint64_t* u_seed_w;
+};
+SIMMR_DEV void outer_ctr_pair(const OuterCtrArgs& oc, const GenomeDev* __restrict__ genomes, uint64_t k, uint32_t genome0,
+                              uint32_t* genome, uint32_t* contig, uint64_t* pe_seed) {
+  uint64_t p = oc.first + k;
+  uint64_t nc = oc.n_contigs0;
+  *genome = genome0;
+  if (oc.mg) {
+    uint32_t lo = 0, hi = oc.n_genomes;  // last genome with base <= the global pair index
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (oc.mg[mid].base <= p) lo = mid; else hi = mid; }
+    const MultiGenome g = oc.mg[lo];
     p -= g.base;
-    u_genome[k] = g.slot;
+    *genome = g.slot;
+    oc.u_genome_w[k] = g.slot;
     nc = genomes[g.slot].n_contigs;
   }
   uint32_t w[4];
-  philox4x32_10((uint32_t)p, 4u | ((uint32_t)(p >> 32) << 8), (uint32_t)seed, (uint32_t)(seed >> 32), w);
-  u_contig[k] = (uint32_t)__umul64hi((uint64_t)w[0] | ((uint64_t)w[1] << 32), nc);
-  u_seed[k] = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+  philox4x32_10((uint32_t)p, 4u | ((uint32_t)(p >> 32) << 8), (uint32_t)oc.seed, (uint32_t)(oc.seed >> 32), w);
+  *contig = (uint32_t)__umul64hi((uint64_t)w[0] | ((uint64_t)w[1] << 32), nc);
+  *pe_seed = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+  oc.u_contig_w[k] = *contig;
+  oc.u_seed_w[k] = *pe_seed;
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -605,7 +614,8 @@ template <bool CTR>
 SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t k,
                                   const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
                                   const uint32_t* __restrict__ u_genome, const PlanArrays& pl, const Tables* __restrict__ T,
-                                  uint32_t* __restrict__ err, uint32_t* rows);
+                                  uint32_t* __restrict__ err, uint32_t* rows, bool given, uint32_t genome_v, uint32_t contig_v,
+                                  uint64_t seed_v);
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8 /* per thread */
 
@@ -616,10 +626,14 @@ k_plan_pe(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32_t genom
           const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
           const uint32_t* __restrict__ u_genome, PlanArrays pl, const Tables* __restrict__ T,
           uint32_t* __restrict__ err, unsigned long long* __restrict__ tile_bytes, uint32_t slot_round,
-          unsigned long long* __restrict__ wave_bytes) {
+          unsigned long long* __restrict__ wave_bytes, OuterCtrArgs oc) {
   __shared__ uint32_t rows[PLAN_THREADS * 17];
   uint64_t k = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
-  const uint32_t planned = k < n_units ? k_plan_pe_unit<CTR>(prof, genomes, genome, k, u_contig, u_seed, u_genome, pl, T, err, rows) : 0u;
+  uint32_t genome_v = genome, contig_v = 0;
+  uint64_t seed_v = 0;
+  if (CTR && k < n_units) outer_ctr_pair(oc, genomes, k, genome, &genome_v, &contig_v, &seed_v);  // (the pair's outer draws)
+  const uint32_t planned = k < n_units ? k_plan_pe_unit<CTR>(prof, genomes, genome, k, u_contig, u_seed, u_genome, pl, T, err, rows,
+                                                            CTR, genome_v, contig_v, seed_v) : 0u;
   // The bytes this workgroup's pairs will write, added to the sum of their tile of the offset scan (SCAN_THREADS *
   // SCAN_ITEMS units: a multiple of this workgroup's 256), so that the scan needs no pass of its own to reduce them.
   // Or (wave_bytes: the plans the counter-mode emit kernel serves) the bytes of every 64 pairs by themselves: that kernel
@@ -641,10 +655,13 @@ template <bool CTR>
 SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __restrict__ genomes, uint32_t genome, uint64_t k,
                                   const uint32_t* __restrict__ u_contig, const uint64_t* __restrict__ u_seed,
                                   const uint32_t* __restrict__ u_genome, const PlanArrays& pl, const Tables* __restrict__ T,
-                                  uint32_t* __restrict__ err, uint32_t* rows) {
-  const GenomeDev G = genomes[u_genome ? u_genome[k] : genome];  // u_genome: several genomes in one plan
-  const uint64_t size = G.contigs[u_contig[k]].size;
-  const uint64_t pe_seed = u_seed[k];
+                                  uint32_t* __restrict__ err, uint32_t* rows, bool given, uint32_t genome_v, uint32_t contig_v,
+                                  uint64_t seed_v) {
+  // (given: the outer draws were made by the caller — SIMMR_RNG_PHILOX_FULL — instead of read from the columns)
+  const GenomeDev G = genomes[given ? genome_v : (u_genome ? u_genome[k] : genome)];  // u_genome: several genomes in one plan
+  const uint32_t contig_k = given ? contig_v : u_contig[k];
+  const uint64_t size = G.contigs[contig_k].size;
+  const uint64_t pe_seed = given ? seed_v : u_seed[k];
   LaneRngT<CTR> rng;
   rng.seed_from_u64(pe_seed, rows + threadIdx.x * 17);  // (CTR: W(pe_seed), rng_device.hpp)
   uint64_t L = prof.read_length, I = prof.insert_size;
@@ -683,11 +700,12 @@ SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __res
   // simulate.rs:266,270: rng.gen::<Option<u64>>() twice (bool, then u64 if Some)
   uint64_t qs, ms;
   if (rng.gen_bool()) qs = rng.next_u64(); else { qs = entropy_substitute(pe_seed, 1); flags |= SIMMR_FLAG_QSEED_SUBST; }
-  if (rng.gen_bool()) ms = rng.next_u64(); else { ms = entropy_substitute(pe_seed, 2); flags |= SIMMR_FLAG_MSEED_SUBST; }
+  if (CTR) ms = 0;  // (mate 2's mutation seed: the stream's last draw, read by no kernel of the counter modes, its flag cleared below)
+  else if (rng.gen_bool()) ms = rng.next_u64(); else { ms = entropy_substitute(pe_seed, 2); flags |= SIMMR_FLAG_MSEED_SUBST; }
   if (prof.kind == SIMMR_K_PERFECT_SHORT) flags &= (uint8_t)~(SIMMR_FLAG_QSEED_SUBST | SIMMR_FLAG_MSEED_SUBST);
   if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode != SIMMR_RNG_REFERENCE) flags &= (uint8_t)~SIMMR_FLAG_MSEED_SUBST;  // drawn but never used
   // Rust would panic on an out-of-range slice; never silently read out of bounds.
-  const uint64_t len = G.contigs[u_contig[k]].len;
+  const uint64_t len = G.contigs[contig_k].len;
   if (fs + L > len || re + L > len) { atomicOr(err, SIMMR_ERRBIT_SLICE); L = 0; }
   if (L > TILE_MAXL) atomicOr(err, SIMMR_NOTEBIT_LONGREAD);
   pl.len[k] = (uint32_t)L;

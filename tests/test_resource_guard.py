@@ -46,7 +46,7 @@ def test_counter_mode_item_kernel_every_instantiation(kernels):
 
 
 def test_other_bench_kernels(kernels):
-    for name, occ, scratch in (("k_emit_perfect_pe<", 7, 0), ("k_plan_pe<", 6, 0), ("k_outer_ctr", 8, 0), ("k_outer_classify", 8, 0),
+    for name, occ, scratch in (("k_emit_perfect_pe<", 7, 0), ("k_plan_pe<", 6, 0), ("k_outer_classify", 8, 0),
                                ("k_outer_scan", 8, 0), ("k_outer_emit", 8, 0), ("k_fastq_size_plan", 8, 0),
                                ("k_emit_lanes<", 4, 32),               # bit-exact mode: 32 bytes per lane, documented
                                (r"k_custom_long_splice<(true|false), (true|false), false>", 4, 0),  # the k-mer splice on the reference's streams: four waves per SIMD around its LDS rows
