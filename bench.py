@@ -75,6 +75,9 @@ def main():
                          "the plan of step k + 1 then runs beside the emit of step k.  Off by default — the emit kernel's time, "
                          "which `roofline` is about, is then that of the kernel alone; the default line times ten steps with it "
                          "as `with_plan_overlap`")
+    ap.add_argument("--no-overlap-side", action="store_true",
+                    help="skip the `with_plan_overlap` side measurement (kernel-trace runs: its launches share the device and "
+                         "would be averaged into the kernels' own times)")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the untimed side measurements (the other rng mode, the FASTQ text)")
     ap.add_argument("--through-fastq", action="store_true",
                     help="one step = plan + FASTQ sizing + emit straight into FASTQ text resident in HBM (simmr_fastq_plan_direct / "
@@ -351,7 +354,7 @@ def main():
 
     # untimed side measurement (N = 1): the same steps with the plan of step k + 1 beside the emit of step k
     with_overlap = None
-    if world == 1 and not args.no_other_mode and not args.plan_overlap and not args.through_fastq:
+    if world == 1 and not args.no_other_mode and not args.no_overlap_side and not args.plan_overlap and not args.through_fastq:
         keep_c = counters_dev.clone()
         eng.set_plan_overlap(True)
         for _ in range(2):

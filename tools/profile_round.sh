@@ -5,7 +5,7 @@ tag="${1:-r4}"; out="gpurun_out/prof_$tag"; mkdir -p "$out"
 export TMPDIR=/tmp
 stats() {  # name, bench args...
   name="$1"; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$name" -o t -- python3 bench.py --no-cpu-baseline "$@" > "$out/${name}_bench.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$name" -o t -- python3 bench.py --no-cpu-baseline --no-overlap-side "$@" > "$out/${name}_bench.log" 2>&1
   f=$(find "$out/$name" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$out/kernel_stats_$name.csv"
   grep '^{"metric"' "$out/${name}_bench.log" | tail -1 > "$out/bench_${name}_under_rocprof.json"  # (rocprofv3 logs after it)
