@@ -83,11 +83,15 @@ enum simmr_profile_kind {
  *   Every profile with per-base draws: minimal-short, minimal-long, perfect-long as above, and the long-read path of a
  *   custom model (SIMMR_CUSTOM with an is_long model), whose base-by-base draws are those of the k-mer splice
  *   (simulate_errors, custom_short.rs:455-516; its qualities use a handful of words per read and stay the reference's):
- *     the alternate of the k-mer visited at position i is drawn from words A = 2 (i & 1) and B = 2 (i & 1) + 1 of the
- *     block with key = the read's seed and counter (i >> 1, 2, 0x73696D6D, 0x72000003), in two levels over the
- *     reference's law P(alternate j) = w_j / sum(w):  level 1, A >> 8 < T24 -> the k-mer stays what it is, with
- *     T24 = min(floor(2^24 P(self)), 2^24 - 1);  level 2 otherwise, m = B * n (64 bits), column c = m >> 32 of an
- *     n-column alias table over the residual law (thresholds in 2^24ths), fraction (m & 0xffffffff) >> 8.
+ *     (specification of the splice's draws, version 2 — version 1 took two words per position and was never released)
+ *     the alternate of the k-mer visited at position i is drawn from ONE word, X = word i & 3 of the block with
+ *     key = the read's seed and counter (i >> 2, 2, 0x73696D6D, 0x72000003), in two levels over the reference's law
+ *     P(alternate j) = w_j / sum(w):
+ *       level 1, X >> 8 < T24 -> the k-mer stays what it is, with T24 = 2^24 - 2^e, 2^e the smallest power of two
+ *         (1 <= e <= 24) of 2^24ths that holds 1 - P(self); a k-mer with an N has no "self": e = 24, T24 = 0;
+ *       level 2 otherwise: Z = (X - (T24 << 8)) << (24 - e) is a full word again, m = Z * n (64 bits), column
+ *         c = m >> 32 of an n-column alias table (Vose, f64, sums in list order) with thresholds in 2^24ths against
+ *         (m & 0xffffffff) >> 8, over the residual law r_j = (p_j - [j is self] (T24 / 2^24) p_j / p_s) / (1 - T24 / 2^24).
  *     (oracle/custom.c: ctr_splice_tables / orc_custom_simulate_errors_philox; the paired-end path of a custom model
  *     has no base-by-base draws and refuses the mode.)
  *   Positions, lengths and seeds still come from the reference's streams.  Statistical tolerance only (BASELINE.json

@@ -38,8 +38,8 @@ struct GenomeDev {
 #define SIMMR_ERRBIT_FASTQ 8u /* a FASTQ header does not fit, or a genome / contig index has no name */
 #define SIMMR_ERRBIT_KMER 16u /* simulate_errors chose an alternate the reference cannot splice (deletion / bad code / bad weights) */
 #define SIMMR_ERRBIT_PDF 4u /* custom PDF picked a bin without a range (a reference panic) or ran out of words */
-#define SIMMR_NOTEBIT_LONGREAD 32u /* not an error: a planned pair has reads longer than TILE_MAXL (selects the emit kernel) */
-#define TILE_MAXL 511u /* longest read the tile form of the counter-mode emit takes (emit_tile.hip) */
+#define SIMMR_NOTEBIT_LONGREAD 32u /* not an error: a planned pair has reads longer than LONGREAD_MAXL (selects the TEXT form of the emit kernel) */
+#define LONGREAD_MAXL 256u /* longest read the whole-line TEXT kernel takes (text_lines.hip: TL_MAXL) */
 
 // One CustomPDF entry (custom_short.rs:28-35): WeightedAliasIndex<f64> + per-bin Uniform<u32>,
 // flattened.  Built on the host exactly as rand_distr 0.4.3 / rand 0.8.5 build them.

@@ -20,9 +20,7 @@
 #include <vector>
 
 #include "kernels.hip"
-#if defined(SIMMR_VARIANTS)  /* `make extras`: forms that were measured and lost, kept buildable for their tests (LAB.md) */
-#include "emit_tile.hip"
-#endif
+#include "text_lines.hip"
 #include "fastq_kernels.hip"
 #include "custom_model.hpp"
 
@@ -65,6 +63,10 @@ enum PlanKind { PLAN_NONE = 0, PLAN_PE = 1, PLAN_LONG = 2 };
 
 }  // namespace
 
+// which form simmr_emit_fastq runs when SIMMR_TEXT_FORM does not say: the one that measures faster (LAB.md, round 5)
+#ifndef TEXT_FORM_DEFAULT
+#define TEXT_FORM_DEFAULT 1
+#endif
 struct simmr_engine {
   int device = -1;
   int n_cu = 0;
@@ -89,6 +91,7 @@ struct simmr_engine {
   uint64_t plan_first = 0, plan_units = 0, plan_total_bases = 0;
   uint32_t read_slots = 0;  // simmr_engine_set_read_slots: the layout of the plans to come (0 compact, 16 SIMMR_SLOT16)
   uint32_t plan_slot = 0;   // ... and of the plan in force
+  bool plan_short_ok = false;  // the current paired plan has no read longer than LONGREAD_MAXL (text_lines.hip takes it)
   bool plan_coarse = false; // pairs for the counter-mode kernel: u_off64 (first byte of every 64th pair) instead of u_off
   DevBuf w_bytes, u_off64, fq_off64;
   uint32_t splice_lds_set[2] = {0, 0};  // dynamic-LDS limit already set on this device for k_custom_long_splice<exc, fast>
@@ -112,9 +115,8 @@ struct simmr_engine {
   int cur_set = 0;
   DevBuf s_w_bytes, s_u_off64, s_m_genomes, s_u_contig, s_u_genome, s_u_seed, s_u_len, s_u_a, s_u_b, s_u_qs2, s_u_ms2, s_u_flags,
       s_u_off, s_u_order, s_d_err, s_d_runs, s_d_usable, s_ph_table;
-  int emit_variant = 0;  // 0 = lane-per-read kernel for short reads; 1 = wave-per-unit kernel (SIMMR_VARIANTS builds only)
   // measurement knobs, read ONCE when the engine is made (a stray variable cannot change a running engine's launches)
-  int philox_form = 1;          // SIMMR_PHILOX_FORM: 1 = the item kernel (default), 2 = the tile kernel where it applies (emit_tile.hip; measured slower: profiles/r3/tile_form_*)
+  int text_form = TEXT_FORM_DEFAULT;  // SIMMR_TEXT_FORM: 1 = the item form (k_emit_philox<TEXT>) always, 2 = the whole-line kernel (text_lines.hip) wherever it applies: same-box A/B
   uint32_t philox_wgs_per_cu = 128;  // SIMMR_PHILOX_WGS_PER_CU (item kernel), clamped to 1..4096.  More workgroups than the 4 per CU that
                                     // are resident: 11.25 ms at 8, 10.6 at 32, 10.4 at 64-256, 11.1 at one block per workgroup
                                     // (profiles/r3/ab_wgs_per_cu_*: the workgroups of a CU stop running their phases in step)
@@ -123,11 +125,7 @@ struct simmr_engine {
   // 4 x, 94.7 at 64 x; k_emit_perfect_pe 6.65 / 5.99 / 5.78; k_emit_custom_pe 10.99 / 10.58 / 10.44 at 16 x; the splice
   // kernel does not care).  SIMMR_GRID_MULT overrides all of them (measurement knob, 1..512).
   uint32_t lanes_mult = 64, perfect_mult = 64, custom_pe_mult = 16, custom_long_mult = 1, fastq_mult = 4;  // (k_fastq_write: 34.6 / 32.8 / 33.2 / 33.4 / 34.4 ms per step at 1 / 4 / 16 / 64 / 256 x, profiles/r3/fastq_grid_probe.log)
-  uint32_t tile_upb = 32;       // SIMMR_TILE_UPB: pairs per block of the tile kernel (1..32)
-  uint32_t tile_cap = 0;        // SIMMR_TILE_CAP: bytes per LDS tile (0 = from the profile's read length)
-  uint32_t tile_wgs_per_cu = 0; // SIMMR_TILE_WGS_PER_CU: 0 = what fits
   int splice_variant = 0;       // SIMMR_SPLICE_VARIANT: 1 = the two-load splice kernel on every model
-  bool plan_tile_ok = false;    // the current paired plan has no read longer than TILE_MAXL
   // outer-stream scratch
   DevBuf o_last_idx, o_wg_sums, o_wg_prefix, o_result;
   // long-read runs
@@ -147,6 +145,7 @@ struct simmr_engine {
   bool fq_paired = false, fq_ready = false;
   bool fq_direct = false;          // planned by simmr_fastq_plan_direct (sizes from the plan, for simmr_emit_fastq)
   uint32_t fq_read_id_base = 0, fq_maxhdr = 0;
+  uint32_t text_lines_lds_set[16] = {0};  // dynamic LDS granted to each instantiation of k_emit_text_lines so far
   DevBuf fq_hlen;                  // header bytes per read (direct form)
   DevBuf fq_tpl_dev;               // the compiled header template, read by the kernels through a pointer
   DevBuf fd_seq, fd_qual, fd_seq_off, fd_start, fd_end, fd_contig, fd_genome, fd_read_id, fd_flags;  // columns of the unfused fallback
@@ -804,7 +803,7 @@ int plan_slot_round(simmr_engine* e, const ProfileDev& prof, uint32_t* round) {
 
 // Pair plans whose emit kernel is the counter-mode item kernel get no per-pair offsets: the plan kernel leaves the bytes
 // of every 64 pairs, their scan (u_off64) places the emit kernel's blocks, and a block places its own reads
-// (k_emit_philox: `coarse`).  The tile form (SIMMR_PHILOX_FORM=2) reads per-pair offsets.
+// (k_emit_philox: `coarse`).
 // k_plan_pe for `count` pairs.  (Round 3 built a register form of it — the pair's ChaCha12 block in registers, every
 // usual draw a fixed word, the 1-2 % of the pairs whose draws take another way left to a second kernel: bit-exact in
 // the whole suite and no faster, 1.22 + 1.31 ms against 1.39: the kernel's thousand instructions per pair are PCG32 and
@@ -822,7 +821,7 @@ int launch_plan_pe(simmr_engine* e, const ProfileDev& prof, uint32_t genome, uin
 }
 
 bool plan_is_coarse(simmr_engine* e, const ProfileDev& prof) {
-  return prof.rng_mode != SIMMR_RNG_REFERENCE && prof.kind != SIMMR_K_CUSTOM && prof.kind != SIMMR_K_PERFECT_SHORT && e->philox_form != 2;
+  return prof.rng_mode != SIMMR_RNG_REFERENCE && prof.kind != SIMMR_K_CUSTOM && prof.kind != SIMMR_K_PERFECT_SHORT;
 }
 
 // the event pair of the emit about to be launched (a ring of EMIT_RING pairs, made on first use)
@@ -891,17 +890,21 @@ static PhiloxKernel philox_text_kernel(bool exc, bool cached, bool escq, bool co
                 : (exc ? k_emit_philox<true, false, false, true, true, false, true> : k_emit_philox<false, false, false, true, true, false, true>);
 }
 
-#if defined(SIMMR_VARIANTS)
-int stream_grid(simmr_engine* e, uint64_t n_units) {
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_emit_stream, 64, 0) != hipSuccess || per_cu < 1)
-    per_cu = 8;
-  uint64_t g = (uint64_t)e->n_cu * (uint64_t)per_cu;
-  if (g > n_units) g = n_units;
-  if (g == 0) g = 1;
-  return (int)g;
+// the whole-line form (text_lines.hip)
+using TextLinesKernel = decltype(&k_emit_text_lines<false, false, false, false>);
+static TextLinesKernel text_lines_kernel(bool exc, bool cached, bool escq, bool copy_only) {
+  if (copy_only) return cached ? (exc ? k_emit_text_lines<true, true, true, false> : k_emit_text_lines<false, true, true, false>)
+                               : (exc ? k_emit_text_lines<true, true, false, false> : k_emit_text_lines<false, true, false, false>);
+  if (!escq) return k_emit_text_lines<true, false, false, false>;
+  return cached ? (exc ? k_emit_text_lines<true, false, true, true> : k_emit_text_lines<false, false, true, true>)
+                : (exc ? k_emit_text_lines<true, false, false, true> : k_emit_text_lines<false, false, false, true>);
 }
-#endif
+// bytes of a header slot of that kernel: the header at any offset below 8, its '\n', what FqW may write past its bytes; a multiple of 8 and an odd number of 8-byte words (the lanes of a wave then start on different banks)
+static uint32_t tl_slot_pitch(uint32_t max_header) {
+  uint32_t w = (7u + max_header + 1u + 12u + 7u) / 8u;  // (a piece of fq_put8 writes three whole words: up to ten bytes past the header's end)
+  if (!(w & 1u)) w++;
+  return 8u * w;
+}
 
 }  // namespace
 
@@ -945,19 +948,12 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
   simmr_engine* e = new simmr_engine();
   e->device = device_ordinal;
   e->n_cu = prop.multiProcessorCount;
-  // Four measurement knobs, read once here (the defaults are what the sweeps of LAB.md found); a `make extras` build
-  // reads the ones of its extra kernels as well.
-#if defined(SIMMR_VARIANTS)
-  if (const char* v = getenv("SIMMR_EMIT_VARIANT")) e->emit_variant = atoi(v);
-  if (const char* v = getenv("SIMMR_PHILOX_FORM")) e->philox_form = atoi(v);
-  if (const char* v = getenv("SIMMR_TILE_UPB")) e->tile_upb = (uint32_t)std::min<unsigned long long>(32, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
-  if (const char* v = getenv("SIMMR_TILE_CAP")) e->tile_cap = (uint32_t)std::min<unsigned long long>(16384, strtoull(v, nullptr, 10)) & ~15u;
-  if (const char* v = getenv("SIMMR_TILE_WGS_PER_CU")) e->tile_wgs_per_cu = (uint32_t)std::min<unsigned long long>(16, strtoull(v, nullptr, 10));
-#endif
+  // Four measurement knobs, read once here (the defaults are what the sweeps of LAB.md found).
   if (const char* v = getenv("SIMMR_GRID_MULT"))
     e->lanes_mult = e->perfect_mult = e->custom_pe_mult = e->custom_long_mult = e->fastq_mult =
         (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_FASTQ_GRID_MULT")) e->fastq_mult = (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
+  if (const char* v = getenv("SIMMR_TEXT_FORM")) e->text_form = atoi(v);
   if (const char* v = getenv("SIMMR_PHILOX_WGS_PER_CU")) e->philox_wgs_per_cu = (uint32_t)std::min<unsigned long long>(4096, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_SPLICE_VARIANT")) e->splice_variant = atoi(v);
   bool ok = e->d_tables.ensure(sizeof(Tables)) && e->d_counters.ensure(8 * SIMMR_N_COUNTERS * (1 + SIMMR_CNT_SHARDS)) &&
@@ -1409,7 +1405,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
     if (prof.kind == SIMMR_K_CUSTOM || prof.rng_mode != SIMMR_RNG_REFERENCE) pw.ms2 = nullptr;
     // the plan kernel adds each pair's bytes to its tile of the offset scan (sort_by_length uses the same scratch first)
     presummed = prof.kind != SIMMR_K_PERFECT_SHORT && !coarse &&
-                !(prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0);
+                !(prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE);
     unsigned long long* tiles = presummed ? tile_sums_begin(e, count) : nullptr;
     if (presummed && !tiles) return e->fail(SIMMR_ENOMEM, "scan scratch allocation failed");
     if (coarse && !e->w_bytes.ensure(((count + 63) / 64) * 8)) return e->fail(SIMMR_ENOMEM, "offset allocation failed");
@@ -1419,7 +1415,7 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
       return rc;
   }
   e->plan_sorted = false;
-  if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant == 0 &&
+  if (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE &&
       (rc = sort_by_length(e, count, 0)))
     return rc;
   if (prof.kind == SIMMR_K_PERFECT_SHORT && count > 0) {
@@ -1438,12 +1434,12 @@ static int pe_plan_impl(simmr_engine* e, uint32_t genome_idx, const simmr_error_
   if (errw & SIMMR_ERRBIT_PDF)
     return e->fail(SIMMR_ERANGE, "a custom PDF selected a density without a bin range (the reference panics: index out of bounds)");
   (void)hipEventElapsedTime(&e->last_plan_ms, e->ev_a, e->ev_b);
-  e->plan_tile_ok = !(errw & SIMMR_NOTEBIT_LONGREAD);
   e->plan_kind = PLAN_PE;
   e->prof = prof;
   e->plan_genome = genome_idx;
   e->plan_slot = slot_round ? SIMMR_SLOT16 : 0u;
   e->plan_coarse = coarse;
+  e->plan_short_ok = !(errw & SIMMR_NOTEBIT_LONGREAD);
   e->plan_first = first;
   e->plan_units = count;
   e->plan_total_bases = total;
@@ -1478,8 +1474,8 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
   if ((rc = make_profile(e, profile, false, &prof))) return rc;
   uint32_t slot_round = 0;
   if ((rc = plan_slot_round(e, prof, &slot_round))) return rc;
-  if (prof.kind == SIMMR_K_CUSTOM || (prof.kind == SIMMR_K_MINIMAL_SHORT && prof.rng_mode == SIMMR_RNG_REFERENCE && e->emit_variant != 0))
-    return e->fail(SIMMR_ENOTSUP, "this profile / emit variant is planned one genome at a time (simmr_pe_plan)");
+  if (prof.kind == SIMMR_K_CUSTOM)
+    return e->fail(SIMMR_ENOTSUP, "a custom profile is planned one genome at a time (simmr_pe_plan)");
   // global pair ranges of the genomes (simulate.rs:179: num_reads / 2 pairs each)
   std::vector<uint64_t> base(n_genomes + 1, 0);
   for (uint32_t g = 0; g < n_genomes; g++) {
@@ -1567,12 +1563,12 @@ int simmr_pe_plan_multi(simmr_engine* e, uint32_t n_genomes, const uint32_t* gen
   if (errw & SIMMR_ERRBIT_SLICE)
     return e->fail(SIMMR_ERANGE, "a read would extend past its sequence (the reference panics on this slice)");
   (void)hipEventElapsedTime(&e->last_plan_ms, e->ev_a, e->ev_b);
-  e->plan_tile_ok = !(errw & SIMMR_NOTEBIT_LONGREAD);
   e->plan_kind = PLAN_PE;
   e->prof = prof;
   e->plan_genome = genome_idx[0];
   e->plan_slot = slot_round ? SIMMR_SLOT16 : 0u;
   e->plan_coarse = coarse;
+  e->plan_short_ok = !(errw & SIMMR_NOTEBIT_LONGREAD);
   e->plan_first = first;
   e->plan_units = count;
   e->plan_total_bases = total;
@@ -1626,38 +1622,6 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
       // pairs of one genome with few contigs: the contig bases live in LDS (no dependent load per record)
       const bool cached = paired && !e->plan_multi && e->plan_genome < e->genomes.size() &&
                           e->genomes[e->plan_genome].contigs.size() <= PHILOX_CBASE;
-#if defined(SIMMR_VARIANTS)
-      if (paired && e->plan_tile_ok && e->philox_form == 2 && !e->plan_slot) {
-        // tile form (emit_tile.hip): the block's piece of both streams is built in LDS and flushed in whole lines
-        const uint32_t upb = e->tile_upb;  // (1..32: one lane of the prologue wave per read)
-        // tile capacity: the block's expected bytes plus slack (a block that does not fit stores directly)
-        uint32_t cap = e->tile_cap ? e->tile_cap : ((2 * upb * (e->prof.read_length + 12u) + 15u) & ~15u);
-        cap = std::min<uint32_t>(std::max<uint32_t>(cap, 256u), 16384u);
-        const uint32_t lds = 2 * (cap + 32u);
-        auto kern = cached ? (exc ? k_emit_philox_tile<true, true> : k_emit_philox_tile<false, true>)
-                           : (exc ? k_emit_philox_tile<true, false> : k_emit_philox_tile<false, false>);
-        int per_cu = (int)e->tile_wgs_per_cu;
-        if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1)) per_cu = 1;
-        const uint64_t blocks = (n_units + upb - 1) / upb;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * (uint64_t)per_cu);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), e->plan_genome,
-                           n_units, pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(),
-                           out->seq, out->qual, out->qual_offset, e->plan_first, read_id_base, out_cols(out), counters, upb, cap);
-#if defined(TILE_DIAG)
-        {  // diagnostic build: cycles per phase, summed over waves (s_memtime runs at 100 MHz on gfx9: 10 ns units)
-          unsigned long long d[16];
-          (void)hipStreamSynchronize(e->stream);
-          (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(tile_diag), sizeof d);
-          const char* nm[6] = {"prologue", "items", "wait_A", "flush", "owner", "wait_B"};
-          fprintf(stderr, "tile_diag grid=%u per_cu=%d lds=%u:", grid, per_cu, lds);
-          for (int c = 0; c < 2; c++) { fprintf(stderr, " [%s n=%llu]", c ? "wave3" : "waves0-2", d[8 * c + 6]); for (int k = 0; k < 6; k++) fprintf(stderr, " %s=%.1f", nm[k], (double)d[8 * c + k] / (double)std::max(1ull, d[8 * c + 6])); }
-          fprintf(stderr, "\n");
-          unsigned long long z[16] = {0};
-          (void)hipMemcpyToSymbol(HIP_SYMBOL(tile_diag), z, sizeof z);
-        }
-#endif
-      } else
-#endif
       {
         const uint64_t blocks = (n_units + PHILOX_UNITS - 1) / PHILOX_UNITS;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)e->n_cu * e->philox_wgs_per_cu);
@@ -1741,7 +1705,7 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          (const uint32_t*)nullptr, e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset,
                          e->plan_first, read_id_base, out_cols(out), counters, (const uint8_t*)nullptr,
                          (const FqTemplate*)nullptr, FqTables{}, 0u, 0u, 0u, (const uint64_t*)nullptr);
-    } else if (e->emit_variant == 0) {  // (always, outside SIMMR_VARIANTS builds)
+    } else {
       // lane-per-read kernel: template on (exception plane present, paired, perfect-long Phred)
       bool exc = false;
       if (paired) exc = e->plan_any_exc;
@@ -1763,14 +1727,6 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                          e->plan_genome, n_units, e->plan_sorted ? e->u_order.as<uint32_t>() : (const uint32_t*)nullptr,
                          pl, e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(),
                          out->seq, out->qual, out->qual_offset, e->d_tables.as<Tables>(), counters);
-    } else {
-#if defined(SIMMR_VARIANTS)
-      hipLaunchKernelGGL(k_emit_stream, dim3(stream_grid(e, n_units)), dim3(64), 0, e->stream, e->prof,
-                         paired ? 1u : 0u, e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl,
-                         e->u_off.as<uint64_t>(), e->u_contig.as<uint32_t>(), u_genome,
-                         e->u_seed.as<uint64_t>(), out->seq, out->qual, out->qual_offset,
-                         e->d_tables.as<Tables>(), counters);
-#endif
     }
   }
   HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
@@ -1916,7 +1872,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   }
   e->plan_sorted = false;
   // (the lane-per-read kernels: the reference's streams, and a custom model in either mode)
-  if (e->emit_variant == 0 && (prof.rng_mode == SIMMR_RNG_REFERENCE || prof.kind == SIMMR_K_CUSTOM) && (rc = sort_by_length(e, count, 6))) return rc;
+  if ((prof.rng_mode == SIMMR_RNG_REFERENCE || prof.kind == SIMMR_K_CUSTOM) && (rc = sort_by_length(e, count, 6))) return rc;
   if ((rc = scan_offsets(e, count, 1u, &total, slot_round))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev_b, e->stream));
   uint32_t errw = 0;
@@ -1930,6 +1886,7 @@ int simmr_long_plan(simmr_engine* e, uint32_t n_genomes, const uint32_t* genome_
   e->plan_genome = 0;
   e->plan_slot = slot_round ? SIMMR_SLOT16 : 0u;
   e->plan_coarse = false;
+  e->plan_short_ok = false;
   e->plan_first = first;
   e->plan_units = count;
   e->plan_total_bases = total;
@@ -2309,7 +2266,47 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
 #if defined(SIMMR_NO_ESCQ)
     escq = false;
 #endif
-    auto kern = philox_text_kernel(exc, cached, escq, e->prof.kind == SIMMR_K_PERFECT_SHORT);  // (perfect-short: bases of the plan, every quality 60)
+    const bool copy_only = e->prof.kind == SIMMR_K_PERFECT_SHORT;  // (perfect-short: bases of the plan, every quality 60)
+    // The whole-line form: paired plans whose reads fit its segments, into a buffer its 16-byte chunks are aligned in,
+    // with header slots that leave room for two workgroups per CU; everything else takes the item form.
+    const uint32_t tl_pitch = tl_slot_pitch(e->fq_maxhdr);
+    const uint32_t tl_lds = TL_GROUP * tl_pitch;
+    if (e->text_form == 2 && paired && e->plan_short_ok && ((uintptr_t)dst & 15u) == 0 && tl_lds <= 40u * 1024u) {
+      auto tk = text_lines_kernel(exc, cached, escq, copy_only);
+      const int slot = (exc ? 1 : 0) | (cached ? 2 : 0) | (escq ? 4 : 0) | (copy_only ? 8 : 0);
+      if (tl_lds > e->text_lines_lds_set[slot]) {  // (static + dynamic LDS may pass the default limit with long headers)
+        HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(tk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl_lds));
+        e->text_lines_lds_set[slot] = tl_lds;
+      }
+      if (getenv("SIMMR_TL_DEBUG")) {  // (measurement aid: how many workgroups of this launch share a CU)
+        int per_cu = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tk, 256, tl_lds);
+        fprintf(stderr, "k_emit_text_lines: dynamic LDS %u bytes (slot pitch %u), %d workgroups per CU, grid %u\n", tl_lds, tl_pitch, per_cu, grid);
+      }
+      const uint32_t t8 = tl_pitch / 8u, t9 = (t8 + 1u) / 2u;
+      hipLaunchKernelGGL(tk, dim3(grid), dim3(256), tl_lds, e->stream, e->prof, e->d_genomes.as<GenomeDev>(), e->plan_genome, n_units, pl,
+                         e->u_contig.as<uint32_t>(), u_genome, e->u_seed.as<uint64_t>(), dst, 33u, e->plan_first, e->fq_read_id_base,
+                         counters, e->fq_hlen.as<uint8_t>(), e->fq_tpl_dev.as<FqTemplate>(), tb, e->fq_lit_bytes, tl_pitch, t9,
+                         65536u / t9 + 1u, (const uint64_t*)e->fq_off64.as<uint64_t>());
+      HIP_TRY(e, hipEventRecord(e->ev_d, e->stream));
+#if defined(TL_DIAG)
+      {  // measurement build: time per section, mean per wave, in microseconds (s_memtime: 100 MHz)
+        unsigned long long d[16];
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(tl_diag), sizeof d);
+        const char* nm[10] = {"prologue", "wait_slots", "format", "wait_format", "segment", "items", "tasks", "extent_fetch", "flush", "tail"};
+        fprintf(stderr, "tl_diag (us per wave, %llu waves):", d[10]);
+        for (int k = 0; k < 10; k++) fprintf(stderr, " %s=%.1f", nm[k], 0.01 * (double)d[k] / (double)std::max(1ull, d[10]));
+        fprintf(stderr, "\n");
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(tl_diag), z, sizeof z);
+      }
+#endif
+      hipError_t s2 = hipGetLastError();
+      if (s2 != hipSuccess) return e->fail(SIMMR_ENODEV, "fastq launch failed: %s", hipGetErrorString(s2));
+      return SIMMR_OK;
+    }
+    auto kern = philox_text_kernel(exc, cached, escq, copy_only);
     // windows per run: the power of two that covers the longest run ('\n' + header + '\n'), at most 32 (512 bytes)
     uint32_t wshift = 0;
     while ((16u << wshift) < e->fq_maxhdr + 2u) wshift++;

@@ -207,9 +207,12 @@ SIMMR_DEV void fq_put_global(FqW& o, const uint8_t* __restrict__ src, uint32_t n
 // the header of a read and its '\n' into an LDS slot (fastq.rs:34-56); returns the bytes written.  `lead`: the run starts
 // with the '\n' that ends the record before (the TEXT form of the emit kernel).
 // `segs` / `n_segs`: the template's pieces, staged in LDS by the caller (fq_stage_template)
+// `at0`: the header starts at byte at0 (< 8) of the slot, whose words up to there are zero (text_lines.hip: slots congruent
+// to the text modulo 8); the value returned then counts from the slot's first byte as well.
 SIMMR_DEV uint32_t fq_format_header(uint8_t* slot, uint32_t lead, const FqSeg* segs, uint32_t n_segs, const FqTables& tb,
-                                    const uint8_t* lit, const FqFields& f, uint32_t pair_char) {
+                                    const uint8_t* lit, const FqFields& f, uint32_t pair_char, uint32_t at0 = 0u) {
   FqW o = fq_begin(slot);
+  o.at = at0;
   if (lead) fq_put1(o, '\n');
   const uint32_t g = f.genome;
   const uint32_t row = tb.g_cbase[g] + f.contig;
@@ -227,6 +230,49 @@ SIMMR_DEV uint32_t fq_format_header(uint8_t* slot, uint32_t lead, const FqSeg* s
       fq_put_dec(o, sg.kind == FQ_READ_ID ? (uint64_t)f.read_id : (sg.kind == FQ_START ? f.start : f.end));
     } else {
       fq_put1(o, sg.kind == FQ_REVCOMP ? ((f.flags & SIMMR_FLAG_REVCOMP) ? 't' : 'f') : pair_char);  // mates are interleaved
+    }
+  }
+  fq_put1(o, '\n');
+  return o.at;
+}
+
+// The same with the two ids' places looked up and their first 48 bytes fetched beforehand (text_lines.hip: the four dependent
+// global loads of the routine above — contig row, id offsets, then each id's bytes where the template has it — cost a
+// batch of headers more time than its thousand instructions; there the rows are read in the block's prologue and the bytes
+// of both ids are requested together before the first piece is written).
+struct FqIds { uint32_t gid_off, gid_len, sid_off, sid_len; };
+SIMMR_DEV FqIds fq_ids(const FqTables& tb, uint32_t genome, uint32_t contig) {
+  const uint32_t row = tb.g_cbase[genome] + contig;
+  return FqIds{tb.g_id_off[genome], tb.g_id_len[genome], tb.c_off[row], tb.c_len[row]};
+}
+SIMMR_DEV void fq_fetch_id(const uint8_t* __restrict__ blob, uint32_t off, uint32_t n, uint64_t v[6]) {
+#pragma unroll
+  for (uint32_t k = 0; k < 6; k++) v[k] = (8u * k < n) ? *(global_u64_unaligned_ptr)(blob + off + 8u * k) : 0ull;
+}
+SIMMR_DEV void fq_put_fetched(FqW& o, const uint64_t v[6], const uint8_t* __restrict__ src, uint32_t n) {
+#pragma unroll
+  for (uint32_t k = 0; k < 6; k++) if (8u * k < n) fq_put8(o, v[k], n - 8u * k < 8u ? n - 8u * k : 8u);
+  for (uint32_t i = 48; i < n; i += 8) fq_put8(o, *(global_u64_unaligned_ptr)(src + i), n - i < 8u ? n - i : 8u);
+}
+SIMMR_DEV uint32_t fq_format_header_fetched(uint8_t* slot, const FqSeg* segs, uint32_t n_segs, const FqTables& tb, const uint8_t* lit,
+                                            const FqFields& f, uint32_t pair_char, uint32_t at0, const FqIds& ids,
+                                            const uint64_t gidb[6], const uint64_t sidb[6]) {
+  FqW o = fq_begin(slot);
+  o.at = at0;
+  for (uint32_t s = 0; s < n_segs; s++) {
+    const FqSeg sg = segs[s];
+    if (sg.kind == FQ_LITERAL) {
+      fq_put_bytes(o, lit + sg.off, sg.len);
+    } else if (sg.kind == FQ_GENOME_ID || sg.kind == FQ_SEQUENCE_ID) {
+      const bool gid = sg.kind == FQ_GENOME_ID;
+      uint64_t v[6];
+#pragma unroll
+      for (uint32_t k = 0; k < 6; k++) v[k] = gid ? gidb[k] : sidb[k];
+      fq_put_fetched(o, v, tb.blob + (gid ? ids.gid_off : ids.sid_off), gid ? ids.gid_len : ids.sid_len);
+    } else if (sg.kind == FQ_READ_ID || sg.kind == FQ_START || sg.kind == FQ_END) {
+      fq_put_dec(o, sg.kind == FQ_READ_ID ? (uint64_t)f.read_id : (sg.kind == FQ_START ? f.start : f.end));
+    } else {
+      fq_put1(o, sg.kind == FQ_REVCOMP ? ((f.flags & SIMMR_FLAG_REVCOMP) ? 't' : 'f') : pair_char);
     }
   }
   fq_put1(o, '\n');

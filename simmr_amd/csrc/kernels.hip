@@ -707,7 +707,7 @@ SIMMR_DEV uint32_t k_plan_pe_unit(const ProfileDev& prof, const GenomeDev* __res
   // Rust would panic on an out-of-range slice; never silently read out of bounds.
   const uint64_t len = G.contigs[contig_k].len;
   if (fs + L > len || re + L > len) { atomicOr(err, SIMMR_ERRBIT_SLICE); L = 0; }
-  if (L > TILE_MAXL) atomicOr(err, SIMMR_NOTEBIT_LONGREAD);
+  if (L > LONGREAD_MAXL) atomicOr(err, SIMMR_NOTEBIT_LONGREAD);
   pl.len[k] = (uint32_t)L;
   pl.a[k] = fs;
   pl.b[k] = re;
@@ -1252,90 +1252,8 @@ k_emit_perfect_pe(const GenomeDev* __restrict__ genomes, uint32_t genome, const 
   }
 }
 
-// ===========================================================================
-// 7. Emit: stream kernel for every profile that draws per-base numbers
-//    (minimal-short pairs, minimal-long / perfect-long reads).
-//
-// One wavefront per unit (pair or long read), persistent over a grid-stride
-// range of units.  Per 256-base tile the wave
-//   (a) generates, one ChaCha12 block per lane, every block of every StdRng
-//       stream the tile will read (mate-1 Phred + mutation stream, mate-2 Phred
-//       stream, mate-2 mutation stream) into LDS windows;
-//   (b) resolves the sequential ziggurat / gen_range consumption with ballots:
-//       all lanes assume "no extra words", the first lane that needed more
-//       (ziggurat slow path: 1.2 %; a substitution: ~1.3 %) is handled
-//       uniformly, and the lanes after it restart from the new stream position;
-//   (c) writes bases and qualities coalesced along the read.
-// ===========================================================================
-
-#define TB 256          /* bases per tile                                    */
-#define WPITCH 17       /* LDS words per block row (conflict-free pitch)     */
-#define WCAP_Q 40       /* blocks in a Phred window   (slots: 8 per block)   */
-#define WCAP_M 24       /* blocks in a mutation window (words: 16 per block) */
-#define SLACK_Q 16      /* extra u64 slots generated per tile                */
-#define SLACK_M 16      /* extra u32 words generated per tile                */
-#define LDS_BLOCKS (2 * WCAP_Q + 2 * WCAP_M)
-
-struct Win {
-  uint64_t seed;       // StdRng::seed_from_u64 argument of this stream
-  uint32_t first_blk;  // first block held
-  uint32_t nblk;       // blocks held (0 = invalid)
-  uint32_t slot;       // LDS row of first_blk
-  uint32_t home;       // LDS row of this window's own region
-  uint32_t cap;        // rows in the own region
-};
-
-struct Seg {
-  uint64_t seed;
-  uint32_t first_blk, nblk, slot;
-};
-
-// Lanes cooperatively generate up to 4 segments of blocks in as few ChaCha
-// passes as possible (one block per lane per pass).
-SIMMR_DEV void gen_segments(uint32_t* __restrict__ lds, const Seg* segs, int nseg) {
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t pre[5];
-  pre[0] = 0;
-#pragma unroll
-  for (int s = 0; s < 4; s++) pre[s + 1] = pre[s] + (s < nseg ? segs[s].nblk : 0u);
-  const uint32_t total = pre[4];
-  for (uint32_t base = 0; base < total; base += 64) {
-    const uint32_t j = base + lane;
-    if (j < total) {
-      uint64_t seed = segs[0].seed;
-      uint32_t fb = segs[0].first_blk, slot = segs[0].slot, p0 = 0;
-#pragma unroll
-      for (int s = 1; s < 4; s++)
-        if (s < nseg && j >= pre[s]) { seed = segs[s].seed; fb = segs[s].first_blk; slot = segs[s].slot; p0 = pre[s]; }
-      const Key key = pcg32_expand(seed);
-      uint32_t o[16];
-      chacha12_block(key, (uint64_t)(fb + (j - p0)), o);
-      uint32_t* row = lds + (slot + (j - p0)) * WPITCH;
-#pragma unroll
-      for (int i = 0; i < 16; i++) row[i] = o[i];
-    }
-  }
-  __syncthreads();
-}
-
-SIMMR_DEV uint32_t win_u32(const uint32_t* __restrict__ lds, const Win& w, uint32_t word) {
-  return lds[(w.slot + ((word >> 4) - w.first_blk)) * WPITCH + (word & 15u)];
-}
-SIMMR_DEV uint64_t win_u64(const uint32_t* __restrict__ lds, const Win& w, uint32_t slot) {
-  const uint32_t* row = lds + (w.slot + ((slot >> 3) - w.first_blk)) * WPITCH + (slot & 7u) * 2u;
-  return ((uint64_t)row[1] << 32) | row[0];
-}
-// (uniform) make sure blocks [blk_lo, blk_hi] are in the window; regenerate
-// the window from blk_lo into its own region otherwise.
-SIMMR_DEV void win_ensure(uint32_t* __restrict__ lds, Win& w, uint32_t blk_lo, uint32_t blk_hi) {
-  if (w.nblk != 0 && blk_lo >= w.first_blk && blk_hi < w.first_blk + w.nblk) return;
-  __syncthreads();
-  Seg s;
-  s.seed = w.seed; s.first_blk = blk_lo; s.slot = w.home;
-  s.nblk = w.cap < 64u ? w.cap : 64u;
-  w.first_blk = blk_lo; w.nblk = s.nblk; w.slot = w.home;
-  gen_segments(lds, &s, 1);
-}
+// (section 7 — the first-generation wave-per-unit kernel k_emit_stream — lost its A/B in round 1 and left the tree in round 5;
+// git history keeps it.  What the lane-per-read kernel still uses of it:)
 
 // Phred value of one accepted standard-normal draw.
 SIMMR_DEV uint32_t phred_of_z(const ProfileDev& prof, const Tables* __restrict__ T, double x) {
@@ -1354,228 +1272,6 @@ SIMMR_DEV uint32_t phred_of_z(const ProfileDev& prof, const Tables* __restrict__
   return sat_u8_f32(floorf(__fadd_rn(prof.mean_phred_f, __fmul_rn(10.0f, z))));
 }
 
-// simulate_phred_scores for bases [0, nb) of a tile; qpos = next u64 slot of the
-// stream.  Writes raw Phred to qout (LDS).
-SIMMR_DEV void phred_tile(uint32_t* __restrict__ lds, Win& w, uint32_t& qpos, uint32_t nb,
-                          uint8_t* __restrict__ qout, const ProfileDev& prof,
-                          const Tables* __restrict__ T) {
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t i = 0;
-  while (i < nb) {
-    const uint32_t nact = (nb - i) < 64u ? (nb - i) : 64u;
-    win_ensure(lds, w, qpos >> 3, (qpos + nact) >> 3);
-    const bool active = lane < nact;
-    uint64_t bits = 0;
-    if (active) bits = win_u64(lds, w, qpos + lane);
-    const uint32_t zi = (uint32_t)bits & 0xffu;
-    const double u = __longlong_as_double((long long)((bits >> 12) | 0x4000000000000000ULL)) - 3.0;
-    const double x = __dmul_rn(u, T->zig_x[zi]);
-    const bool fast = fabs(x) < T->zig_x[zi + 1];
-    const uint64_t ex = __ballot(active && !fast);
-    const uint32_t n_ok = ex ? (uint32_t)__builtin_ctzll(ex) : nact;
-    if (lane < n_ok) qout[i + lane] = (uint8_t)phred_of_z(prof, T, x);
-    i += n_ok;
-    qpos += n_ok;
-    if (ex) {
-      // ziggurat slow path for the attempt at slot qpos, executed uniformly.
-      const uint64_t b2 = win_u64(lds, w, qpos);
-      qpos++;
-      const uint32_t zj = (uint32_t)b2 & 0xffu;
-      const double u2 = __longlong_as_double((long long)((b2 >> 12) | 0x4000000000000000ULL)) - 3.0;
-      const double x2 = __dmul_rn(u2, T->zig_x[zj]);
-      bool got = false;
-      double xr = 0.0;
-      if (zj == 0) {
-        double xx = 1.0, yy = 0.0;
-        while (__dmul_rn(-2.0, yy) < __dmul_rn(xx, xx)) {
-          win_ensure(lds, w, qpos >> 3, (qpos + 1) >> 3);
-          const uint64_t a = win_u64(lds, w, qpos), b = win_u64(lds, w, qpos + 1);
-          qpos += 2;
-          const double x_ = __longlong_as_double((long long)((a >> 12) | 0x3FF0000000000000ULL)) - (1.0 - 2.220446049250313e-16 / 2.0);
-          const double y_ = __longlong_as_double((long long)((b >> 12) | 0x3FF0000000000000ULL)) - (1.0 - 2.220446049250313e-16 / 2.0);
-          xx = log(x_) / SIMMR_ZIG_R;
-          yy = log(y_);
-        }
-        xr = u2 < 0.0 ? xx - SIMMR_ZIG_R : SIMMR_ZIG_R - xx;
-        got = true;
-      } else {
-        win_ensure(lds, w, qpos >> 3, qpos >> 3);
-        const uint64_t a = win_u64(lds, w, qpos);
-        qpos++;
-        const double r = (double)(a >> 11) * (1.0 / 9007199254740992.0);
-        const double f1 = T->zig_f[zj + 1], f0 = T->zig_f[zj];
-        const double t = __dadd_rn(f1, __dmul_rn(__dsub_rn(f0, f1), r));
-        if (t < exp(__dmul_rn(__dmul_rn(-x2, x2), 0.5))) { got = true; xr = x2; }
-      }
-      if (got) {
-        if (lane == 0) qout[i] = (uint8_t)phred_of_z(prof, T, xr);
-        i++;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// simulate_point_mutations for a tile.  codes[]: 0-3 = ACGT, >= 4 = 'N' / '-'.
-SIMMR_DEV void mutate_tile(uint32_t* __restrict__ lds, Win& w, uint32_t& mpos, uint32_t nb,
-                           const uint8_t* __restrict__ q, uint8_t* __restrict__ codes,
-                           const Tables* __restrict__ T, uint32_t& n_subst) {
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t i = 0;
-  while (i < nb) {
-    const uint32_t nact = (nb - i) < 64u ? (nb - i) : 64u;
-    win_ensure(lds, w, mpos >> 4, (mpos + nact + 1) >> 4);
-    const bool active = lane < nact;
-    bool need = false;
-    if (active) {
-      const uint32_t wd = win_u32(lds, w, mpos + lane);
-      const float r = (float)(wd >> 8) * (1.0f / 16777216.0f);  // Standard f32
-      need = (r > T->acc[q[i + lane]]) && (codes[i + lane] < 4u);
-    }
-    const uint64_t ex = __ballot(need);
-    const uint32_t n_ok = ex ? (uint32_t)__builtin_ctzll(ex) : nact;
-    i += n_ok;
-    mpos += n_ok;
-    if (ex) {
-      // base i mutates: its f32 word is at mpos; then choose(&[3 others]) =
-      // gen_range(0..3u32): zone 0xBFFFFFFF (minimal_short.rs:122-125)
-      mpos++;
-      uint32_t k;
-      for (;;) {
-        win_ensure(lds, w, mpos >> 4, mpos >> 4);
-        const uint32_t v = win_u32(lds, w, mpos);
-        mpos++;
-        const uint64_t m = (uint64_t)v * 3u;
-        if ((uint32_t)m <= 0xBFFFFFFFu) { k = (uint32_t)(m >> 32); break; }
-      }
-      if (lane == 0) {
-        const uint32_t c = codes[i];
-        codes[i] = (uint8_t)(k + (k >= c ? 1u : 0u));  // k-th of the three other bases, in ACGT order
-      }
-      n_subst++;
-      i++;
-    }
-  }
-  __syncthreads();
-}
-
-SIMMR_DEV void load_codes(const GenomeDev& G, uint64_t pos0, uint32_t nb, uint8_t* __restrict__ dst,
-                          uint32_t& n_acgt) {
-  const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t b = lane; b < nb; b += 64) {
-    const uint64_t p = pos0 + b;
-    uint32_t code = (G.packed[p >> 4] >> ((p & 15u) * 2u)) & 3u;
-    if (G.has_exc) code |= ((G.mask[p >> 5] >> (p & 31u)) & 1u) << 2;
-    dst[b] = (uint8_t)code;
-    n_acgt += code < 4u ? 1u : 0u;
-  }
-}
-
-#if defined(SIMMR_VARIANTS)  /* the first-generation wave-per-unit kernel: only in `make extras` builds (SIMMR_EMIT_VARIANT=1), as an independently written cross-check */
-extern "C" __global__ void __launch_bounds__(64)
-k_emit_stream(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ genomes,
-              uint32_t genome_const, uint64_t n_units, PlanArrays pl,
-              const uint64_t* __restrict__ u_off, const uint32_t* __restrict__ u_contig,
-              const uint32_t* __restrict__ u_genome, const uint64_t* __restrict__ u_seed,
-              uint8_t* __restrict__ seq, uint8_t* __restrict__ qual, uint32_t qual_offset,
-              const Tables* __restrict__ T, unsigned long long* __restrict__ counters) {
-  __shared__ uint32_t lds[LDS_BLOCKS * WPITCH];
-  __shared__ uint8_t q1[TB], c1[TB], q2[TB], c2[TB];
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t n_subst = 0, n_acgt = 0;
-  uint64_t qsum = 0;
-  const bool mutates = prof.kind != SIMMR_K_PERFECT_SHORT;
-
-  for (uint64_t k = blockIdx.x; k < n_units; k += gridDim.x) {
-    const uint32_t L = pl.len[k];
-    if (L == 0) continue;
-    const GenomeDev G = genomes[u_genome ? u_genome[k] : genome_const];
-    const uint64_t cbase = G.contigs[u_contig[k]].base;
-    const uint64_t o1 = u_off[k];
-    const uint64_t o2 = o1 + L;
-    const uint64_t src1 = cbase + pl.a[k];  // forward slice start
-    const uint64_t src2 = cbase + pl.b[k];  // mate-2 slice start (forward strand)
-
-    Win Aq, Am, Bq, Cm;
-    Aq.seed = u_seed[k]; Aq.home = 0; Aq.cap = WCAP_Q; Aq.nblk = 0; Aq.slot = 0; Aq.first_blk = 0;
-    Am.seed = Aq.seed; Am.home = 2 * WCAP_Q; Am.cap = WCAP_M; Am.nblk = 0; Am.slot = Am.home; Am.first_blk = 0;
-    Bq.seed = paired ? pl.qs2[k] : 0; Bq.home = WCAP_Q; Bq.cap = WCAP_Q; Bq.nblk = 0; Bq.slot = Bq.home; Bq.first_blk = 0;
-    Cm.seed = paired ? pl.ms2[k] : 0; Cm.home = 2 * WCAP_Q + WCAP_M; Cm.cap = WCAP_M; Cm.nblk = 0; Cm.slot = Cm.home; Cm.first_blk = 0;
-    uint32_t qposA = 0, mposA = 0, qposB = 0, mposC = 0;
-
-    for (uint32_t t0 = 0; t0 < L; t0 += TB) {
-      const uint32_t nb = (L - t0) < TB ? (L - t0) : TB;
-      // (a) one batched generation pass for everything this tile should need
-      Seg segs[4];
-      int ns = 0;
-      {
-        const uint32_t qlo = qposA >> 3, qhi = (qposA + nb + SLACK_Q) >> 3;
-        uint32_t n = qhi - qlo + 1; if (n > WCAP_Q) n = WCAP_Q;
-        Aq.first_blk = qlo; Aq.nblk = n; Aq.slot = Aq.home;
-        segs[ns].seed = Aq.seed; segs[ns].first_blk = qlo; segs[ns].nblk = n; segs[ns].slot = Aq.home; ns++;
-        const uint32_t mlo = mposA >> 4, mhi = (mposA + nb + SLACK_M) >> 4;
-        if (mlo >= qlo && mhi < qlo + n) {  // same stream: the Phred window already holds these blocks
-          Am.first_blk = Aq.first_blk; Am.nblk = Aq.nblk; Am.slot = Aq.slot;
-        } else {
-          uint32_t m = mhi - mlo + 1; if (m > WCAP_M) m = WCAP_M;
-          Am.first_blk = mlo; Am.nblk = m; Am.slot = Am.home;
-          segs[ns].seed = Am.seed; segs[ns].first_blk = mlo; segs[ns].nblk = m; segs[ns].slot = Am.home; ns++;
-        }
-      }
-      if (paired) {
-        const uint32_t qlo = qposB >> 3, qhi = (qposB + nb + SLACK_Q) >> 3;
-        uint32_t n = qhi - qlo + 1; if (n > WCAP_Q) n = WCAP_Q;
-        Bq.first_blk = qlo; Bq.nblk = n; Bq.slot = Bq.home;
-        segs[ns].seed = Bq.seed; segs[ns].first_blk = qlo; segs[ns].nblk = n; segs[ns].slot = Bq.home; ns++;
-        const uint32_t mlo = mposC >> 4, mhi = (mposC + nb + SLACK_M) >> 4;
-        uint32_t m = mhi - mlo + 1; if (m > WCAP_M) m = WCAP_M;
-        Cm.first_blk = mlo; Cm.nblk = m; Cm.slot = Cm.home;
-        segs[ns].seed = Cm.seed; segs[ns].first_blk = mlo; segs[ns].nblk = m; segs[ns].slot = Cm.home; ns++;
-      }
-      __syncthreads();
-      gen_segments(lds, segs, ns);
-
-      // (b) mate 1 / the long read
-      const bool alias = (Am.slot == Aq.slot);
-      phred_tile(lds, Aq, qposA, nb, q1, prof, T);
-      if (alias && (Aq.slot != Am.slot || Aq.first_blk != Am.first_blk)) Am.nblk = 0;  // window moved
-      load_codes(G, src1 + t0, nb, c1, n_acgt);
-      __syncthreads();
-      if (mutates) mutate_tile(lds, Am, mposA, nb, q1, c1, T, n_subst);
-      for (uint32_t b = lane; b < nb; b += 64) {
-        seq[o1 + t0 + b] = (uint8_t)"ACGTN-N-"[c1[b]];
-        const uint32_t qv = q1[b];
-        qual[o1 + t0 + b] = (uint8_t)(qv + qual_offset);
-        qsum += qv;
-      }
-      // (c) mate 2: mutate the forward-strand slice, then reverse-complement
-      if (paired) {
-        phred_tile(lds, Bq, qposB, nb, q2, prof, T);
-        load_codes(G, src2 + t0, nb, c2, n_acgt);
-        __syncthreads();
-        if (mutates) mutate_tile(lds, Cm, mposC, nb, q2, c2, T, n_subst);
-        for (uint32_t b = lane; b < nb; b += 64) {
-          seq[o2 + (L - 1 - (t0 + b))] = (uint8_t)"TGCAN-N-"[c2[b]];  // simulate.rs:283
-          const uint32_t qv = q2[b];
-          qual[o2 + t0 + b] = (uint8_t)(qv + qual_offset);              // quality is NOT reversed
-          qsum += qv;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // counters: one atomic per wave per counter
-  for (int d = 32; d > 0; d >>= 1) {
-    n_acgt += __shfl_down(n_acgt, d, 64);
-    qsum += __shfl_down(qsum, d, 64);
-  }
-  if (lane == 0 && counters) {
-    shard_add(counters, SIMMR_CNT_SUBSTITUTIONS, (unsigned long long)n_subst);
-    shard_add(counters, SIMMR_CNT_ACGT_BASES, (unsigned long long)n_acgt);
-    shard_add(counters, SIMMR_CNT_QUAL_SUM, (unsigned long long)qsum);
-  }
-}
-#endif  // SIMMR_VARIANTS
 
 // ===========================================================================
 // 8. Emit, lane-per-read form (the fast path for short reads)

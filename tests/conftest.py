@@ -15,19 +15,6 @@ def pytest_configure(config):
                             "(reference-held / public third-party / self-generated; tests/test_oracle_kat.py)")
 
 
-def extras_library_loaded():
-    """True when this process runs against the `make extras` build of the HIP library (simmr_amd/csrc/Makefile): the one
-    that still carries the forms that were measured and lost — the LDS-tiled counter-mode kernel and the wave-per-unit
-    kernel — whose tests only run there:
-        make -C simmr_amd/csrc extras
-        SIMMR_HIP_LIB=simmr_amd/csrc/variants/libsimmr_hip_variants.so python -m pytest tests -m gpu"""
-    return os.environ.get("SIMMR_HIP_LIB", "").endswith("libsimmr_hip_variants.so")
-
-
-needs_extras = pytest.mark.skipif(not extras_library_loaded(), reason="a kernel of the `make extras` build only "
-                                  "(SIMMR_HIP_LIB=simmr_amd/csrc/variants/libsimmr_hip_variants.so)")
-
-
 @pytest.fixture(scope="session", autouse=True)
 def _hip_library_is_built():
     """A fresh checkout has no binaries (they are git-ignored): build the C-ABI library once, as

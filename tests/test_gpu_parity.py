@@ -9,7 +9,6 @@ substitute (include/simmr_hip.h) and the reads are flagged.
 import numpy as np
 import pytest
 
-from tests.conftest import needs_extras
 
 from simmr_amd import (MinimalLongErrorProfile, MinimalShortErrorProfile, PerfectLongErrorProfile,
                        PerfectShortErrorProfile, _abi)
@@ -130,39 +129,6 @@ def test_minimal_short_params(engine, oracle, genome_multi, L, I, q):
     dev = engine.simulate_pe_reads_from_genome(1, prof, 1500, 5, qual_offset=33)
     ora = _oracle.simulate_pe(oracle, genome_multi, prof, 1500, 5, qual_offset=33, max_len=4096)
     assert_same(dev.to_host(), ora.trimmed())
-
-
-@needs_extras
-def test_minimal_short_wave_per_pair_variant(oracle, genome_1m, monkeypatch):
-    """The wave-per-unit emit kernel (used for long reads) on pairs: same bytes."""
-    from simmr_amd.engine import Engine
-    monkeypatch.setenv("SIMMR_EMIT_VARIANT", "1")
-    e2 = Engine(0)
-    try:
-        e2.stage_synthetic(0, [1_000_000], 1)
-        prof = MinimalShortErrorProfile(read_length=170, insert_size=90).pod()
-        dev = e2.simulate_pe_reads_from_genome(0, prof, 3000, 11)
-        ora = _oracle.simulate_pe(oracle, genome_1m, prof, 3000, 11)
-        assert_same(dev.to_host(), ora.trimmed())
-    finally:
-        e2.close()
-
-
-@needs_extras
-def test_long_wave_per_read_variant(oracle, genome_multi, monkeypatch):
-    """k_emit_stream (wave per read, LDS windows) stays covered for long reads."""
-    from simmr_amd.engine import Engine
-    monkeypatch.setenv("SIMMR_EMIT_VARIANT", "1")
-    e2 = Engine(0)
-    try:
-        e2.stage_genome(0, genome_multi.contigs)
-        for prof in (MinimalLongErrorProfile().pod(),
-                     PerfectLongErrorProfile(gamma_mean=3000.0, gamma_std=2500.0, length_mode=_abi.LEN_PER_READ).pod()):
-            dev = e2.simulate_long_reads([0], [40], prof, 21)
-            ora = _oracle.simulate_long(oracle, [genome_multi], [40], prof, 21)
-            assert_same(dev.to_host(), ora.trimmed())
-    finally:
-        e2.close()
 
 
 def test_minimal_short_exceptions(engine, oracle):

@@ -232,7 +232,7 @@ def _canaries_intact(bufs, PAD, tb):
         assert bool((b[:PAD] == 0xA5).all()) and bool((b[PAD + tb:] == 0xA5).all())
 
 
-@pytest.mark.parametrize("path", ["perfect-short", "minimal-short", "minimal-short-wave", "philox-short", "custom-short",
+@pytest.mark.parametrize("path", ["perfect-short", "minimal-short", "philox-short", "custom-short",
                                   "minimal-long", "philox-long", "perfect-long", "custom-long"])
 def test_emit_stays_inside_exact_capacity(engine, genome_multi, path, monkeypatch):
     """include/simmr_hip.h promises that seq and qual need total_bases bytes, not a byte more: every emit kernel is run
@@ -242,18 +242,11 @@ def test_emit_stays_inside_exact_capacity(engine, genome_multi, path, monkeypatc
     from simmr_amd import (CustomShortErrorProfile, PerfectLongErrorProfile, PerfectShortErrorProfile, model_io)
     from simmr_amd.engine import Engine
     eng = engine
-    if path == "minimal-short-wave":  # the wave-per-unit emit kernel is chosen when the engine is created
-        from tests.conftest import extras_library_loaded
-        if not extras_library_loaded():
-            pytest.skip("k_emit_stream is in the `make extras` build only")
-        monkeypatch.setenv("SIMMR_EMIT_VARIANT", "1")
-        eng = Engine(0)
-        eng.stage_genome(1, genome_multi.contigs)
     keep = None
     long_mode = path.endswith("long")
     if path == "perfect-short":
         pod = PerfectShortErrorProfile(read_length=37, insert_size=45).pod()
-    elif path in ("minimal-short", "minimal-short-wave"):
+    elif path == "minimal-short":
         pod = MinimalShortErrorProfile(read_length=41, insert_size=60).pod()
     elif path == "philox-short":
         pod = MinimalShortErrorProfile(read_length=41, insert_size=60, rng_mode=_abi.RNG_PHILOX).pod()

@@ -188,3 +188,13 @@ def test_header_states_the_shipped_philox_specification():
     assert "0x73696D6Du" in (ROOT / "simmr_amd" / "csrc" / "rng_device.hpp").read_text()  # (philox4x32_10, used by kernels.hip)
     for needle in ("SIMMR_RNG_PHILOX_FULL", "(w >> 2, 3, 0x73696D6D, 0x72000003)", "4 | (p >> 32) << 8"):  # the full counter mode
         assert needle in text, needle
+    # the k-mer splice of a custom long-read model: the shipped one-word form, not the two-word form
+    # of its first commit; the same statement in the oracle and next to the product's table builder
+    for needle in ("(i >> 2, 2, 0x73696D6D, 0x72000003)", "X = word i & 3", "T24 = 2^24 - 2^e", "Z = (X - (T24 << 8)) << (24 - e)"):
+        assert needle in text, needle
+    for stale in ("i >> 1, 2", "A = 2 (i & 1)", "m = B * n", "min(floor(2^24 P(self))"):
+        assert stale not in text, stale
+    for f in ("oracle/custom.c", "simmr_amd/csrc/custom_model.hpp"):
+        assert "2^24 - 2^e" in (ROOT / f).read_text(), f
+    assert "(uint32_t)(i >> 2), 2u, 0x73696D6Du, 0x72000003u" in (ROOT / "oracle" / "custom.c").read_text()
+    assert "philox4x32_10(i >> 2, 2u," in (ROOT / "simmr_amd" / "csrc" / "kernels.hip").read_text()
