@@ -116,6 +116,7 @@ struct simmr_engine {
   DevBuf s_w_bytes, s_u_off64, s_m_genomes, s_u_contig, s_u_genome, s_u_seed, s_u_len, s_u_a, s_u_b, s_u_qs2, s_u_ms2, s_u_flags,
       s_u_off, s_u_order, s_d_err, s_d_runs, s_d_usable, s_ph_table;
   // measurement knobs, read ONCE when the engine is made (a stray variable cannot change a running engine's launches)
+  bool inject_null_ctr_tables = false;  // SIMMR_FAULT_INJECT=null_ctr_tables: test switch, see custom_long_tables_missing
   int text_form = TEXT_FORM_DEFAULT;  // SIMMR_TEXT_FORM: 1 = the item form (k_emit_philox<TEXT>) always, 2 = the whole-line kernel (text_lines.hip) wherever it applies: same-box A/B
   uint32_t philox_wgs_per_cu = 128;  // SIMMR_PHILOX_WGS_PER_CU (item kernel), clamped to 1..4096.  More workgroups than the 4 per CU that
                                     // are resident: 11.25 ms at 8, 10.6 at 32, 10.4 at 64-256, 11.1 at one block per workgroup
@@ -445,6 +446,9 @@ int make_custom_profile(simmr_engine* e, const simmr_error_profile* p, bool want
     d.custom.kmer_recs_ctr = e->c_krecs_ctr.as<Rec16>();
     d.custom.kmer_cols_ctr = kt.stride ? e->c_kcols_ctr.as<Rec16>() : nullptr;
     d.custom.kmer_tab32 = kt.stride ? e->c_ktab32.as<uint32_t>() : nullptr;
+  }
+  if (e->inject_null_ctr_tables) {  // SIMMR_FAULT_INJECT=null_ctr_tables (tests/test_gpu_parity.py: the emit must refuse, not launch)
+    d.custom.kmer_recs_ctr = nullptr; d.custom.kmer_cols_ctr = nullptr; d.custom.kmer_tab32 = nullptr;
   }
   e->custom_prof = d;
   e->custom_hash = mh;
@@ -890,6 +894,25 @@ static PhiloxKernel philox_text_kernel(bool exc, bool cached, bool escq, bool co
                 : (exc ? k_emit_philox<true, false, false, true, true, false, true> : k_emit_philox<false, false, false, true, true, false, true>);
 }
 
+// Every device table the custom long-read kernels dereference for this mode and form must exist BEFORE they are launched:
+// a kernel handed a null table base faults the GPU (round 4, gpurun_out/ctr1_*: "Memory access fault ... on address (nil)"
+// from the first build of the splice's counter mode; LAB.md, round 5, has what is known about it), and a fault on this
+// pool can reset every GPU of the host.  Returns the name of the first table that is missing, or null.
+static const char* custom_long_tables_missing(const ProfileDev& prof, bool fast, bool ctr) {
+  const CustomDev& c = prof.custom;
+  if (!c.pdfs) return "pdfs";
+  if (!c.col_rec) return "col_rec";
+  if (!c.bin_rec) return "bin_rec";
+  if (!c.kmer_direct) return "kmer_direct";
+  if (!c.kmer_slots) return "kmer_slots";
+  if (fast) {
+    if (ctr) { if (!c.kmer_cols_ctr) return "kmer_cols_ctr"; if (!c.kmer_tab32) return "kmer_tab32"; }
+    else { if (!c.kmer_cols) return "kmer_cols"; if (!c.kmer_cnt8) return "kmer_cnt8"; }
+  }
+  if (ctr ? !c.kmer_recs_ctr : !c.kmer_recs) return ctr ? "kmer_recs_ctr" : "kmer_recs";
+  return nullptr;
+}
+
 // the whole-line form (text_lines.hip)
 using TextLinesKernel = decltype(&k_emit_text_lines<false, false, false, false>);
 static TextLinesKernel text_lines_kernel(bool exc, bool cached, bool escq, bool copy_only) {
@@ -954,6 +977,7 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
         (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_FASTQ_GRID_MULT")) e->fastq_mult = (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_TEXT_FORM")) e->text_form = atoi(v);
+  if (const char* v = getenv("SIMMR_FAULT_INJECT")) e->inject_null_ctr_tables = strcmp(v, "null_ctr_tables") == 0;
   if (const char* v = getenv("SIMMR_PHILOX_WGS_PER_CU")) e->philox_wgs_per_cu = (uint32_t)std::min<unsigned long long>(4096, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_SPLICE_VARIANT")) e->splice_variant = atoi(v);
   bool ok = e->d_tables.ensure(sizeof(Tables)) && e->d_counters.ensure(8 * SIMMR_N_COUNTERS * (1 + SIMMR_CNT_SHARDS)) &&
@@ -1640,6 +1664,12 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
                            coarse ? (const uint64_t*)e->u_off64.as<uint64_t>() : (const uint64_t*)nullptr);
       }
     } else if (e->prof.kind == SIMMR_K_CUSTOM && !paired) {
+      {
+        const bool fast0 = e->prof.custom.kmer_stride != 0 && e->splice_variant != 1;
+        if (const char* missing = custom_long_tables_missing(e->prof, fast0, e->prof.rng_mode != SIMMR_RNG_REFERENCE))
+          return e->fail(SIMMR_EINVAL, "custom long-read emit refused: device table `%s` of the model is not set for rng_mode %u "
+                                       "(nothing was launched)", missing, e->prof.rng_mode);
+      }
       HIP_TRY(e, hipMemsetAsync(e->d_err.p, 0, 64, e->stream));
       bool exc = false;
       for (const auto& g : e->genomes) exc = exc || (g.staged && g.has_exc);

@@ -368,6 +368,33 @@ k_emit_text_lines(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32
       for (;;) {
         if (e == s && j_e == j_s) break;  // (cannot happen: engine.hip sizes the ring so that a read always fits)
         TL_T(4);
+        // ---- how far the text will be complete after this round (every whole line below that point can go) ----
+        const bool last = (e == n_it) && (j_e == nsr);
+        uint32_t C;
+        if (last) {
+          C = x_end;
+        } else {
+          const uint32_t jl = j_e - 1u;  // (a round that is not the last started a read or is inside one: j_e >= 1)
+          const uint32_t gl = __builtin_amdgcn_readlane(my_gs, jl), ng = __builtin_amdgcn_readlane(my_g, jl);
+          if (e > gl && e < gl + ng) {  // inside read jl: its bases are complete up to item e (a reverse mate's fill from the end)
+            const uint32_t dl = __builtin_amdgcn_readlane(my_dst, jl);
+            C = __builtin_amdgcn_readlane(my_rev, jl) ? dl : dl + 16u * (e - gl);
+          } else {
+            C = j_e < nsr ? __builtin_amdgcn_readlane(my_x, j_e) : x_end;
+          }
+        }
+        const uint32_t limit = last ? x_end : (C & ~63u);
+        const uint32_t F2 = limit > F ? limit : F;
+        // ---- the next round's extent, item records and plane words: asked for now, so that the two LDS lookups and the
+        // memory load behind them run under this round's items (what they depend on — where this round ends — is known)
+        uint32_t e2 = e, j_e2 = j_e;
+        Fetch nxt;
+        nxt.r = R0; nxt.ci = 0; nxt.ra = make_uint4(0u, 0u, 0u, 0u); nxt.raw = 0ull;
+        if (!last) {
+          extent(e, j_e, F2, e2, j_e2);
+          nxt = fetch(e, e2);
+        }
+        TL_T(7);
         // ---- items ----
         if (s + lane < e) {
           const uint32_t r = cur.r;
@@ -479,61 +506,55 @@ k_emit_text_lines(ProfileDev prof, const GenomeDev* __restrict__ genomes, uint32
             }
           }
         }
-        // ---- how far the text is complete: every whole line below the first byte that is still to come can go ----
-        const bool last = (e == n_it) && (j_e == nsr);
-        uint32_t C;
-        if (last) {
-          C = x_end;
-        } else {
-          const uint32_t jl = j_e - 1u;  // (a round that is not the last started a read or is inside one: j_e >= 1)
-          const uint32_t gl = __builtin_amdgcn_readlane(my_gs, jl), ng = __builtin_amdgcn_readlane(my_g, jl);
-          if (e > gl && e < gl + ng) {  // inside read jl: its bases are complete up to item e (a reverse mate's fill from the end)
-            const uint32_t dl = __builtin_amdgcn_readlane(my_dst, jl);
-            C = __builtin_amdgcn_readlane(my_rev, jl) ? dl : dl + 16u * (e - gl);
-          } else {
-            C = j_e < nsr ? __builtin_amdgcn_readlane(my_x, j_e) : x_end;
-          }
-        }
-        const uint32_t limit = last ? x_end : (C & ~63u);
-        const uint32_t F2 = limit > F ? limit : F;
         TL_T(6);
-        // ---- the next round's extent and plane words: fetched in front of this round's stores ----
-        // (into `cur` itself, whose last use was in this round's items: a second variable copied over at the loop's end is
-        // a register move that has to wait for the load — and, the counter being in order, for the stores behind it)
-        uint32_t e2 = e, j_e2 = j_e;
-        if (!last) {
-          extent(e, j_e, F2, e2, j_e2);
-          cur = fetch(e, e2);
-        }
+        // ---- the next round's item records and plane words take the place of this round's, in front of this round's stores
+        // (a register move that waits for the load — it was asked for at the round's top, and the stores of the round before
+        // are older still)
+        if (!last) cur = nxt;
         tl_wave_sync();
-        TL_T(7);
         // ---- flush ----
-        for (uint32_t cx = F + 16u * lane; cx < limit; cx += 1024u) {
-          const uint32_t ro = cx & (TL_RING - 1u);
-          v4u32* rp = reinterpret_cast<v4u32*>(ringb + ro);
-          v4u32 v = *rp;
-          *rp = v4u32{0u, 0u, 0u, 0u};
-          if (ro < TL_GUARD) {  // what ran past the ring's end belongs here
-            v4u32* gp = reinterpret_cast<v4u32*>(ringb + TL_RING + ro);
-            v |= *gp;
-            *gp = v4u32{0u, 0u, 0u, 0u};
+        // (at most TL_RING bytes = four passes of 64 chunks; the passes' LDS reads are issued together, then their stores:
+        // one LDS latency per flush instead of one per pass)
+        {
+          v4u32 v[4];
+#pragma unroll
+          for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t cx = F + 16u * lane + 1024u * k;
+            v[k] = v4u32{0u, 0u, 0u, 0u};
+            if (cx < limit) {
+              const uint32_t ro = cx & (TL_RING - 1u);
+              v4u32* rp = reinterpret_cast<v4u32*>(ringb + ro);
+              v[k] = *rp;
+              *rp = v4u32{0u, 0u, 0u, 0u};
+              if (ro < TL_GUARD) {  // what ran past the ring's end belongs here
+                v4u32* gp = reinterpret_cast<v4u32*>(ringb + TL_RING + ro);
+                v[k] |= *gp;
+                *gp = v4u32{0u, 0u, 0u, 0u};
+              }
+            }
           }
-          const uint32_t lo = cx < x_begin ? x_begin - cx : 0u;
-          const uint32_t hi = limit - cx < 16u ? limit - cx : 16u;
+#pragma unroll
+          for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t cx = F + 16u * lane + 1024u * k;
+            if (cx < limit) {
+              const uint32_t lo = cx < x_begin ? x_begin - cx : 0u;
+              const uint32_t hi = limit - cx < 16u ? limit - cx : 16u;
 #if defined(SIMMR_ABLATE_STORES)
-          asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(lo), "v"(hi));
+              asm volatile("" :: "v"(v[k].x), "v"(v[k].y), "v"(v[k].z), "v"(v[k].w), "v"(lo), "v"(hi));
 #else
-          if (lo == 0u && hi == 16u) {
-            stream_store(reinterpret_cast<v4u32*>(gbase + cx), v);
-          } else if (lo < hi) {
-            // a chunk a neighbour shares (the segment's first or last): kept for the end of the segment — byte stores
-            // inside this loop cost every round a wait for all outstanding stores (the compiler guards the loop's
-            // registers against them at the loop's head)
-            const uint32_t k = lo ? 0u : 1u;
-            *reinterpret_cast<v4u32*>(&edge_v[wave][k]) = v;
-            edge_m[wave][k] = cx | (lo << 24) | ((hi & 15u) << 28);
-          }
+              if (lo == 0u && hi == 16u) {
+                stream_store(reinterpret_cast<v4u32*>(gbase + cx), v[k]);
+              } else if (lo < hi) {
+                // a chunk a neighbour shares (the segment's first or last): kept for the end of the segment — byte stores
+                // inside this loop cost every round a wait for all outstanding stores (the compiler guards the loop's
+                // registers against them at the loop's head)
+                const uint32_t kk = lo ? 0u : 1u;
+                *reinterpret_cast<v4u32*>(&edge_v[wave][kk]) = v[k];
+                edge_m[wave][kk] = cx | (lo << 24) | ((hi & 15u) << 28);
+              }
 #endif
+            }
+          }
         }
         if (last) { TL_T(8); }
         if (last) break;

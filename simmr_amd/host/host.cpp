@@ -387,7 +387,7 @@ std::string usage() {
          "  --seed <N>                    Random seed\n"
          "  --size-adjusted               Adjust by genome size\n"
          "  --contiguous                  Treat separate sequences in a genome as one contiguous sequence\n"
-         "extensions: --device <N>  --gamma <mean,std>  --per-read-lengths  --uniform-start  --host-fastq  --host-normalize  --device-chunk-reads <N>  --rng <reference|philox|philox-full>\n";
+         "extensions: --device <N>  --devices <a,b,...>  --gamma <mean,std>  --per-read-lengths  --uniform-start  --host-fastq  --host-normalize  --device-chunk-reads <N>  --rng <reference|philox|philox-full>\n";
 }
 
 static bool parse_u64(const std::string& s, uint64_t max, uint64_t* out) {
@@ -448,6 +448,18 @@ bool parse_cli_args(int argc, const char* const* argv, CliArgs* a, std::string* 
     else if (arg == "--host-fastq") a->host_fastq = true;
     else if (arg == "--host-normalize") a->host_normalize = true;
     else if (arg == "--device-chunk-reads") { if (!need(&v) || !parse_u64(v, UINT64_MAX, &u) || u == 0) { *err = "invalid value for --device-chunk-reads"; return false; } a->device_chunk_reads = u; }
+    else if (arg == "--devices") {
+      if (!need(&v)) return false;
+      a->devices.clear();
+      size_t pos = 0;
+      while (pos <= v.size()) {
+        const size_t comma = std::min(v.find(',', pos), v.size());
+        if (!parse_u64(v.substr(pos, comma - pos), 1023, &u)) { *err = "invalid value for --devices (a comma-separated list of device ordinals)"; return false; }
+        a->devices.push_back((int)u);
+        pos = comma + 1;
+      }
+      if (a->devices.empty() || a->devices.size() > 64) { *err = "invalid value for --devices"; return false; }
+    }
     else if (arg == "--device") { if (!need(&v) || !parse_u64(v, 1023, &u)) { *err = "invalid value for --device"; return false; } a->device = (int)u; }
     else if (arg == "--gamma") {
       if (!need(&v)) return false;

@@ -8,7 +8,10 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -89,8 +92,11 @@ struct TextDrain {
   FILE* f = nullptr;
   static constexpr size_t CHUNK = 256u << 20;
   int pending = -1;  // buffer whose text still has to go to the file
-  bool open(const std::string& output, std::string* err) {
-    f = fopen(output.c_str(), "ab");
+  bool own_file = true;
+  // `shared`: the file several drains append to, each when it is its turn (run_scope_devices); the caller closes it
+  bool open(const std::string& output, std::string* err, FILE* shared = nullptr) {
+    if (shared) { f = shared; own_file = false; }
+    else f = fopen(output.c_str(), "ab");
     if (!f) { *err = "cannot open " + output; return false; }
     if (hipHostMalloc(&pin[0], CHUNK, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&pin[1], CHUNK, hipHostMallocDefault) != hipSuccess ||
         hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&emitted, hipEventDisableTiming) != hipSuccess) {
@@ -138,7 +144,7 @@ struct TextDrain {
     return true;
   }
   ~TextDrain() {
-    if (f) fclose(f);
+    if (f && own_file) fclose(f);
     if (cs) (void)hipStreamDestroy(cs);
     if (emitted) (void)hipEventDestroy(emitted);
     for (void* q : pin) if (q) (void)hipHostFree(q);
@@ -169,8 +175,8 @@ struct Scope {
   std::vector<uint64_t> genome_units;
   uint32_t id_base;
   // plans units [first, first + count) of the scope; SIMMR_* code
-  std::function<int(simmr_range, simmr_plan_info*)> plan;
-  std::function<int(uint32_t, const simmr_reads_out*)> emit;  // columns (host writer only)
+  std::function<int(simmr_engine*, simmr_range, simmr_plan_info*)> plan;
+  std::function<int(simmr_engine*, uint32_t, const simmr_reads_out*)> emit;  // columns (host writer only)
 };
 
 // Generates the scope range by range and appends its FASTQ to args.output.  0, or 1 after die().
@@ -189,7 +195,7 @@ static int run_scope(simmr_engine* eng, const CliArgs& args, const std::vector<G
   for (uint64_t first = 0; first < total_units || (first == 0 && total_units == 0); first += chunk_units) {
     const simmr_range rg{first, std::min<uint64_t>(chunk_units, total_units - first)};
     simmr_plan_info pi{};
-    if (sc.plan(rg, &pi) != SIMMR_OK) return die(simmr_last_error(eng));  // the reference unwrap()s this Err (simulate.rs:137)
+    if (sc.plan(eng, rg, &pi) != SIMMR_OK) return die(simmr_last_error(eng));  // the reference unwrap()s this Err (simulate.rs:137)
     bool written = false;
     if (use_device_text) {
       uint64_t bytes = 0;
@@ -217,7 +223,7 @@ static int run_scope(simmr_engine* eng, const CliArgs& args, const std::vector<G
     if (!written) {  // columns to the host, framed by the restatement of fastq.rs in host.cpp, genome by genome
       DeviceOut d;
       if (!d.init(pi.n_reads, pi.total_bases, pi.slot_bytes)) return die("device allocation failed");
-      if (sc.emit(sc.id_base, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
+      if (sc.emit(eng, sc.id_base, &d.o) != SIMMR_OK) return die(simmr_last_error(eng));
       HostReads h;
       if (!d.to_host(pi.n_reads, pi.total_bases, sc.paired, &h)) return die("copy back failed");
       uint64_t g_first = 0;  // first unit of genome gi in the scope
@@ -235,6 +241,84 @@ static int run_scope(simmr_engine* eng, const CliArgs& args, const std::vector<G
   if (use_device_text && !drain.flush(&err)) fprintf(stderr, "ERROR simmr-hip: Failed to write reads to the output file: %s\n", err.c_str());
   if (n_ranges > 1)
     info((std::to_string(total_units * rpu) + " reads in " + std::to_string(n_ranges) + " device passes, " + std::to_string(text_bytes) + " bytes of FASTQ").c_str());
+  return 0;
+}
+
+// ---- the same over several engines (--devices a,b,...): the whole node behind the reference's one call ------------------
+// The reference's product is one call that writes one FASTQ (main.rs:180-206).  Here the scope's ranges — the same ranges
+// run_scope walks, whose text does not depend on how the run is cut (tests/test_gpu_cli.py) — are dealt to the engines in
+// turn: engine d plans and emits ranges d, d + N, d + 2N, ... on a host thread of its own (one engine per device, or
+// several on one: an ordinal may repeat), and the ranges' text is appended to the file in range order — a thread drains its
+// range when the range before it is on disk, and generates its next one while the other threads drain theirs.  Ids are
+// those of the single-engine run (the library's ids come from the global unit index, simulate.rs:85-89); nothing is
+// exchanged between devices, the run counters are not needed for the files.  0, or 1 after die().
+static int run_scope_devices(const std::vector<simmr_engine*>& engs, const std::vector<int>& ordinals, const CliArgs& args,
+                             const std::vector<Genome>& genomes, const Scope& sc, uint64_t chunk_units) {
+  uint64_t total_units = 0;
+  for (uint64_t u : sc.genome_units) total_units += u;
+  if (total_units == 0) return 0;  // (the reference writes nothing for a scope without a unit)
+  const uint32_t rpu = sc.paired ? 2u : 1u;
+  const size_t N = engs.size();
+  // ranges no larger than a device pass, and at least one per engine
+  if (chunk_units == 0 || chunk_units > total_units) chunk_units = total_units;
+  chunk_units = std::max<uint64_t>(std::min<uint64_t>(chunk_units, (total_units + N - 1) / N), 1);
+  const uint64_t n_ranges = (total_units + chunk_units - 1) / chunk_units;
+  FILE* f = fopen(args.output.c_str(), "ab");
+  if (!f) return die("cannot open " + args.output);
+  std::mutex m;
+  std::condition_variable cv;
+  uint64_t turn = 0;        // the range whose text goes to the file next
+  bool failed = false;
+  std::string first_error;
+  uint64_t text_bytes = 0;
+  auto fail = [&](const std::string& what) {
+    std::lock_guard<std::mutex> lk(m);
+    if (!failed) { failed = true; first_error = what; }
+    cv.notify_all();
+  };
+  auto worker = [&](size_t d) {
+    simmr_engine* eng = engs[d];
+    if (hipSetDevice(ordinals[d]) != hipSuccess) return fail("hipSetDevice failed");
+    NameTables nt(genomes, sc.g0, sc.g1);
+    TextDrain drain;
+    std::string err;
+    if (!drain.open(args.output, &err, f)) return fail(err);
+    for (uint64_t k = d; k < n_ranges; k += N) {
+      { std::lock_guard<std::mutex> lk(m); if (failed) return; }
+      const simmr_range rg{k * chunk_units, std::min<uint64_t>(chunk_units, total_units - k * chunk_units)};
+      simmr_plan_info pi{};
+      if (sc.plan(eng, rg, &pi) != SIMMR_OK) return fail(simmr_last_error(eng));
+      uint64_t bytes = 0;
+      const int rc = simmr_fastq_plan_direct(eng, args.read_header_format.c_str(), &nt.names, sc.id_base, &bytes);
+      if (rc == SIMMR_ENOTSUP) return fail(std::string("--devices writes the text on the devices, and this run's headers need the host writer (") + simmr_last_error(eng) + "): use --device with --host-fastq");
+      if (rc != SIMMR_OK) return fail(simmr_last_error(eng));
+      uint8_t* dst = bytes ? drain.buffer(0, bytes) : nullptr;
+      if (bytes && !dst) return fail("no device memory for " + std::to_string(bytes) + " bytes of FASTQ text: use a smaller --device-chunk-reads");
+      if (bytes && simmr_emit_fastq(eng, dst, bytes) != SIMMR_OK) return fail(simmr_last_error(eng));
+      if (!drain.submit(0, bytes, &err)) return fail(err);  // (the first piece starts its way to the host behind the emit)
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return failed || turn == k; });
+        if (failed) return;
+      }
+      const bool ok = drain.flush(&err);  // this thread owns the file until it passes the turn on
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (!ok && !failed) { failed = true; first_error = "Failed to write reads to the output file: " + err; }
+        text_bytes += bytes;
+        turn = k + 1;
+      }
+      cv.notify_all();
+      if (!ok) return;
+    }
+  };
+  std::vector<std::thread> threads;
+  for (size_t d = 0; d < N; d++) threads.emplace_back(worker, d);
+  for (auto& t : threads) t.join();
+  fclose(f);
+  if (failed) return die(first_error);
+  info((std::to_string(total_units * rpu) + " reads in " + std::to_string(n_ranges) + " device passes on " + std::to_string(N) +
+        " engines, " + std::to_string(text_bytes) + " bytes of FASTQ").c_str());
   return 0;
 }
 
@@ -310,11 +394,19 @@ static int run_main(int argc, char** argv) {
   if (args.error_profile == ErrorProfileKind::CustomLong && !eprofile->is_long_read())
     return die("You specified a custom long-read error profile but the provided error profile is for short reads");
 
-  simmr_engine* eng = nullptr;
-  if (simmr_engine_create(args.device, &eng) != SIMMR_OK) return die(std::string("cannot create engine: ") + simmr_last_error(nullptr));
-  // 16-byte read slots wherever the emit kernel of a plan writes them (include/simmr_hip.h: simmr_reads_out); the columns
-  // only exist on the --host-fastq path (the text path writes no columns), and DeviceOut::to_host reads either layout
-  if (simmr_engine_set_read_slots(eng, SIMMR_SLOT16) != SIMMR_OK) return die(simmr_last_error(eng));
+  // one engine per entry of --devices (an ordinal may repeat: two engines on one device), or the one of --device
+  const std::vector<int> ordinals = args.devices.empty() ? std::vector<int>{args.device} : args.devices;
+  if (ordinals.size() > 1 && args.host_fastq) return die("--devices writes the text on the devices: it does not combine with --host-fastq");
+  std::vector<simmr_engine*> engs;
+  for (int ord : ordinals) {
+    simmr_engine* en = nullptr;
+    if (simmr_engine_create(ord, &en) != SIMMR_OK) return die(std::string("cannot create engine: ") + simmr_last_error(nullptr));
+    // 16-byte read slots wherever the emit kernel of a plan writes them (include/simmr_hip.h: simmr_reads_out); the columns
+    // only exist on the --host-fastq path (the text path writes no columns), and DeviceOut::to_host reads either layout
+    if (simmr_engine_set_read_slots(en, SIMMR_SLOT16) != SIMMR_OK) return die(simmr_last_error(en));
+    engs.push_back(en);
+  }
+  simmr_engine* const eng = engs[0];
 
   info("Loading genomes");
   std::vector<Genome> genomes;
@@ -337,6 +429,12 @@ static int run_main(int argc, char** argv) {
       if (args.genome_file && args.abundance_profile == AbundanceProfileKind::Custom && !rec.abundance)
         return die("You used a custom abundance profile but didn't provide abundances for genome " + g.filepath);
       g.abundance = rec.abundance;
+      // every further engine stages its own copy of the reference (replicated, as across ranks: DESIGN.md section 5)
+      for (size_t k = 1; rc == 0 && k < engs.size(); k++) {
+        Genome again;
+        if (load_genome_device(engs[k], (uint32_t)genomes.size(), rec.filepath, args.contiguous, device_min_size, &again, &err) != 0)
+          return die("Failed to stage " + rec.filepath + " on device " + std::to_string(ordinals[k]) + ": " + err);
+      }
       if (rc == 0) genomes.push_back(std::move(g));
     }
   } else if (args.genome_file) {  // main.rs:38-100
@@ -398,8 +496,9 @@ static int run_main(int argc, char** argv) {
     std::vector<const uint8_t*> ptrs;
     std::vector<uint64_t> lens, sizes;
     for (const Seq& s : g.sequence) { ptrs.push_back((const uint8_t*)s.seq.data()); lens.push_back(s.seq.size()); sizes.push_back(s.size); }
-    if (simmr_stage_genome(eng, (uint32_t)gi, (uint32_t)ptrs.size(), ptrs.data(), lens.data(), sizes.data()) != SIMMR_OK)
-      return die(std::string("staging failed: ") + simmr_last_error(eng));
+    for (simmr_engine* en : engs)
+      if (simmr_stage_genome(en, (uint32_t)gi, (uint32_t)ptrs.size(), ptrs.data(), lens.data(), sizes.data()) != SIMMR_OK)
+        return die(std::string("staging failed: ") + simmr_last_error(en));
   }
 
   // abundances (simulate.rs:121-132 / :334-343)
@@ -428,6 +527,9 @@ static int run_main(int argc, char** argv) {
   const uint64_t seed = args.seed.value_or(0);
 
   const uint64_t chunk_reads = args.device_chunk_reads;
+  auto run = [&](const Scope& sc, uint64_t chunk_units) {
+    return engs.size() > 1 ? run_scope_devices(engs, ordinals, args, genomes, sc, chunk_units) : run_scope(eng, args, genomes, sc, chunk_units);
+  };
   if (!is_long) {
     info("Simulating short reads");
     const uint64_t text_per_pair = 2 * (2 * (uint64_t)args.read_length + 4 + 160);
@@ -447,11 +549,11 @@ static int run_main(int argc, char** argv) {
     if (mrc == SIMMR_OK) {
       Scope sc{true, 0, genomes.size(), {}, 0, nullptr, nullptr};
       for (size_t gi = 0; gi < genomes.size(); gi++) sc.genome_units.push_back(ab[gi].first / 2);  // simulate.rs:179
-      sc.plan = [&](simmr_range rg, simmr_plan_info* pi) {
-        return simmr_pe_plan_multi(eng, (uint32_t)genomes.size(), all_idx.data(), all_reads.data(), &pod, 1, run_seed, rg, pi);
+      sc.plan = [&](simmr_engine* en, simmr_range rg, simmr_plan_info* pi) {
+        return simmr_pe_plan_multi(en, (uint32_t)genomes.size(), all_idx.data(), all_reads.data(), &pod, 1, run_seed, rg, pi);
       };
-      sc.emit = [&](uint32_t idb, const simmr_reads_out* o) { return simmr_pe_emit(eng, idb, o); };
-      if (int rc = run_scope(eng, args, genomes, sc, chunk_units)) return rc;
+      sc.emit = [&](simmr_engine* en, uint32_t idb, const simmr_reads_out* o) { return simmr_pe_emit(en, idb, o); };
+      if (int rc = run(sc, chunk_units)) return rc;
     }
     uint32_t id_base = 0;  // the global AtomicU32 of simulate.rs:85-89
     for (size_t gi = 0; mrc == SIMMR_ENOTSUP && gi < genomes.size(); gi++) {
@@ -463,9 +565,9 @@ static int run_main(int argc, char** argv) {
         g_seed = p0.seed_used;
       }
       Scope sc{true, gi, gi + 1, {ab[gi].first / 2}, id_base, nullptr, nullptr};
-      sc.plan = [&, gi, g_seed](simmr_range rg, simmr_plan_info* pi) { return simmr_pe_plan(eng, (uint32_t)gi, &pod, ab[gi].first, 1, g_seed, rg, pi); };
-      sc.emit = [&](uint32_t idb, const simmr_reads_out* o) { return simmr_pe_emit(eng, idb, o); };
-      if (int rc = run_scope(eng, args, genomes, sc, chunk_units)) return rc;
+      sc.plan = [&, gi, g_seed](simmr_engine* en, simmr_range rg, simmr_plan_info* pi) { return simmr_pe_plan(en, (uint32_t)gi, &pod, ab[gi].first, 1, g_seed, rg, pi); };
+      sc.emit = [&](simmr_engine* en, uint32_t idb, const simmr_reads_out* o) { return simmr_pe_emit(en, idb, o); };
+      if (int rc = run(sc, chunk_units)) return rc;
       id_base += (uint32_t)(ab[gi].first / 2);
     }
   } else {
@@ -483,14 +585,14 @@ static int run_main(int argc, char** argv) {
     // a long read is up to 65 535 bases (u16 lengths); the gamma profiles average 20 000 (minimal_long.rs:64-65)
     const uint64_t chunk_units = chunk_reads ? chunk_reads : auto_chunk_units(2 * 24000 + 260);
     Scope sc{false, 0, genomes.size(), reads, 0, nullptr, nullptr};
-    sc.plan = [&](simmr_range rg, simmr_plan_info* pi) {
+    sc.plan = [&](simmr_engine* en, simmr_range rg, simmr_plan_info* pi) {
       // (without --seed the library selects per-read lengths by itself; the ranges then share the seed drawn above)
       simmr_error_profile p = pod;
       if (!has_seed) p.length_mode = SIMMR_LEN_PER_READ;
-      return simmr_long_plan(eng, (uint32_t)genomes.size(), idx.data(), reads.data(), &p, 1, run_seed, rg, pi);
+      return simmr_long_plan(en, (uint32_t)genomes.size(), idx.data(), reads.data(), &p, 1, run_seed, rg, pi);
     };
-    sc.emit = [&](uint32_t idb, const simmr_reads_out* o) { return simmr_long_emit(eng, idb, o); };
-    if (int rc = run_scope(eng, args, genomes, sc, chunk_units)) return rc;
+    sc.emit = [&](simmr_engine* en, uint32_t idb, const simmr_reads_out* o) { return simmr_long_emit(en, idb, o); };
+    if (int rc = run(sc, chunk_units)) return rc;
   }
   info(("Writing simulated reads to " + args.output).c_str());
 
@@ -499,7 +601,7 @@ static int run_main(int argc, char** argv) {
   for (size_t gi = 0; gi < genomes.size(); gi++) rows.push_back({genomes[gi].uuid, genomes[gi].filepath, ab[gi].first, ab[gi].second});
   info(("Writing simulation metadata to " + meta_path).c_str());
   if (!write_metadata(rows, meta_path, &err)) fprintf(stderr, "ERROR simmr-hip: Failed to write metadata file: %s\n", err.c_str());
-  simmr_engine_destroy(eng);
+  for (simmr_engine* en : engs) simmr_engine_destroy(en);
   return 0;
 }
 

@@ -191,6 +191,7 @@ struct CliArgs {  // cli.rs:93-220, same flags and defaults
   bool contiguous = false;
   // extensions of this implementation (not reference flags)
   int device = 0;
+  std::vector<int> devices;  // --devices a,b,...: one engine per entry (an ordinal may repeat), the run's ranges dealt to them in turn
   bool host_normalize = false;  // --host-normalize: normalise FASTA on the host instead of the device
   bool host_fastq = false;  // --host-fastq: frame the FASTQ on the host instead of the device
   uint64_t device_chunk_reads = 0;  // --device-chunk-reads: reads generated per device pass (0: what fits the free device memory)

@@ -246,6 +246,45 @@ def test_cli_device_chunks_do_not_change_the_output(workdir):
             assert (d / f"chunk_{i}_{c}.fq.tsv").read_text() == (d / f"chunk_ref_{i}.fq.tsv").read_text()
 
 
+def test_cli_several_engines_write_the_single_engine_file(workdir):
+    """--devices a,b,...: the whole node behind the reference's one call (main.rs:180-206) — one engine per entry, the run's
+    ranges dealt to them in turn on host threads, the text appended in range order.  On the one GPU of this box two and three
+    engines on device 0 must write the bytes (and metadata) of the single-engine run: all profiles of the device-text path,
+    one pass per engine and several, and the refusals."""
+    from tests import _model
+    d, _ = workdir
+    (d / "long_model3.bin").write_bytes(_model.synthetic_long_model(kmer_size=6, n_positions=400, seed=8, n_kmers=4 ** 6, lengths=(1500, 6000, 100)))
+    (d / "short_model3.bin").write_bytes(_model.synthetic_short_model())
+    (d / "abund3.tsv").write_text("path\tid\tabundance\n" + f"{d}/g0.fna\tgA\t0.7\n{d}/g1.fna\tgB\t0.3\n")
+    runs = [
+        ["--genome-file", str(d / "genomes.tsv"), "--num-reads", "5001", "--seed", "7", "--error-profile", "perfect-short"],
+        ["--genome-file", str(d / "genomes.tsv"), "--num-reads", "5001", "--seed", "7", "--error-profile", "minimal-short"],
+        ["--genome-file", str(d / "genomes.tsv"), "--num-reads", "5001", "--seed", "7", "--error-profile", "minimal-short", "--rng", "philox-full"],
+        ["--genome-file", str(d / "genomes.tsv"), "--num-reads", "1200", "--seed", "3", "--error-profile", "custom-short",
+         "--custom-profile", str(d / "short_model3.bin")],
+        ["--genome-file", str(d / "genomes.tsv"), "--num-reads", "61", "--seed", "11", "--error-profile", "perfect-long",
+         "--per-read-lengths", "--gamma", "3000,2500"],
+        ["--genome-file", str(d / "abund3.tsv"), "--num-reads", "41", "--seed", "19", "--error-profile", "custom-long",
+         "--custom-profile", str(d / "long_model3.bin"), "--abundance-profile", "custom", "--rng", "philox"],
+    ]
+    for i, argv in enumerate(runs):
+        one = d / f"dev_one_{i}.fq"
+        subprocess.check_call([str(EXE), "--output", str(one), "--device", "0"] + argv)
+        assert one.stat().st_size > 0
+        for devices, chunk in (("0,0", None), ("0,0,0", "334" if i < 4 else "7")):
+            out = d / f"dev_{i}_{devices.count(',')}.fq"
+            extra = ["--device-chunk-reads", chunk] if chunk else []
+            subprocess.check_call([str(EXE), "--output", str(out), "--devices", devices] + extra + argv)
+            assert out.read_bytes() == one.read_bytes(), (argv, devices)
+            assert (d / f"{out.name}.tsv").read_text() == (d / f"{one.name}.tsv").read_text()
+    r = subprocess.run([str(EXE), "--output", str(d / "x.fq"), "--devices", "0,0", "--host-fastq"] + runs[0], capture_output=True)
+    assert r.returncode != 0 and b"--host-fastq" in r.stderr
+    r = subprocess.run([str(EXE), "--output", str(d / "x.fq"), "--devices", "0,99"] + runs[0], capture_output=True)
+    assert r.returncode != 0 and b"cannot create engine" in r.stderr
+    r = subprocess.run([str(EXE), "--output", str(d / "x.fq"), "--devices", "0,,1"] + runs[0], capture_output=True)
+    assert r.returncode == 2
+
+
 def test_cli_a_genome_without_a_pair_is_skipped(workdir, oracle):
     """A scope with zero units — a genome whose abundance share is below one pair, or --num-reads 1 — writes nothing and
     the run goes on to the next genome, as the reference's loop does (simulate.rs:179: num_reads / 2 pairs)."""

@@ -495,6 +495,30 @@ def test_custom_long_bit_exact(engine, oracle, genome_multi, genome_1m, k, seed,
     assert c[_abi.CNT_QUAL_SUM] == ((d["qual"].astype(np.int64) - 33) % 256).sum()
 
 
+def test_custom_long_emit_refuses_a_model_without_its_counter_mode_tables(genome_1m, monkeypatch):
+    """The guard in front of the custom long-read kernels (engine.hip: custom_long_tables_missing): a
+    profile whose device tables for the requested mode are not set must be refused with SIMMR_EINVAL before anything is
+    launched — the first build of the splice's counter mode faulted the GPU on a nil table address (LAB.md, round 5).
+    SIMMR_FAULT_INJECT=null_ctr_tables (read when the engine is made) drops the counter mode's three tables from the
+    profile; the reference mode, whose tables are still there, keeps working on the same engine."""
+    from simmr_amd import CustomShortErrorProfile, SimmrError
+    from simmr_amd.engine import Engine
+    from tests import _model
+    monkeypatch.setenv("SIMMR_FAULT_INJECT", "null_ctr_tables")
+    eng = Engine(0)
+    try:
+        eng.stage_genome(0, genome_1m.contigs)
+        for k in (7, 10):  # the fixed-stride form with its LDS table, and the two-load form
+            blob = _model.synthetic_long_model(kmer_size=k, n_positions=300, seed=42, n_kmers=3000)
+            with pytest.raises(SimmrError) as ei:
+                eng.simulate_long_reads([0], [40], CustomShortErrorProfile(blob, _abi.RNG_PHILOX).pod(), 3)
+            assert ei.value.code == _abi.EINVAL and "kmer_" in str(ei.value) and "nothing was launched" in str(ei.value)
+            reads = eng.simulate_long_reads([0], [40], CustomShortErrorProfile(blob, _abi.RNG_REFERENCE).pod(), 3)
+            assert reads.n_reads == 40
+    finally:
+        eng.close()
+
+
 @RNG_MODES
 @pytest.mark.parametrize("k,max_alts", [(7, 21), (6, 32), (7, 40), (5, 255)])
 def test_custom_long_alternate_lists_of_simmrd_size(engine, oracle, genome_1m, k, max_alts, rng_mode):
