@@ -311,6 +311,12 @@ static uint32_t ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t 
   return T24;
 }
 
+/* the same tables for the test tree (tests/test_oracle_custom.py: the law they encode, enumerated exactly) */
+uint32_t orc_ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t n, uint32_t self_code, int has_self,
+                               uint32_t* thr, uint32_t* alias) {
+  return ctr_splice_tables(alt, w, n, self_code, has_self, thr, alias);
+}
+
 /* `philox` != 0: SIMMR_RNG_PHILOX for a custom long-read model — the walk is the reference's; the alternate of the k-mer
  * visited at position i is drawn from ONE word, X = word i & 3 of the Philox4x32-10 block with key = the read's seed and
  * counter (i >> 2, 2, 'simm', 'r\0\0\3'), through the two levels of ctr_splice_tables.  Tolerance parity: the law of every

@@ -225,4 +225,8 @@ const char* orc_last_error(void);
 #ifdef __cplusplus
 }
 #endif
+/* the counter mode's two-level tables of one k-mer's alternates (custom.c: ctr_splice_tables); returns T24 */
+uint32_t orc_ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t n, uint32_t self_code, int has_self,
+                               uint32_t* thr, uint32_t* alias);
+
 #endif

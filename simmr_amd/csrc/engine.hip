@@ -321,6 +321,13 @@ static void plan_sets_swap(simmr_engine* e) {
   std::swap(e->d_usable, e->s_d_usable); std::swap(e->ph_table, e->s_ph_table);
   e->cur_set ^= 1;
 }
+// INVARIANT the overlap rests on: only the eighteen buffers swapped above exist twice.  The scratch that plan
+// calls and emits share WITHOUT a second copy — scan_tmp, len_hist, the outer-stream scratch o_*, d_scalars, m_contig / m_seed,
+// the FASTQ sizing buffers fq_* and the custom model's tables c_* — is safe only because every user of it ends in a
+// host-side synchronisation of its stream before it returns: every plan call (read_err_word / sync_check), simmr_fastq_plan
+// and simmr_fastq_plan_direct (the size readback), simmr_outer_summarize, and a custom emit (it reads the error word
+// back).  A new user of that scratch that returns without synchronising breaks the overlap silently.
+// tests/test_gpu_shapes.py::test_plan_overlap_gives_the_same_reads runs plan -> fastq_plan_direct -> emit_fastq back to back.
 // One per plan call.  With the overlap on: marks what the caller's stream has been given so far (all of it may read the
 // set in force), takes the other set, lets the plan stream wait for whatever read THAT set when it was given up, and
 // makes the plan stream the engine's stream for the duration of the call; on the way out — whichever way — the caller's
@@ -834,9 +841,12 @@ hipError_t next_emit_events(simmr_engine* e) {
   if (!e->ring_c[i]) {
     if (e->n_emits == 0) { e->ring_c[0] = e->ev_c; e->ring_d[0] = e->ev_d; }
     else {
-      hipError_t s = hipEventCreate(&e->ring_c[i]);
+      // both events exist before either is published: a slot never holds a start event without its end event
+      hipEvent_t c = nullptr, d = nullptr;
+      hipError_t s = hipEventCreate(&c);
       if (s != hipSuccess) return s;
-      if ((s = hipEventCreate(&e->ring_d[i])) != hipSuccess) return s;
+      if ((s = hipEventCreate(&d)) != hipSuccess) { (void)hipEventDestroy(c); return s; }
+      e->ring_c[i] = c; e->ring_d[i] = d;
     }
   }
   e->ev_c = e->ring_c[i]; e->ev_d = e->ring_d[i];
@@ -2395,14 +2405,19 @@ int simmr_emit_kernel_ms_mean(simmr_engine* e, uint32_t last_n, float* ms) {
   const uint64_t have = std::min<uint64_t>(e->n_emits, (uint64_t)simmr_engine::EMIT_RING);
   const uint64_t n = std::min<uint64_t>(last_n, have);
   if (n == 0) return e->fail(SIMMR_ESTATE, "no emit yet");
+  // (an emit that failed between taking its slot and recording its end event leaves a pair that cannot be read: such a
+  // slot is skipped, not an error of this call)
   double sum = 0.0;
+  uint64_t got = 0;
   for (uint64_t k = 0; k < n; k++) {
     const int i = (int)((e->n_emits - 1 - k) % simmr_engine::EMIT_RING);
     float t = 0.f;
-    HIP_TRY(e, hipEventElapsedTime(&t, e->ring_c[i], e->ring_d[i]));
+    if (!e->ring_c[i] || !e->ring_d[i] || hipEventElapsedTime(&t, e->ring_c[i], e->ring_d[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
     sum += t;
+    got++;
   }
-  *ms = (float)(sum / (double)n);
+  if (got == 0) return e->fail(SIMMR_ESTATE, "no completed emit among the last %llu", (unsigned long long)n);
+  *ms = (float)(sum / (double)got);
   return SIMMR_OK;
 }
 

@@ -2139,7 +2139,7 @@ k_emit_philox(ProfileDev prof, uint32_t paired, const GenomeDev* __restrict__ ge
           if (o.flags) COL_STORE(&o.flags[rd], (paired && !rev) ? (uint8_t)0 : (uint8_t)fl);
         }
         if (!rev) {
-          p_bases32 += paired ? 2u * L : L;  // (L <= 65535)
+          p_bases32 += paired ? 2u * L : L;  // (a pair's reads are u16 lengths; a long read can be longer: the sum moves to LDS at 2^31 either way)
           if (p_bases32 >= 0x80000000u) { atomicAdd(&spill_bases, (unsigned long long)p_bases32); p_bases32 = 0u; }
         }
         s_redrawn += (uint32_t)__builtin_popcountll(__ballot(!rev && (fl & SIMMR_FLAG_REDRAWN)));
@@ -2819,13 +2819,23 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
         const uint32_t n_s = __shfl(n, (int)src, 64);
         if (n_s <= b_fill) continue;  // wave-uniform
         const uint64_t off_s = __shfl(off, (int)src, 64), fill_s = __shfl(fill, (int)src, 64);
-        for (uint32_t p = b_fill + lane * 16u; p < n_s; p += 1024u) {
-          uint8_t* qd = qual + off_s + p;
-          if (p + 16u <= n_s) {
-            *reinterpret_cast<u64_unaligned*>(qd) = fill_s;
-            *reinterpret_cast<u64_unaligned*>(qd + 8) = fill_s;
-          } else {
-            store_tail(qd, fill_s, fill_s, n_s - p);
+        // The constant rest of a read is most of what this kernel writes (20 GB per million reads of 20 kb: the kernel is
+        // bound by these stores, not by the modelled positions — both rewrites of the sampling loop that round 5 tried left
+        // it slower, profiles/r5/ab_custom_qual_*.log).  Lanes own ALIGNED 16-byte chunks of device memory, lane l the
+        // chunk l of every kilobyte from the line the run starts in: a wave's store instruction is sixteen whole 64-byte
+        // lines (nontemporal: nobody reads them on the device), and only the run's first and last chunk are written bytewise.
+        uint8_t* const run_a = qual + off_s + b_fill;                      // first byte of the run
+        uint8_t* const run_b = qual + off_s + n_s;                         // one past its last
+        uint8_t* const line0 = (uint8_t*)((uintptr_t)run_a & ~(uintptr_t)63);
+        for (uint8_t* q16 = line0 + 16u * lane; q16 < run_b; q16 += 1024u) {
+          if (q16 >= run_a && q16 + 16 <= run_b) {
+            v4u32 v;
+            v.x = (uint32_t)fill_s; v.y = v.x; v.z = v.x; v.w = v.x;
+            stream_store(reinterpret_cast<v4u32*>(q16), v);
+          } else if (q16 + 16 > run_a) {
+            uint8_t* lo = q16 < run_a ? run_a : q16;
+            uint8_t* hi = q16 + 16 < run_b ? q16 + 16 : run_b;
+            for (uint8_t* b = lo; b < hi; b++) *b = (uint8_t)fill_s;
           }
         }
       }

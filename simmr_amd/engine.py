@@ -149,7 +149,11 @@ class Engine:
         self._check(self.lib.simmr_engine_set_stream(self._h, C.c_void_p(s.cuda_stream)))
 
     def set_read_slots(self, slot_bytes: int):
-        """Layout of the reads that plans made from now on emit: 0 compact, 16 = SIMMR_SLOT16 (simmr_engine_set_read_slots)."""
+        """Layout of the reads that plans made from now on emit: 0 compact, 16 = SIMMR_SLOT16 (simmr_engine_set_read_slots).
+        The setting is the ENGINE's and it sticks: simmr_amd.simulate's entry points select SIMMR_SLOT16 and leave it
+        selected, so direct pe_plan / long_plan calls made on the same engine afterwards also get the slot layout, in which
+        seq_off[r + 1] - seq_off[r] is not read r's length (PlanInfo.slot_bytes / Reads.slot_bytes say which layout a plan
+        emits; the C ABI's own default is compact)."""
         self._check(self.lib.simmr_engine_set_read_slots(self._h, int(slot_bytes)))
 
     def set_plan_overlap(self, on: bool):

@@ -564,6 +564,12 @@ static char* dup_str(const std::string& s) {
   return p;
 }
 void simmr_host_free(void* p) { free(p); }
+// the PRODUCT's builder of the counter mode's splice tables (csrc/custom_model.hpp: what engine.hip uploads), for the CPU
+// test that enumerates the law the tables encode (the test tree's custom-profile specification tests)
+uint32_t simmr_host_ctr_splice_tables(const uint32_t* alt, const float* w, uint32_t n, uint32_t self_code, int has_self,
+                                      uint32_t* thr, uint32_t* alias) {
+  return simmr::ctr_splice_tables(alt, w, n, self_code, has_self != 0, thr, alias);
+}
 char* simmr_host_normalize(const char* raw, uint64_t n) { return dup_str(normalize(std::string(raw, n))); }
 char* simmr_host_format_f64(double v) { return dup_str(format_f64_display(v)); }
 char* simmr_host_format_header(const char* fmt, const char* genome_id, uint32_t read_id, const char* seq_id,

@@ -37,7 +37,8 @@ class GenomeRef:
 
 
 def _prefer_layout(backend, read_slots: int) -> None:
-    """simmr_engine_set_read_slots: the layout of the plans the entry points below are about to make"""
+    """simmr_engine_set_read_slots: the layout of the plans the entry points below are about to make.  The setting stays on
+    the engine after they return (Engine.set_read_slots says what that means for direct plan calls)."""
     if hasattr(backend, "set_read_slots"):
         backend.set_read_slots(read_slots)
 

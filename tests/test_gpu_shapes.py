@@ -447,7 +447,20 @@ def test_plan_overlap_gives_the_same_reads(oracle):
                 o = _oracle.simulate_long(oracle, [g0, g1], [150, 90], p, 3, first=f, count=60, qual_offset=33).trimmed()
                 d = runs[i].to_host(); i += 1
                 assert np.array_equal(d["seq"], o["seq"]) and np.array_equal(d["qual"], o["qual"]), (f,)
+        # plan -> fastq_plan_direct -> emit_fastq back to back (the FASTQ sizing buffers exist once; every user
+        # of them synchronises before it returns, engine.hip: "INVARIANT the overlap rests on")
+        from tests.test_gpu_cli import FMT
+        names = [(0, "genome-zero", ["c0", "c1 with words", "c2"])]
+        texts = []
+        for k in range(6):
+            eng.pe_plan(0, prof, reads, seed, 2500 * k, 2500)
+            texts.append(eng.fastq_direct(FMT, names, 7))
+        torch.cuda.synchronize()
         eng.set_plan_overlap(False)
+        for k in range(6):
+            eng.pe_plan(0, prof, reads, seed, 2500 * k, 2500)
+            want = eng.fastq_direct(FMT, names, 7).cpu().numpy().tobytes()
+            assert texts[k].cpu().numpy().tobytes() == want, k
         d = eng.simulate_pe_reads_from_genome(1, prof2, 6000, 9, qual_offset=33).to_host()
         assert np.array_equal(d["seq"], ob["seq"])
     finally:

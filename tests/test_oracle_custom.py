@@ -191,3 +191,80 @@ def test_counter_mode_splice_specification(oracle):
     part = _oracle.simulate_long(oracle, [g], [120], ctr_pod, 9, first=37, count=40).trimmed()
     lo, hi = int(rb["seq_off"][37]), int(rb["seq_off"][77])
     assert np.array_equal(part["seq"], rb["seq"][lo:hi]) and np.array_equal(part["qual"], rb["qual"][lo:hi])
+
+
+def _splice_law_from_tables(T24, thr, alias, alt, n):
+    """P(alternate code) that the counter mode's two-level draw of one k-mer ENCODES, exactly (a count of the 2^32 words X):
+    level 1, X >> 8 < T24 -> self; level 2, Z = (X - (T24 << 8)) << (24 - e) over the remaining 2^(e + 8) words,
+    column c = (Z n) >> 32, ((Z n) & 0xffffffff) >> 8 < thr[c] ? alternate c : alternate alias[c]
+    (include/simmr_hip.h; Z = t * 2^(24 - e), t = 0 .. 2^(e + 8) - 1: the t of a column and of its lower part are ranges)."""
+    rest = (1 << 24) - T24          # 2^e level-1 values go to level 2
+    e = rest.bit_length() - 1
+    assert rest == 1 << e and 1 <= e <= 24
+    S = 1 << (24 - e)
+    K = 1 << (e + 8)
+    ceil_div = lambda a, b: -(-a // b)
+    counts = {}
+    for c in range(n):
+        lo = ceil_div(c << 32, S * n)
+        mid = min(ceil_div((c << 32) + (int(thr[c]) << 8), S * n), ceil_div((c + 1) << 32, S * n))
+        hi = min(ceil_div((c + 1) << 32, S * n), K)
+        lo, mid = min(lo, K), min(mid, K)
+        counts[int(alt[c])] = counts.get(int(alt[c]), 0) + max(mid - lo, 0)
+        counts[int(alt[int(alias[c])])] = counts.get(int(alt[int(alias[c])]), 0) + max(hi - mid, 0)
+    assert sum(counts.values()) == K
+    return counts
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_counter_mode_splice_tables_encode_the_reference_law(oracle, which):
+    """The table builder is the one piece the product and the CPU specification share line for line, so a bit-for-bit
+    comparison of their outputs cannot find an error in it.  Here the law the tables encode is counted exactly
+    over the 2^32 words of a draw and compared with the reference's law P(alternate j) = w_j / sum(w)
+    (custom_short.rs:497-503) for random lists — dominant self, no self, self listed twice, zero weights, one entry, forty —
+    for the oracle's builder (oracle/custom.c) and for the product's (csrc/custom_model.hpp through libsimmr_host.so)."""
+    if which == "oracle":
+        fn = oracle.orc_ctr_splice_tables
+    else:
+        import os
+        from pathlib import Path
+        host = C.CDLL(os.environ.get("SIMMR_HOST_LIB") or str(Path(__file__).resolve().parent.parent / "simmr_amd" / "host" / "libsimmr_host.so"))
+        fn = host.simmr_host_ctr_splice_tables
+    fn.restype = C.c_uint32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(2025)
+    worst = 0.0
+    for trial in range(400):
+        n = int(rng.choice([1, 2, 3, 4, 6, 9, 20, 40]))
+        self_code = 1000
+        alt = rng.choice(np.arange(1, 900), size=n, replace=False).astype(np.uint32)
+        w = rng.uniform(0.0, 3.0, n).astype(np.float32)
+        w[rng.random(n) < 0.15] = 0.0
+        shape = trial % 5
+        if shape != 1 and n >= 1:          # a self entry (shape 1: none at all)
+            alt[0] = self_code
+            w[0] = np.float32(rng.choice([0.2, 5.0, 50.0, 5000.0]))
+        if shape == 2 and n >= 3:          # self listed twice
+            alt[2] = self_code
+            w[2] = np.float32(1.0)
+        if shape == 3:                     # nearly all weight on self: level 2 is the smallest power of two
+            w[1:] *= np.float32(1e-5)
+        if w.sum() == 0:
+            w[-1] = np.float32(1.0)
+        has_self = 0 if trial % 11 == 0 else 1   # a k-mer with an N has no "self", whatever its list says
+        thr = np.zeros(n, np.uint32)
+        alias = np.zeros(n, np.uint32)
+        T24 = fn(alt.ctypes.data, w.ctypes.data, n, self_code, has_self, thr.ctypes.data, alias.ctypes.data)
+        assert 0 <= T24 < 1 << 24 and (alias < n).all() and (thr <= 1 << 24).all()
+        counts = _splice_law_from_tables(int(T24), thr, alias, alt, n)
+        if T24:
+            assert has_self and self_code in alt
+            counts[self_code] = counts.get(self_code, 0) + (int(T24) << 8)
+        W = float(w.astype(np.float64).sum())
+        for code in set(int(a) for a in alt):
+            want = float(w[alt == code].astype(np.float64).sum()) / W
+            got = counts.get(code, 0) / 2.0 ** 32
+            worst = max(worst, abs(got - want))
+            assert abs(got - want) <= (n + 1) * 2.0 ** -23, (trial, n, code, got, want, T24)
+        assert sum(counts.values()) == 1 << 32
+    assert worst > 0.0  # (the tables are integer: some rounding must show)
