@@ -409,7 +409,7 @@ def main():
     text_alg_bytes = plane_bytes + int(fq["bytes"])
     if through is not None and through["emit_kernel_ms"] > 0:
         a = text_alg_bytes / (through["emit_kernel_ms"] * 1e-3) / 1e9
-        through["roofline"] = {"bound": "hbm", "kernel": "k_emit_philox<TEXT>" if args.profile != "perfect-short" else "k_emit_philox<COPY_ONLY, TEXT>",
+        through["roofline"] = {"bound": "hbm", "kernel": text_kernel_label(args),
                                "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
                                "traffic": measured_traffic(args, 2 * pairs_per_gpu, text=True),
                                "alg_bytes_per_launch": text_alg_bytes, "kernel_ms": through["emit_kernel_ms"],
@@ -490,7 +490,7 @@ def main():
                             if args.rng == "reference" else
                             "VALU issue (integer RNG and table lookups) next to the issue of the store instructions and the "
                             "HBM write path behind them: see `valu` and DESIGN.md section 4"),
-                "kernel": (("k_emit_philox<COPY_ONLY, TEXT>" if args.profile == "perfect-short" else "k_emit_philox<TEXT>") if args.through_fastq else
+                "kernel": (text_kernel_label(args) if args.through_fastq else
                            "k_emit_perfect_pe" if args.profile == "perfect-short" else
                            "k_emit_custom_pe" if args.profile == "custom-short" else
                            "k_custom_long_qual + k_custom_long_splice" + ("<CTR>" if args.rng == "philox" else "") if custom is not None else
@@ -539,10 +539,19 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-PMC_RECORD = ROOT / "profiles" / "r4" / "pmc_traffic.json"
+def text_kernel_label(args):
+    """which kernel simmr_emit_fastq runs for this command: the item form, or (SIMMR_TEXT_FORM=2, read by the engine when it
+    is made) the whole-line form of simmr_amd/csrc/text_lines.hip for paired plans of short reads"""
+    if os.environ.get("SIMMR_TEXT_FORM") == "2" and args.profile in ("minimal-short", "perfect-short"):
+        return "k_emit_text_lines<COPY_ONLY>" if args.profile == "perfect-short" else "k_emit_text_lines"
+    return "k_emit_philox<COPY_ONLY, TEXT>" if args.profile == "perfect-short" else "k_emit_philox<TEXT>"
+
+
+PMC_RECORD = ROOT / "profiles" / "r5" / "pmc_traffic.json"
 # everything the counters of a launch depend on: the kernels, and the launch geometry and kernel selection in engine.hip
 KERNEL_SOURCES = ("simmr_amd/csrc/kernels.hip", "simmr_amd/csrc/rng_device.hpp", "simmr_amd/csrc/device_types.hpp",
-                  "simmr_amd/csrc/fastq_format.hpp", "simmr_amd/csrc/fastq_kernels.hip", "simmr_amd/csrc/engine.hip")
+                  "simmr_amd/csrc/fastq_format.hpp", "simmr_amd/csrc/fastq_kernels.hip", "simmr_amd/csrc/text_lines.hip",
+                  "simmr_amd/csrc/engine.hip")
 
 
 def kernel_source_hash():
@@ -556,7 +565,7 @@ def kernel_source_hash():
 
 
 def _profile_record(args, reads_per_gpu, text=False):
-    """(record, why_not): the committed rocprofv3 PMC record of this very command (profiles/r3/pmc_traffic.json: one
+    """(record, why_not): the committed rocprofv3 PMC record of this very command (profiles/r5/pmc_traffic.json: one
     counter set per run, no tracing) — only for the workload it was measured on and only if the kernel sources still
     hash to what they were when it was collected."""
     try:

@@ -981,7 +981,8 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
   simmr_engine* e = new simmr_engine();
   e->device = device_ordinal;
   e->n_cu = prop.multiProcessorCount;
-  // Four measurement knobs, read once here (the defaults are what the sweeps of LAB.md found).
+  // Four measurement knobs (grid multiples, workgroups per CU, the splice variant) + SIMMR_TEXT_FORM (which kernel writes the
+  // FASTQ text: same-box A/B) + SIMMR_FAULT_INJECT (test switch), read once here; the defaults are what the sweeps of LAB.md found.
   if (const char* v = getenv("SIMMR_GRID_MULT"))
     e->lanes_mult = e->perfect_mult = e->custom_pe_mult = e->custom_long_mult = e->fastq_mult =
         (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));

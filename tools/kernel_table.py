@@ -4,6 +4,7 @@ copied by hand (hand-copied figures had drifted from 
 
     python3 tools/kernel_table.py r5            # markdown table on stdout
     python3 tools/kernel_table.py r5 --check    # also verifies that DESIGN.md / profiles/README.md quote it verbatim
+    python3 tools/kernel_table.py r5 --update   # rewrites the quoted table in both documents
 
 For every bench command of the round (profiles/<round>/kernel_stats_bench_<cmd>.csv = the rocprofv3 --kernel-trace --stats
 summary of that command, profiles/<round>/bench_<cmd>_under_rocprof.json = the JSON line the same run printed) it lists
@@ -84,6 +85,12 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r5"
     t = table(tag)
     print(t)
+    if "--update" in sys.argv:  # rewrite the block between the markers in both documents
+        for rel in ("DESIGN.md", "profiles/README.md"):
+            f = ROOT / rel
+            txt = f.read_text()
+            a, b = txt.index(f"<!-- tools/kernel_table.py {tag}:"), txt.index(f"<!-- end of tools/kernel_table.py {tag} -->")
+            f.write_text(txt[:a] + t + txt[b + len(f"<!-- end of tools/kernel_table.py {tag} -->"):])
     if "--check" in sys.argv:
         bad = [p for p in ("DESIGN.md", "profiles/README.md") if t not in (ROOT / p).read_text()]
         if bad:

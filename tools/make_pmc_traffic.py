@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""profiles/r4/pmc_traffic.json from the PMC summaries of tools/profile_round.sh, stamped with the hash of the kernel
+"""profiles/<round>/pmc_traffic.json from the PMC summaries of tools/profile_round.sh, stamped with the hash of the kernel
 sources it was collected from (bench.py reports its numbers only while that hash still matches).
 
 usage: tools/make_pmc_traffic.py <dir with pmc_default.txt [pmc_compact.txt pmc_perfect.txt pmc_custom_long.txt]>
-       [--mix plain,vop3_sdwa,mad_u64] [--mix-slot plain,vop3_sdwa,mad_u64]
+       [--mix plain,vop3_sdwa,mad_u64] [--mix-slot plain,vop3_sdwa,mad_u64] [--round r5] [--splice-bases N]
+--splice-bases: bases the custom-long bench's splice launch wrote (the command's stream bytes / 2): the record of the
+counter-mode splice then carries its write amplification on its own, WRITE_SIZE / bases
 (pmc_default.txt = the default command, i.e. the 16-byte read slots; pmc_compact.txt = the same with --layout compact)"""
 import json
 import sys
@@ -59,7 +61,15 @@ def main():
                                                  "(tools/profile_round.sh), per launch")
             if key in mixes:
                 out[key]["valu_class_mix"] = mixes[key]
-    dst = ROOT / "profiles" / "r4" / "pmc_traffic.json"
+    if "--splice-bases" in sys.argv:
+        bases = float(sys.argv[sys.argv.index("--splice-bases") + 1])
+        for key in ("k_custom_long_splice_ctr", "k_custom_long_splice"):
+            if key in out and "WRITE_SIZE_KB" in out[key] and bases > 0:
+                out[key]["bases_written"] = bases
+                out[key]["write_bytes_per_base"] = out[key]["WRITE_SIZE_KB"] * 1024.0 / bases  # (1.0 = every base stored once)
+                out[key]["fetch_bytes_per_base"] = out[key]["FETCH_SIZE_KB"] * 1024.0 / bases
+    tag = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r5"
+    dst = ROOT / "profiles" / tag / "pmc_traffic.json"
     dst.parent.mkdir(parents=True, exist_ok=True)
     dst.write_text(json.dumps(out, indent=1) + "\n")
     print(dst, out["source_sha256"][:12])
