@@ -1698,8 +1698,9 @@ static int emit_common(simmr_engine* e, uint32_t read_id_base, const simmr_reads
         // with smaller tables 256-lane workgroups do
         auto kern = fast ? (exc ? k_custom_long_splice<true, true, true> : k_custom_long_splice<false, true, true>)
                          : (exc ? k_custom_long_splice<true, false, true> : k_custom_long_splice<false, false, true>);
-        const uint32_t lds = fast ? splice_ctr_lds_bytes(e->prof.custom.kmer_size) : 0u;
-        const uint32_t lanes = lds > 16384u ? SPLICE_CTR_LANES_MAX : 256u;
+        const uint32_t tab = fast ? splice_ctr_lds_bytes(e->prof.custom.kmer_size) : 0u;
+        const uint32_t lanes = tab > 16384u ? SPLICE_CTR_LANES_MAX : 256u;
+        const uint32_t lds = fast ? tab + 16u * lanes : 0u;  // the k-mer table + 16 bytes per lane (an even group waiting for its odd neighbour's store)
         if (lds > 32768u && lds > e->splice_ctr_lds_set[exc ? 1 : 0]) {  // (64 KB of table + the kernel's static LDS: over the default limit)
           HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           e->splice_ctr_lds_set[exc ? 1 : 0] = lds;

@@ -2867,7 +2867,7 @@ k_custom_long_qual(ProfileDev prof, uint64_t n_units, const uint32_t* __restrict
 // position to take back; the LDS holds T24 << 8 | count per k-mer (4^k words).
 constexpr uint32_t SPLICE_FAST_LANES = 1024u;
 __host__ __device__ inline uint32_t splice_fast_lds_bytes(uint32_t k) { return 32u * SPLICE_FAST_LANES * 4u + 256u * 4u + (1u << (2u * k)); }
-__host__ __device__ inline uint32_t splice_ctr_lds_bytes(uint32_t k) { return 4u << (2u * k); }
+__host__ __device__ inline uint32_t splice_ctr_lds_bytes(uint32_t k) { return 4u << (2u * k); }  // (+ 16 bytes per lane: the store stash, engine.hip)
 #if !defined(SPLICE_CTR_LANES)
 #define SPLICE_CTR_LANES 768
 #endif
@@ -3231,6 +3231,22 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
         }
         if (i0 < n) {
           const uint64_t lo = (uint64_t)out[0] | ((uint64_t)out[1] << 32), hi = (uint64_t)out[2] | ((uint64_t)out[3] << 32);
+#if !defined(SIMMR_SPLICE_NO_PAIRS)
+          if (CTR && FAST) {
+            // Two groups per store (round 5): a lane's 16-byte store at any byte address dirties 1.5 32-byte sectors on
+            // average, and they went to memory before the lane's next store reached them — 2.96 bytes written per base
+            // (profiles/r5/pmc_traffic.json).  An even group now waits in the lane's 16 bytes of LDS (behind the k-mer table)
+            // and goes out together with its odd neighbour: 32 contiguous bytes, two sectors.
+            uint4* const stash = reinterpret_cast<uint4*>(splice_lds + (1u << (2u * K))) + threadIdx.x;
+            const bool odd = ((i0 >> 4) & 1u) != 0u, full = i0 + 16u <= n;
+            if (!odd && i0 + 16u < n) {  // a full group with a group behind it
+              *stash = make_uint4(out[0], out[1], out[2], out[3]);
+            } else {
+              if (odd) { const uint4 pv = *stash; store16(sd + i0 - 16u, (uint64_t)pv.x | ((uint64_t)pv.y << 32), (uint64_t)pv.z | ((uint64_t)pv.w << 32)); }
+              if (full) store16(sd + i0, lo, hi); else store_tail(sd + i0, lo, hi, n - i0);
+            }
+          } else
+#endif
           if (i0 + 16u <= n) {
 #if defined(SIMMR_SPLICE_NT)
             __builtin_nontemporal_store(lo, reinterpret_cast<u64_unaligned*>(sd + i0));
