@@ -2975,6 +2975,7 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
 #endif
       constexpr uint32_t SW = !FAST ? 1u : (CTR ? (uint32_t)SPLICE_CTR_SRC_WORDS : 16u);
       uint32_t sw[SW];
+      uint4 held = make_uint4(0u, 0u, 0u, 0u);  // (reference mode, FAST: an even group waiting for its odd neighbour's store)
       for (uint32_t i0 = 0; __any(i0 < n); i0 += 16u) {
         // the 16 source bases that enter the window during this group: positions i0 + K .. i0 + K + 15
         // (at most K + 31 bases past the read, K + 271 with the 256-base chunks: inside the plane's back padding)
@@ -3232,17 +3233,23 @@ k_custom_long_splice(ProfileDev prof, const GenomeDev* __restrict__ genomes, uin
         if (i0 < n) {
           const uint64_t lo = (uint64_t)out[0] | ((uint64_t)out[1] << 32), hi = (uint64_t)out[2] | ((uint64_t)out[3] << 32);
 #if !defined(SIMMR_SPLICE_NO_PAIRS)
-          if (CTR && FAST) {
+          if (FAST && (CTR || !HAS_EXC)) {  // (the reference mode's form for genomes with N runs has no register left: 126 of 128)
             // Two groups per store (round 5): a lane's 16-byte store at any byte address dirties 1.5 32-byte sectors on
             // average, and they went to memory before the lane's next store reached them — 2.96 bytes written per base
             // (profiles/r5/pmc_traffic.json).  An even group now waits in the lane's 16 bytes of LDS (behind the k-mer table)
-            // and goes out together with its odd neighbour: 32 contiguous bytes, two sectors.
+            // and goes out together with its odd neighbour: 32 contiguous bytes, two sectors.  (The reference mode's form has
+            // no LDS left — its word rows take 128 KB — but registers to spare at four waves per SIMD: the group waits there.)
             uint4* const stash = reinterpret_cast<uint4*>(splice_lds + (1u << (2u * K))) + threadIdx.x;
             const bool odd = ((i0 >> 4) & 1u) != 0u, full = i0 + 16u <= n;
             if (!odd && i0 + 16u < n) {  // a full group with a group behind it
-              *stash = make_uint4(out[0], out[1], out[2], out[3]);
+              if (CTR) *stash = make_uint4(out[0], out[1], out[2], out[3]);
+              else held = make_uint4(out[0], out[1], out[2], out[3]);
             } else {
-              if (odd) { const uint4 pv = *stash; store16(sd + i0 - 16u, (uint64_t)pv.x | ((uint64_t)pv.y << 32), (uint64_t)pv.z | ((uint64_t)pv.w << 32)); }
+              if (odd) {
+                uint4 pv = held;
+                if (CTR) pv = *stash;
+                store16(sd + i0 - 16u, (uint64_t)pv.x | ((uint64_t)pv.y << 32), (uint64_t)pv.z | ((uint64_t)pv.w << 32));
+              }
               if (full) store16(sd + i0, lo, hi); else store_tail(sd + i0, lo, hi, n - i0);
             }
           } else
