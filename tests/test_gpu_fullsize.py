@@ -325,3 +325,44 @@ def test_c2_full_size_slot16_is_the_compact_run(big):
     for (a, b), (ws, wq) in zip(wins, want):
         assert bool((window_bytes(slot.seq, first, L, a, b) == ws).all())
         assert bool((window_bytes(slot.qual, place[:n], L, a, b) == wq).all())
+
+
+def test_whole_line_text_is_the_item_form_text_at_full_size(big):
+    """BASELINE configs[1] at full size through both forms of the text kernel (simmr_emit_fastq: the item form, the library's
+    default, and the whole-line form of text_lines.hip, SIMMR_TEXT_FORM=2): 41 GB of FASTQ text each, compared on the device
+    byte for byte, with the run counters; and the text's own structure — every fourth line a '+', header lines start with '@'
+    — through position-independent counts."""
+    import os
+    import torch
+    from simmr_amd.engine import Engine
+    from tests.test_gpu_cli import FMT
+    names = [(5, "0b5e3c9e-7d1c-4c1a-9c55-2f7d3a1b6e42", ["synthetic_100Mbp"])]
+    prof = MinimalShortErrorProfile(rng_mode=_abi.RNG_PHILOX_FULL).pod()
+    texts, counters = [], []
+    for form in ("1", "2"):
+        old = os.environ.get("SIMMR_TEXT_FORM")
+        os.environ["SIMMR_TEXT_FORM"] = form
+        try:
+            eng = Engine(0)
+        finally:
+            if old is None:
+                del os.environ["SIMMR_TEXT_FORM"]
+            else:
+                os.environ["SIMMR_TEXT_FORM"] = old
+        try:
+            eng.stage_synthetic(5, [GENOME], 2)
+            eng.counters_reset()
+            eng.pe_plan(5, prof, N_READS, 42)
+            texts.append(eng.fastq_direct(FMT, names, 0))
+            counters.append(eng.counters())
+        finally:
+            eng.close()
+    a, b = texts
+    assert a.numel() == b.numel() > 40_000_000_000
+    step = 1 << 30
+    for lo in range(0, a.numel(), step):
+        assert torch.equal(a[lo:lo + step], b[lo:lo + step]), f"first difference in bytes [{lo}, {lo + step})"
+    assert np.array_equal(counters[0], counters[1]) and counters[0][_abi.CNT_READS] == N_READS
+    # structure: 4 lines per record; one '@' line start and one "\n+\n" per record at least (quality bytes may also be '@' or '+')
+    n_nl = sum(int((b[lo:lo + step] == 10).sum()) for lo in range(0, b.numel(), step))
+    assert n_nl == 4 * N_READS and int(b[0]) == ord("@") and int(b[-1]) == 10
