@@ -248,12 +248,15 @@ static int run_scope(simmr_engine* eng, const CliArgs& args, const std::vector<G
 // The reference's product is one call that writes one FASTQ (main.rs:180-206).  Here the scope's ranges — the same ranges
 // run_scope walks, whose text does not depend on how the run is cut (tests/test_gpu_cli.py) — are dealt to the engines in
 // turn: engine d plans and emits ranges d, d + N, d + 2N, ... on a host thread of its own (one engine per device, or
-// several on one: an ordinal may repeat), and the ranges' text is appended to the file in range order — a thread drains its
-// range when the range before it is on disk, and generates its next one while the other threads drain theirs.  Ids are
+// several on one: an ordinal may repeat), copies each range's text to pinned host memory over ITS device's link as soon as
+// it is emitted — the devices' copies run side by side; a drain that waited for its turn would put the whole node behind one
+// PCIe link — and appends it to the file when the range before it is on disk.  Ranges are at most MAX_RANGE_TEXT bytes of
+// text (a range waits in host memory for its turn).  Ids are
 // those of the single-engine run (the library's ids come from the global unit index, simulate.rs:85-89); nothing is
 // exchanged between devices, the run counters are not needed for the files.  0, or 1 after die().
 static int run_scope_devices(const std::vector<simmr_engine*>& engs, const std::vector<int>& ordinals, const CliArgs& args,
-                             const std::vector<Genome>& genomes, const Scope& sc, uint64_t chunk_units) {
+                             const std::vector<Genome>& genomes, const Scope& sc, uint64_t chunk_units, uint64_t text_bytes_per_unit) {
+  constexpr uint64_t MAX_RANGE_TEXT = 1ull << 30;  // (pinned host memory per engine; allocating it costs ~0.25 s per GB, once)
   uint64_t total_units = 0;
   for (uint64_t u : sc.genome_units) total_units += u;
   if (total_units == 0) return 0;  // (the reference writes nothing for a scope without a unit)
@@ -262,6 +265,7 @@ static int run_scope_devices(const std::vector<simmr_engine*>& engs, const std::
   // ranges no larger than a device pass, and at least one per engine
   if (chunk_units == 0 || chunk_units > total_units) chunk_units = total_units;
   chunk_units = std::max<uint64_t>(std::min<uint64_t>(chunk_units, (total_units + N - 1) / N), 1);
+  chunk_units = std::max<uint64_t>(std::min<uint64_t>(chunk_units, MAX_RANGE_TEXT / std::max<uint64_t>(text_bytes_per_unit, 1)), 1);
   const uint64_t n_ranges = (total_units + chunk_units - 1) / chunk_units;
   FILE* f = fopen(args.output.c_str(), "ab");
   if (!f) return die("cannot open " + args.output);
@@ -280,9 +284,12 @@ static int run_scope_devices(const std::vector<simmr_engine*>& engs, const std::
     simmr_engine* eng = engs[d];
     if (hipSetDevice(ordinals[d]) != hipSuccess) return fail("hipSetDevice failed");
     NameTables nt(genomes, sc.g0, sc.g1);
-    TextDrain drain;
-    std::string err;
-    if (!drain.open(args.output, &err, f)) return fail(err);
+    // this engine's text buffers: one on the device, one pinned on the host (both grow to the largest range), a copy stream
+    struct Bufs {
+      void* dev = nullptr; void* host = nullptr; uint64_t dev_cap = 0, host_cap = 0; hipStream_t cs = nullptr;
+      ~Bufs() { if (dev) (void)hipFree(dev); if (host) (void)hipHostFree(host); if (cs) (void)hipStreamDestroy(cs); }
+    } b;
+    if (hipStreamCreateWithFlags(&b.cs, hipStreamNonBlocking) != hipSuccess) return fail("stream allocation failed");
     for (uint64_t k = d; k < n_ranges; k += N) {
       { std::lock_guard<std::mutex> lk(m); if (failed) return; }
       const simmr_range rg{k * chunk_units, std::min<uint64_t>(chunk_units, total_units - k * chunk_units)};
@@ -292,19 +299,39 @@ static int run_scope_devices(const std::vector<simmr_engine*>& engs, const std::
       const int rc = simmr_fastq_plan_direct(eng, args.read_header_format.c_str(), &nt.names, sc.id_base, &bytes);
       if (rc == SIMMR_ENOTSUP) return fail(std::string("--devices writes the text on the devices, and this run's headers need the host writer (") + simmr_last_error(eng) + "): use --device with --host-fastq");
       if (rc != SIMMR_OK) return fail(simmr_last_error(eng));
-      uint8_t* dst = bytes ? drain.buffer(0, bytes) : nullptr;
-      if (bytes && !dst) return fail("no device memory for " + std::to_string(bytes) + " bytes of FASTQ text: use a smaller --device-chunk-reads");
-      if (bytes && simmr_emit_fastq(eng, dst, bytes) != SIMMR_OK) return fail(simmr_last_error(eng));
-      if (!drain.submit(0, bytes, &err)) return fail(err);  // (the first piece starts its way to the host behind the emit)
+      if (bytes > b.dev_cap) {
+        if (b.dev) (void)hipFree(b.dev);
+        b.dev = nullptr; b.dev_cap = 0;
+        if (hipMalloc(&b.dev, bytes + bytes / 16 + 256) != hipSuccess) { (void)hipGetLastError(); return fail("no device memory for " + std::to_string(bytes) + " bytes of FASTQ text: use a smaller --device-chunk-reads"); }
+        b.dev_cap = bytes + bytes / 16 + 256;
+      }
+      if (bytes > b.host_cap) {
+        if (b.host) (void)hipHostFree(b.host);
+        b.host = nullptr; b.host_cap = 0;
+        if (hipHostMalloc(&b.host, bytes + bytes / 16 + 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail("no pinned host memory for " + std::to_string(bytes) + " bytes of FASTQ text"); }
+        b.host_cap = bytes + bytes / 16 + 256;
+      }
+      if (bytes) {
+        if (simmr_emit_fastq(eng, (uint8_t*)b.dev, bytes) != SIMMR_OK) return fail(simmr_last_error(eng));
+        // over this device's own link, now: the emit ran on the null stream of the device, the copy stream waits for it
+        hipEvent_t done = nullptr;
+        if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess || hipEventRecord(done, nullptr) != hipSuccess ||
+            hipStreamWaitEvent(b.cs, done, 0) != hipSuccess ||
+            hipMemcpyAsync(b.host, b.dev, bytes, hipMemcpyDeviceToHost, b.cs) != hipSuccess || hipStreamSynchronize(b.cs) != hipSuccess) {
+          if (done) (void)hipEventDestroy(done);
+          return fail("copy back failed");
+        }
+        (void)hipEventDestroy(done);
+      }
       {
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return failed || turn == k; });
         if (failed) return;
       }
-      const bool ok = drain.flush(&err);  // this thread owns the file until it passes the turn on
+      const bool ok = bytes == 0 || fwrite(b.host, 1, bytes, f) == bytes;  // this thread owns the file until it passes the turn on
       {
         std::lock_guard<std::mutex> lk(m);
-        if (!ok && !failed) { failed = true; first_error = "Failed to write reads to the output file: " + err; }
+        if (!ok && !failed) { failed = true; first_error = "Failed to write reads to the output file: short write"; }
         text_bytes += bytes;
         turn = k + 1;
       }
@@ -528,7 +555,8 @@ static int run_main(int argc, char** argv) {
 
   const uint64_t chunk_reads = args.device_chunk_reads;
   auto run = [&](const Scope& sc, uint64_t chunk_units) {
-    return engs.size() > 1 ? run_scope_devices(engs, ordinals, args, genomes, sc, chunk_units) : run_scope(eng, args, genomes, sc, chunk_units);
+    const uint64_t text_per_unit = sc.paired ? 2 * (2 * (uint64_t)args.read_length + 4 + 160) : 2 * 24000 + 260;  // (as the range sizes below)
+    return engs.size() > 1 ? run_scope_devices(engs, ordinals, args, genomes, sc, chunk_units, text_per_unit) : run_scope(eng, args, genomes, sc, chunk_units);
   };
   if (!is_long) {
     info("Simulating short reads");
