@@ -116,6 +116,7 @@ struct simmr_engine {
   DevBuf s_w_bytes, s_u_off64, s_m_genomes, s_u_contig, s_u_genome, s_u_seed, s_u_len, s_u_a, s_u_b, s_u_qs2, s_u_ms2, s_u_flags,
       s_u_off, s_u_order, s_d_err, s_d_runs, s_d_usable, s_ph_table;
   // measurement knobs, read ONCE when the engine is made (a stray variable cannot change a running engine's launches)
+  bool tl_debug = false;                // SIMMR_TL_DEBUG: print the occupancy of k_emit_text_lines launches
   bool inject_null_ctr_tables = false;  // SIMMR_FAULT_INJECT=null_ctr_tables: test switch, see custom_long_tables_missing
   int text_form = TEXT_FORM_DEFAULT;  // SIMMR_TEXT_FORM: 1 = the item form (k_emit_philox<TEXT>) always, 2 = the whole-line kernel (text_lines.hip) wherever it applies: same-box A/B
   uint32_t philox_wgs_per_cu = 128;  // SIMMR_PHILOX_WGS_PER_CU (item kernel), clamped to 1..4096.  More workgroups than the 4 per CU that
@@ -988,6 +989,7 @@ int simmr_engine_create(int device_ordinal, simmr_engine** out) {
         (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_FASTQ_GRID_MULT")) e->fastq_mult = (uint32_t)std::min<unsigned long long>(512, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_TEXT_FORM")) e->text_form = atoi(v);
+  e->tl_debug = getenv("SIMMR_TL_DEBUG") != nullptr;
   if (const char* v = getenv("SIMMR_FAULT_INJECT")) e->inject_null_ctr_tables = strcmp(v, "null_ctr_tables") == 0;
   if (const char* v = getenv("SIMMR_PHILOX_WGS_PER_CU")) e->philox_wgs_per_cu = (uint32_t)std::min<unsigned long long>(4096, std::max<unsigned long long>(1, strtoull(v, nullptr, 10)));
   if (const char* v = getenv("SIMMR_SPLICE_VARIANT")) e->splice_variant = atoi(v);
@@ -2320,7 +2322,7 @@ int simmr_emit_fastq(simmr_engine* e, uint8_t* dst, uint64_t dst_capacity) {
         HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(tk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl_lds));
         e->text_lines_lds_set[slot] = tl_lds;
       }
-      if (getenv("SIMMR_TL_DEBUG")) {  // (measurement aid: how many workgroups of this launch share a CU)
+      if (e->tl_debug) {  // (SIMMR_TL_DEBUG, measurement aid: how many workgroups of this launch share a CU)
         int per_cu = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tk, 256, tl_lds);
         fprintf(stderr, "k_emit_text_lines: dynamic LDS %u bytes (slot pitch %u), %d workgroups per CU, grid %u\n", tl_lds, tl_pitch, per_cu, grid);

@@ -28,7 +28,11 @@
 //   those two are stored bytewise.  Nothing waits for another wave between the two barriers of a header phase.
 //
 // Byte-identical to the item form by construction of the same draws (the item code below is k_emit_philox's), and
-// tested so: tests/test_gpu_fastq.py, tests/test_gpu_cli.py, tests/test_gpu_slots.py run both forms.
+// tested so: tests/test_gpu_text_lines.py compares the two forms byte for byte (read lengths 1-256, header shapes, N runs,
+// several genomes, perfect-short, exact-capacity destinations), tests/test_gpu_fullsize.py at 100 M reads.
+// MEASURED SLOWER than the item form (24.0 against 19.0-20.5 ms per 100 M reads: 7.6 instead of 15.6 L2 requests per read,
+// but 37 % more instructions on a path that is bound by instruction issue; LAB.md round 5): the
+// library runs it only when an engine is made with SIMMR_TEXT_FORM=2.
 // Covers: paired plans of the counter modes and perfect-short with every read <= TL_MAXL bases (the plan kernel notes
 // longer ones: SIMMR_NOTEBIT_LONGREAD) into a 16-byte-aligned buffer.  Everything else keeps the item form.
 #pragma once
